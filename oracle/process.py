@@ -1,0 +1,79 @@
+"""Oracle: DLPM noise schedule, Sigma recursion and the x_{t-1} update (CPU, torch fp32).
+
+TEST INFRASTRUCTURE ONLY.  Restates dlpm/methods/dlpm.py with per-sample scalars
+([T,B] tables) instead of the reference's fully expanded [T,B,C,H,W] tensors; for
+isotropic noise the arithmetic per element is identical (same fp32 op order).
+"""
+import math
+
+import numpy as np
+import torch
+
+
+def schedule(T, alpha, scale='scale_preserving'):
+    """gammas, bargammas, sigmas, barsigmas: dlpm/methods/dlpm.py:114-156 (linear time spacing :103-105)."""
+    ts = torch.arange(0, T, dtype=torch.float32)
+    if scale == 'scale_preserving':
+        f = torch.cos((ts / T + 0.008) / 1.008 * torch.pi / 2) ** 2
+        abar = f / f[0]
+        beta = 1 - abar / torch.cat([abar[:1], abar[:-1]])
+        g = (1 - beta) ** (1 / alpha)
+        bg = torch.cumprod(g, dim=0)
+        s = (1 - g ** alpha) ** (1 / alpha)
+        bs = (1 - bg ** alpha) ** (1 / alpha)
+        return g, bg, s, bs
+    raise NotImplementedError(scale)
+
+
+def sigma_table(A, g, s):
+    """Sigma_0 = s_0^2 A_0 ; Sigma_t = s_t^2 A_t + g_t^2 Sigma_{t-1}  (dlpm.py:230-239).  A: [T,B]."""
+    rows = [s[0] ** 2 * A[0]]
+    for t in range(1, A.shape[0]):
+        rows.append(s[t] ** 2 * A[t] + g[t] ** 2 * rows[-1])
+    return torch.stack(rows)
+
+
+def gamma_var(t, Sig, g):
+    """Gamma_t = 1 - g_t^2 Sigma_{t-1} / Sigma_t (dlpm.py:250-254); var = Gamma_t Sigma_{t-1} (:256-257)."""
+    Gam = 1 - (g[t] ** 2 * Sig[t - 1]) / Sig[t]
+    return Gam, Gam * Sig[t - 1]
+
+
+def _b(v, x):
+    return v.view(-1, *([1] * (x.dim() - 1)))
+
+
+def dlpm_step(x, eps, t, Sig, g, bs, z):
+    """mean = (x - bs_t Gamma_t eps)/g_t (dlpm.py:272-278); x' = mean + 1[t!=1] sqrt(var) z
+    (GenerativeLevyProcess.py:236-238)."""
+    Gam, var = gamma_var(t, Sig, g)
+    mean = (x - (bs[t] * _b(Gam, x)) * eps) / g[t]
+    mask = 0.0 if t == 1 else 1.0
+    return mean + (mask * torch.sqrt(_b(var, x))) * z, mean, var
+
+
+def dlim_step(x, eps, t, g, bs, eta=0.0, alpha=None, A=None, z=None):
+    """dlpm.py:281-297.  eta > 0 uses the per-sample A[t] (the reference's A[t] indexing with a
+    [B] tensor is shape-broken, see tools/make_fixtures.py f5 note); the diagonal is restated."""
+    if eta == 0.0:
+        return (x - bs[t] * eps) / g[t] + bs[t - 1] * eps
+    sig = eta * bs[t - 1]
+    out = (x - bs[t] * eps) / g[t]
+    out = out + (bs[t - 1] ** alpha - sig ** alpha) ** (1 / alpha) * eps
+    mask = 0.0 if t == 1 else 1.0
+    var = mask * sig ** 2 * A[t]
+    return out + torch.sqrt(_b(var, x)) * z
+
+
+def clipped_eps(x, eps, t, bg, bs):
+    """clip_denoised branch: xstart = ((x - eps bs_t)/bg_t).clamp(-1,1); eps' = (x - xstart bg_t)/bs_t
+    (GenerativeLevyProcess.py:186-207, dlpm.py:191-202)."""
+    xs = ((x - eps * bs[t]) / bg[t]).clamp(-1, 1)
+    return (x - xs * bg[t]) / bs[t]
+
+
+def generation_postprocess(x, is_image):
+    """bem/GenerationManager.py:50-63 + bem/datasets/__init__.py:108-109."""
+    c = 1.0 if is_image else 6.0
+    y = x.clamp(-c, c).cpu()
+    return (y + 1) / 2 if is_image else y

@@ -1,0 +1,89 @@
+"""Oracle: the reverse-time sampling loop (CPU) -- TEST INFRASTRUCTURE ONLY.
+
+Restates GenerativeLevyProcess.sample -> p_sample_loop / ddim_sample_loop
+(dlpm/methods/GenerativeLevyProcess.py:241-330, 365-452, 512-569) with the RNG
+consumption order of SURVEY.md 8c-bis:
+
+  1. A[k], k = 0..T-1     stream N: B uniforms then B exponentials per k, clamp_a applied
+  2. x_T = bs[T-1] * sqrt(a) * randn, a unclamped (Distributions.py:63-65), clamp_eps applied
+  3. i = T-1..1           stream P: B*D normals per step, also at i == 1 (masked)
+
+`model(x, t)` is any callable taking fp32 x and t = i/T floats.
+"""
+import numpy as np
+import torch
+
+from . import process as P
+from .rng import MT
+
+
+class Streams:
+    """The two process-global generators of the reference, as oracle MT19937 streams."""
+
+    def __init__(self, np_seed=0, torch_seed=0):
+        self.N = MT(np_seed)
+        self.P = MT(torch_seed)
+
+    def skewed_levy(self, alpha, B, clamp_a=None):
+        # gen_skewed_levy, isotropic: bem/datasets/Distributions.py:33-51
+        if alpha == 2.0:
+            return torch.full((B,), 2.0)
+        a = torch.tensor(self.N.skewed_levy(alpha, B), dtype=torch.float32)
+        if clamp_a is not None:
+            a = torch.clamp(a, 0.0, clamp_a)
+        return a
+
+    def randn(self, shape):
+        n = int(np.prod(shape))
+        return torch.from_numpy(self.P.torch_randn(n)).reshape(list(shape))
+
+
+def sample(model, shape, T, alpha, streams, deterministic=False, dlim_eta=0.0, clip_denoised=False,
+           clamp_a=None, clamp_eps=None, get_sample_history=False, trace=None):
+    B = shape[0]
+    g, bg, s, bs = P.schedule(T, alpha)
+    A = torch.stack([streams.skewed_levy(alpha, B, clamp_a) for _ in range(T)])    # dlpm.py:226-227
+    Sig = P.sigma_table(A, g, s)                                                    # dlpm.py:230-239
+    # x_T: GenerativeLevyProcess.py:313 -> gen_sas (own unclamped a, then randn, then clamp_eps)
+    a0 = streams.skewed_levy(alpha, B, None)
+    e = torch.sqrt(P._b(a0, torch.empty(shape))) * streams.randn(shape)
+    if clamp_eps is not None:
+        e = torch.clamp(e, -clamp_eps, clamp_eps)
+    x = bs[-1] * e
+    hist = [x]
+    if trace is not None:
+        trace.update(A=A, Sigmas=Sig, xT=x, z=[])
+    for i in range(T - 1, 0, -1):
+        t = torch.full((B,), i, dtype=torch.int64)
+        eps = model(x, t.float() * (1.0 / T))                                       # :92-96,180
+        if clip_denoised:
+            eps = P.clipped_eps(x, eps, i, bg, bs)
+        if deterministic:
+            z = streams.randn(shape) if dlim_eta != 0.0 else None
+            x = P.dlim_step(x, eps, i, g, bs, eta=dlim_eta, alpha=alpha, A=A, z=z)
+        else:
+            z = streams.randn(shape)
+            if trace is not None:
+                trace['z'].append(z)
+            x, _, _ = P.dlpm_step(x, eps, i, Sig, g, bs, z)
+        hist.append(x)
+    if get_sample_history:
+        return x, torch.stack(hist)
+    return x
+
+
+def sample_with_tables(model, shape, T, alpha, A, xT, zs, clip_denoised=False):
+    """Same loop with injected noise (A [T,B], x_T, z per step): the checker for the HIP sampler
+    when both are fed identical noise."""
+    g, bg, s, bs = P.schedule(T, alpha)
+    Sig = P.sigma_table(A, g, s)
+    x = xT
+    k = 0
+    for i in range(T - 1, 0, -1):
+        t = torch.full((shape[0],), float(i)) * (1.0 / T)
+        eps = model(x, t)
+        if clip_denoised:
+            eps = P.clipped_eps(x, eps, i, bg, bs)
+        x, _, _ = P.dlpm_step(x, eps, i, Sig, g, bs, zs[k])
+        k += 1
+    return x

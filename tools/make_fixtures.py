@@ -1,0 +1,450 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference).  Nothing from the
+reference is copied: the script imports it by path (with import-time stubs for
+torchvision / imageio / torchquad, none of which is called on the sampling
+path), feeds it seeded inputs and stores inputs + outputs as small .npz files.
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tools/make_fixtures.py
+
+Fixture families:
+  F1 schedule            DLPM.gen_noise_schedule                  dlpm/methods/dlpm.py:114-156
+  F2 skewed_levy, randn  gen_skewed_levy / torch.randn streams    bem/datasets/Distributions.py:33-73
+  F3 sigma_tables        compute_Sigmas / Gamma / Sigma_tilde     dlpm/methods/dlpm.py:230-257
+  F4 single_step         anterior_mean_variance_dlpm/_dlim, clip  dlpm/methods/dlpm.py:272-297
+  F5 trajectories        GenerativeLevyProcess.sample             dlpm/methods/GenerativeLevyProcess.py:512-569
+  F6 unet / mlp forward  UNetModel.forward, MLPModel.forward      dlpm/models/unet.py:463-492, Model.py:148-211
+  F7 layers              GroupNorm32, QKVAttention, embedding...  dlpm/models/unet.py, nn.py
+  F8 generation manager  clamp + inverse affine                   bem/GenerationManager.py:29-63
+"""
+import os
+import sys
+import hashlib
+
+sys.dont_write_bytecode = True
+from unittest.mock import MagicMock
+
+for _m in ['torchvision', 'torchvision.transforms', 'torchvision.transforms.functional',
+           'torchvision.datasets', 'torchvision.datasets.utils', 'torchvision.utils',
+           'imageio', 'torchquad']:
+    sys.modules[_m] = MagicMock()
+REF = os.environ.get('DLPM_REFERENCE', '/root/reference')
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+import yaml
+
+from dlpm.methods.GenerativeLevyProcess import GenerativeLevyProcess
+from dlpm.methods.dlpm import DLPM
+import dlpm.models.unet as ref_unet
+import dlpm.models.nn as ref_nn
+import dlpm.models.Model as ref_mlp
+from bem.GenerationManager import GenerationManager
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **conv)
+    print('wrote %-28s %8.1f kB' % (name + '.npz', os.path.getsize(path) / 1e3))
+
+
+# ----------------------------------------------------------------------------
+# synthetic-weights rule shared with the build (dlpm_amd.weights documents it):
+# the reference zero-initialises the last conv of every ResBlock, every
+# attention proj_out and out[2]; a random-init net therefore outputs exactly 0.
+# Fixtures re-draw those tensors N(0, std^2) and perturb the GroupNorm affine so
+# that every code path carries signal.
+# ----------------------------------------------------------------------------
+ZERO_SUFFIXES = ('out_layers.3.weight', 'out_layers.3.bias', 'proj_out.weight',
+                 'proj_out.bias', 'out.2.weight', 'out.2.bias')
+NORM_MARKERS = ('in_layers.0.', 'out_layers.0.', '.norm.', 'out.0.')
+
+
+def rerandomize(model, seed, std=0.02, perturb_norm=True):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith(ZERO_SUFFIXES):
+                p.copy_(torch.randn(p.shape, generator=g) * std)
+            elif perturb_norm and any(m in name for m in NORM_MARKERS):
+                if name.endswith('weight'):
+                    p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    return model
+
+
+def make_unet(in_ch, mc, mult, attn, heads, res):
+    # constructor arguments as dlpm/dlpm_experiment.py:38-56
+    return ref_unet.UNetModel(in_channels=in_ch, model_channels=mc, out_channels=in_ch,
+                              num_res_blocks=res, attention_resolutions=attn, dropout=0.0,
+                              channel_mult=mult, dims=2, num_classes=None, use_checkpoint=False,
+                              num_heads=heads, num_heads_upsample=-1, use_scale_shift_norm=True)
+
+
+def weight_digest(model):
+    h = hashlib.sha256()
+    for k, v in model.state_dict().items():
+        h.update(k.encode())
+        h.update(v.detach().cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+# ----------------------------------------------------------------------------
+def f1_schedule():
+    arrs = {}
+    for T, alpha in [(100, 1.7), (1000, 1.7), (1000, 1.8), (50, 1.7), (20, 1.5), (4000, 1.8), (1000, 2.0)]:
+        d = DLPM(alpha, 'cpu', T)
+        tag = 'T%d_a%s' % (T, str(alpha).replace('.', 'p'))
+        arrs[tag + '_g'] = d.gammas
+        arrs[tag + '_bg'] = d.bargammas
+        arrs[tag + '_s'] = d.sigmas
+        arrs[tag + '_bs'] = d.barsigmas
+    # rescale_diffusion path (dlpm.py:176-185)
+    d = DLPM(1.7, 'cpu', 4000)
+    d.rescale_diffusion(100)
+    arrs['rescaled_4000_to_100_a1p7_bg'] = d.bargammas
+    save('f1_schedule', **arrs)
+
+
+def f2_noise():
+    arrs = {}
+    for seed, alpha, n, clamp in [(0, 1.7, 4096, None), (1, 1.5, 4096, None), (2, 1.8, 4096, 10.0),
+                                  (3, 1.9, 4096, 20.0), (4, 2.0, 64, None), (5, 1.2, 1024, None)]:
+        tag = 's%d_a%s' % (seed, str(alpha).replace('.', 'p'))
+        np.random.seed(seed)
+        d = DLPM(alpha, 'cpu', 10)
+        if clamp is not None:
+            d.gen_a.setParams(clamp_a=clamp)
+        a = d.gen_a.generate(size=[n, 1, 2])[:, 0, 0]
+        a2 = d.gen_a.generate(size=[7, 1, 2])[:, 0, 0]  # stream continues
+        rs = np.random.RandomState(seed)
+        arrs[tag + '_U'] = rs.random_sample(n)
+        arrs[tag + '_W'] = rs.standard_exponential(n)
+        arrs[tag + '_a'] = a
+        arrs[tag + '_a_next7'] = a2
+        arrs[tag + '_meta'] = np.array([seed, alpha, n, -1.0 if clamp is None else clamp])
+    # non-isotropic draws (Distributions.py:47-48)
+    np.random.seed(11)
+    d = DLPM(1.7, 'cpu', 10, isotropic=False)
+    arrs['noniso_s11_a1p7'] = d.gen_a.generate(size=[3, 2, 4])
+    # gen_sas (x_T init): consumes N then P stream; a is UNclamped, eps clamped
+    np.random.seed(21)
+    torch.manual_seed(21)
+    d = DLPM(1.7, 'cpu', 10)
+    d.gen_eps.setParams(clamp_eps=3.0)
+    arrs['sas_s21_a1p7_clamp3'] = d.gen_eps.generate(size=[8, 3, 4, 4])
+    save('f2_skewed_levy', **arrs)
+
+    arrs = {}
+    for seed, sizes in [(0, [5, 16, 17, 1000]), (7, [3, 3, 40, 6149]), (123, [64, 1, 2, 15, 16, 31])]:
+        torch.manual_seed(seed)
+        for i, n in enumerate(sizes):
+            arrs['s%d_call%d_n%d' % (seed, i, n)] = torch.randn(n)
+    torch.manual_seed(5)
+    arrs['s5_like_2x3x4x4'] = torch.randn_like(torch.zeros(2, 3, 4, 4))
+    save('f2_randn', **arrs)
+
+
+def f3_tables():
+    rs = np.random.RandomState(42)
+    T, B = 100, 8
+    d = DLPM(1.7, 'cpu', T)
+    A = torch.tensor(np.abs(rs.standard_cauchy((T, B))).astype(np.float32) + 0.05)
+    d.A = A.clone()
+    d.compute_Sigmas()
+    Sig = d.Sigmas
+    Gam = torch.stack([d.compute_Gamma_t(t, Sig[t - 1], Sig[t]) for t in range(1, T)])
+    var = torch.stack([d.compute_Sigma_tilde_t_1(Gam[t - 1], Sig[t - 1]) for t in range(1, T)])
+    save('f3_sigma_tables', A=A, Sigmas=Sig, Gamma_1_to_T=Gam, var_1_to_T=var,
+         g=d.gammas, bs=d.barsigmas, s=d.sigmas, meta=np.array([T, B, 1.7]))
+
+
+def f4_single_step():
+    arrs = {}
+    torch.manual_seed(3)
+    np.random.seed(3)
+    T = 50
+    shape = [4, 3, 4, 4]
+    d = DLPM(1.7, 'cpu', T)
+    d.sample_A(shape, T)
+    d.compute_Sigmas()
+    arrs['A'] = d.A[:, :, 0, 0, 0]
+    arrs['g'], arrs['bg'], arrs['s'], arrs['bs'] = d.gammas, d.bargammas, d.sigmas, d.barsigmas
+    x = torch.randn(shape) * 3
+    eps = torch.randn(shape)
+    arrs['x'], arrs['eps'] = x, eps
+    for t in [1, 2, 17, 49]:
+        m, v = d.anterior_mean_variance_dlpm(x, torch.tensor(t), eps)
+        arrs['dlpm_mean_t%d' % t] = m
+        arrs['dlpm_var_t%d' % t] = v[:, 0, 0, 0]
+        m0, _ = d.anterior_mean_variance_dlim(x, torch.full((4,), t), eps, eta=0.0)
+        arrs['dlim0_t%d' % t] = m0
+        m5, v5 = d.anterior_mean_variance_dlim(x, torch.full((4,), t), eps, eta=0.5)
+        arrs['dlim05_mean_t%d' % t] = m5
+        # reference quirk: self.A[t] with a [B] tensor t yields [B,B,...] (dlpm.py:295); the
+        # intended per-sample variance is its diagonal
+        ar = torch.arange(4)
+        arrs['dlim05_var_t%d' % t] = v5[ar, ar, 0, 0, 0]
+        xs = d.predict_xstart(x, torch.full((4,), t), eps)
+        arrs['xstart_t%d' % t] = xs
+        arrs['eps_from_clipped_xstart_t%d' % t] = d.predict_eps(x, torch.full((4,), t), xs.clamp(-1, 1))
+    save('f4_single_step', **arrs)
+
+
+class _Recorder:
+    """Wraps torch.randn_like / gen_eps to record every draw of a sample() call."""
+
+    def __init__(self):
+        self.z = []
+
+    def __enter__(self):
+        self._orig = torch.randn_like
+        rec = self
+
+        def randn_like(x, *a, **k):
+            out = rec._orig(x, *a, **k)
+            rec.z.append(out.clone())
+            return out
+        torch.randn_like = randn_like
+        return self
+
+    def __exit__(self, *a):
+        torch.randn_like = self._orig
+
+
+class SynthModel(torch.nn.Module):
+    # eps = 0.5 x + t   (t arrives already divided by T: GenerativeLevyProcess.py:92-96,180)
+    def forward(self, x, t):
+        return 0.5 * x + t.view(-1, *([1] * (x.dim() - 1)))
+
+
+class ZeroModel(torch.nn.Module):
+    def forward(self, x, t):
+        return torch.zeros_like(x)
+
+
+def run_traj(name, model, shape, T, alpha, deterministic=False, eta=0.0, clamp_a=None, clamp_eps=None,
+             clip=False, extra=None):
+    np.random.seed(0)
+    torch.manual_seed(0)
+    meth = GenerativeLevyProcess(alpha=alpha, device='cpu', reverse_steps=T, rescale_timesteps=True)
+    with _Recorder() as rec:
+        x, hist = meth.sample({'default': model}, shape, T, deterministic=deterministic, dlim_eta=eta,
+                              clamp_a=clamp_a, clamp_eps=clamp_eps, clip_denoised=clip,
+                              get_sample_history=True)
+    nd = len(shape) - 1
+    idx = (slice(None), slice(None)) + (0,) * nd
+    arrs = dict(final=x, history=hist, A=meth.dlpm.A[idx], xT=hist[0],
+                meta=np.array([T, alpha, float(deterministic), eta,
+                               -1 if clamp_a is None else clamp_a, -1 if clamp_eps is None else clamp_eps,
+                               float(clip)]),
+                shape=np.array(shape))
+    if rec.z:
+        arrs['z'] = torch.stack(rec.z)
+    if extra:
+        arrs.update(extra)
+    save(name, **arrs)
+    return x
+
+
+def f5_trajectories():
+    run_traj('f5_traj_zero_toy', ZeroModel(), [4, 1, 2], 100, 1.7)
+    run_traj('f5_traj_synth_toy', SynthModel(), [4, 1, 2], 100, 1.7)
+    run_traj('f5_traj_synth_img', SynthModel(), [2, 3, 4, 4], 50, 1.7, clamp_a=10, clamp_eps=50)
+    run_traj('f5_traj_dlim_toy', SynthModel(), [4, 1, 2], 100, 1.7, deterministic=True, eta=0.0)
+    # no eta > 0 DLIM trajectory: the reference indexes self.A[t] with a [B] tensor
+    # (dlpm.py:295), which yields a [B,B,...] variance and breaks the loop's shapes for
+    # every B; the single-step diagonal in f4 pins the intended arithmetic instead.
+    run_traj('f5_traj_clip_img', SynthModel(), [2, 3, 4, 4], 30, 1.8, clamp_a=10, clamp_eps=50, clip=True)
+    run_traj('f5_traj_synth_img_big', SynthModel(), [4, 3, 8, 8], 20, 1.7, clamp_a=10, clamp_eps=50)
+
+    # real MLP (2d_data.yml), default torch init under manual_seed(1)
+    p = yaml.safe_load(open(os.path.join(REF, 'dlpm/configs/2d_data.yml')))
+    p['device'] = 'cpu'
+    torch.manual_seed(1)
+    mlp = ref_mlp.MLPModel(p)
+    mlp.eval()
+    sd = {'w__' + k: v for k, v in mlp.state_dict().items()}
+    run_traj('f5_traj_mlp_toy', mlp, [4, 1, 2], 100, 1.7, extra=sd)
+    # larger batch (n >= 16 randn path) short run with the MLP
+    run_traj('f5_traj_mlp_toy_b32', mlp, [32, 1, 2], 25, 1.7, extra=None)
+
+
+def f6_models():
+    # ---- MLP forward
+    p = yaml.safe_load(open(os.path.join(REF, 'dlpm/configs/2d_data.yml')))
+    p['device'] = 'cpu'
+    torch.manual_seed(1)
+    mlp = ref_mlp.MLPModel(p).eval()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(16, 1, 2, generator=g) * 2
+    t = torch.rand(16, generator=g)
+    with torch.inference_mode():
+        y = mlp(x, t)
+    arrs = {'w__' + k: v for k, v in mlp.state_dict().items()}
+    save('f6_mlp_forward', x=x, t=t, y=y, nparams=np.array(sum(q.numel() for q in mlp.parameters())), **arrs)
+
+    # ---- UNets: weights reproducible from (init seed, rerandomize seed); stored: io + digests
+    cfgs = {
+        'tiny':   dict(in_ch=3, mc=32, mult=[1, 2], attn=[2], heads=4, res=1, hw=16, B=2, store_w=True),
+        'tiny2':  dict(in_ch=1, mc=32, mult=[1, 2, 2], attn=[2, 4], heads=4, res=2, hw=16, B=3, store_w=False),
+        'mnist':  dict(in_ch=1, mc=32, mult=[1, 2, 2, 2], attn=[2, 4], heads=4, res=2, hw=32, B=2, store_w=False),
+        'cifar':  dict(in_ch=3, mc=128, mult=[1, 2, 2, 2], attn=[4, 8, 16], heads=4, res=2, hw=32, B=1, store_w=False),
+    }
+    for name, c in cfgs.items():
+        torch.manual_seed(1234)
+        net = make_unet(c['in_ch'], c['mc'], c['mult'], c['attn'], c['heads'], c['res']).eval()
+        digest_init = weight_digest(net)
+        rerandomize(net, 4321)
+        g = torch.Generator().manual_seed(77)
+        x = torch.randn(c['B'], c['in_ch'], c['hw'], c['hw'], generator=g)
+        t = torch.rand(c['B'], generator=g)
+        with torch.inference_mode():
+            y = net(x, t)
+            feats = net.get_feature_vectors(x, t)
+            # same t for the whole batch (the sampler's case)
+            t_same = torch.full((c['B'],), 0.37)
+            y_same = net(x, t_same)
+        arrs = dict(x=x, t=t, y=y, y_same_t=y_same, t_same=t_same,
+                    cfg=np.array([c['in_ch'], c['mc'], c['heads'], c['res'], c['hw'], c['B']]),
+                    mult=np.array(c['mult']), attn=np.array(c['attn']),
+                    digest_init=np.frombuffer(bytes.fromhex(digest_init), dtype=np.uint8),
+                    digest_final=np.frombuffer(bytes.fromhex(weight_digest(net)), dtype=np.uint8),
+                    nparams=np.array(sum(q.numel() for q in net.parameters())))
+        # per-block statistics for bisecting (mean, mean|.|, first 4 values)
+        stats = []
+        for grp in ('down', 'up'):
+            for f in feats[grp]:
+                stats.append([f.mean().item(), f.abs().mean().item()] + f.flatten()[:4].tolist())
+        f = feats['middle']
+        stats.append([f.mean().item(), f.abs().mean().item()] + f.flatten()[:4].tolist())
+        arrs['block_stats'] = np.array(stats, dtype=np.float64)
+        if c['store_w']:
+            # weights are NOT stored: they are reproducible from the two seeds and pinned by
+            # digest_init / digest_final (tests rebuild them and compare the digests)
+            for i, f in enumerate(feats['down']):
+                arrs['feat_down_%d' % i] = f
+            arrs['feat_middle'] = feats['middle']
+            for i, f in enumerate(feats['up']):
+                arrs['feat_up_%d' % i] = f
+        save('f6_unet_' + name, **arrs)
+
+
+def f7_layers():
+    arrs = {}
+    g = torch.Generator().manual_seed(5)
+    # timestep_embedding at fractional t (nn.py:103-121)
+    t = torch.tensor([0.0, 0.001, 0.37, 0.999, 1.0, 17.0])
+    for dim in (32, 128):
+        arrs['temb_dim%d' % dim] = ref_nn.timestep_embedding(t, dim)
+    arrs['temb_t'] = t
+    # GroupNorm32 (+SiLU) (+scale/shift)
+    for C, G, hw in [(32, 32, 8), (96, 32, 4), (128, 32, 8), (384, 32, 4)]:
+        gn = ref_nn.normalization(C, num_groups=min(32, C))
+        with torch.no_grad():
+            gn.weight.copy_(1 + 0.2 * torch.randn(C, generator=g))
+            gn.bias.copy_(0.2 * torch.randn(C, generator=g))
+        x = torch.randn(2, C, hw, hw, generator=g) * 2 + 0.5
+        sc = torch.randn(2, C, 1, 1, generator=g) * 0.3
+        sh = torch.randn(2, C, 1, 1, generator=g) * 0.3
+        y = gn(x)
+        tag = 'gn_C%d_hw%d' % (C, hw)
+        arrs[tag + '_x'], arrs[tag + '_w'], arrs[tag + '_b'] = x, gn.weight, gn.bias
+        arrs[tag + '_y'] = y
+        arrs[tag + '_y_silu'] = ref_nn.SiLU()(y)
+        arrs[tag + '_sc'], arrs[tag + '_sh'] = sc, sh
+        arrs[tag + '_y_ss_silu'] = ref_nn.SiLU()(y * (1 + sc) + sh)
+    # QKVAttention: head-major qkv layout after reshape(b*heads, 3*ch, T) (unet.py:224,243-250)
+    att = ref_unet.QKVAttention()
+    for ch, T in [(16, 64), (64, 16), (16, 256), (64, 64)]:
+        qkv = torch.randn(3, 3 * ch, T, generator=g)
+        arrs['qkv_ch%d_T%d_in' % (ch, T)] = qkv
+        arrs['qkv_ch%d_T%d_out' % (ch, T)] = att(qkv)
+    # ResBlock / AttentionBlock / Upsample / Downsample with stored weights
+    torch.manual_seed(8)
+    rb = ref_unet.ResBlock(32, 128, 0.0, out_channels=64, dims=2, use_scale_shift_norm=True).eval()
+    rerandomize(rb, 99)
+    with torch.no_grad():
+        rb.out_layers[3].weight.copy_(torch.randn(rb.out_layers[3].weight.shape, generator=g) * 0.05)
+        rb.out_layers[3].bias.copy_(torch.randn(64, generator=g) * 0.05)
+    x = torch.randn(2, 32, 8, 8, generator=g)
+    emb = torch.randn(2, 128, generator=g)
+    arrs['resblock_x'], arrs['resblock_emb'] = x, emb
+    arrs['resblock_y'] = rb(x, emb)
+    for k, v in rb.state_dict().items():
+        arrs['resblock_w__' + k] = v
+    ab = ref_unet.AttentionBlock(64, num_heads=4).eval()
+    with torch.no_grad():
+        ab.proj_out.weight.copy_(torch.randn(ab.proj_out.weight.shape, generator=g) * 0.1)
+        ab.proj_out.bias.copy_(torch.randn(64, generator=g) * 0.1)
+        ab.norm.weight.copy_(1 + 0.1 * torch.randn(64, generator=g))
+        ab.norm.bias.copy_(0.1 * torch.randn(64, generator=g))
+    x = torch.randn(2, 64, 4, 4, generator=g)
+    arrs['attnblock_x'] = x
+    arrs['attnblock_y'] = ab(x)
+    for k, v in ab.state_dict().items():
+        arrs['attnblock_w__' + k] = v
+    up = ref_unet.Upsample(32, True).eval()
+    dn = ref_unet.Downsample(32, True).eval()
+    x = torch.randn(2, 32, 4, 4, generator=g)
+    arrs['updown_x'] = x
+    arrs['up_y'] = up(x)
+    arrs['down_y'] = dn(up(x))
+    for k, v in up.state_dict().items():
+        arrs['up_w__' + k] = v
+    for k, v in dn.state_dict().items():
+        arrs['down_w__' + k] = v
+    with torch.no_grad():
+        arrs = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in arrs.items()}
+    save('f7_layers', **arrs)
+
+
+def f8_generation_manager():
+    class FakeMethod:
+        device = 'cpu'
+
+        def __init__(self, x):
+            self.x = x
+
+        def sample(self, shape, models, print_progression=False, get_sample_history=False, **kw):
+            self.kw = kw
+            self.shape = shape
+            if get_sample_history:
+                return self.x, torch.stack([self.x * 2, self.x])
+            return self.x
+    g = torch.Generator().manual_seed(2)
+    arrs = {}
+    for is_image, shape in [(True, [5, 3, 4, 4]), (False, [5, 1, 2])]:
+        x = torch.randn(shape, generator=g) * (2 if is_image else 8)
+        loader = [(torch.zeros([7] + shape[1:]), torch.zeros(7))]
+        gm = GenerationManager(FakeMethod(x), loader, is_image, reverse_steps=10, clamp_a=None)
+        gm.generate({'default': None}, 5)
+        tag = 'img' if is_image else 'toy'
+        arrs[tag + '_x'] = x
+        arrs[tag + '_samples'] = gm.samples
+        gm.generate({'default': None}, 5, get_sample_history=True)
+        arrs[tag + '_hist_samples'] = gm.samples
+        arrs[tag + '_history'] = gm.history
+    save('f8_generation_manager', **arrs)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8']
+    table = dict(f1=f1_schedule, f2=f2_noise, f3=f3_tables, f4=f4_single_step, f5=f5_trajectories,
+                 f6=f6_models, f7=f7_layers, f8=f8_generation_manager)
+    with torch.no_grad():
+        for w in which:
+            table[w]()
+    assert not any('__pycache__' in r for r, _, _ in os.walk(REF)), 'bytecode leaked into the reference tree'
