@@ -1,0 +1,68 @@
+"""Build libdlpm_amd.so (gfx950) in-tree with hipcc.
+
+    python -m dlpm_amd.build            # incremental: only stale objects are recompiled
+    python -m dlpm_amd.build --force
+
+hipcc cross-compiles without a GPU; the resulting .so travels to the GPU box with the snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(HERE, '_obj')
+LIB_DIR = os.path.join(HERE, 'lib')
+LIB = os.path.join(LIB_DIR, 'libdlpm_amd.so')
+SOURCES = ['host.cpp', 'noise.hip', 'conv_igemm.hip', 'conv_direct.hip', 'groupnorm.hip', 'attention.hip',
+           'embed.hip', 'unet.hip', 'mlp.hip', 'sampler.hip']
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    headers.append(os.path.join(HERE, '..', 'include', 'dlpm_amd.h'))
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.rsplit('.', 1)[0] + '.o')
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            jobs.append([HIPCC] + FLAGS + ['-x', 'hip', '-c', s, '-o', o])
+
+    def run(cmd):
+        if verbose:
+            print('[dlpm_amd.build]', os.path.basename(cmd[-3]), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed:\n%s\n%s' % (' '.join(cmd), r.stderr))
+        if r.stderr.strip() and verbose:
+            print(r.stderr)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or _stale(LIB, objs):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n%s' % r.stderr)
+        if verbose:
+            print('[dlpm_amd.build] linked', LIB)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

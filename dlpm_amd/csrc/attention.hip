@@ -1,0 +1,152 @@
+// attention.hip -- QKVAttention on the fp32 MFMA (v_mfma_f32_16x16x4_f32), softmax in fp32.
+//
+// Replaces QKVAttention.forward (dlpm/models/unet.py:236-250):
+//   w = softmax((q * s)(k * s)^T), s = ch^(-1/4);  out = w v
+// on qkv laid out NHWC [B, T, 3C] whose channel axis is head-major [head][q | k | v][ch] -- the
+// layout the reference's reshape(b*heads, 3*ch, T) + split produces (unet.py:224,243-244).
+//
+// One workgroup per (sample, head, block of 64 queries); K (pre-scaled) and V of the head are
+// staged once in LDS.  Each wave owns 16 queries and computes S^T = K Q^T tile by tile, which
+// leaves the query on the lane and the keys in registers: the row softmax is an in-register
+// reduction plus two cross-lane steps, and -- because the MFMA's k index may be permuted freely
+// as long as A and B agree -- the normalised probabilities are ALREADY in the A-operand layout of
+// the P V product.  No score matrix is ever written to LDS or HBM.
+#include "conv.h"
+
+namespace dlpm {
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int CH, int NT>
+__global__ void __launch_bounds__(256) k_attention(const float *__restrict__ qkv, float *__restrict__ out, int T, int C,
+                                                   int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int LD = CH + 4;
+    float *Ks = lds, *Vs = lds + (size_t)T * LD;
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int64_t rs = 3 * (int64_t)C;  // row stride of qkv
+    const float *base = qkv + (int64_t)b * T * rs + (int64_t)h * 3 * CH;
+
+    for (int idx = tid; idx < T * (CH / 4); idx += nthreads) {
+        const int s = idx / (CH / 4), c4 = (idx % (CH / 4)) * 4;
+        float4 k = *reinterpret_cast<const float4 *>(base + s * rs + CH + c4);
+        float4 v = *reinterpret_cast<const float4 *>(base + s * rs + 2 * CH + c4);
+        k.x *= scale; k.y *= scale; k.z *= scale; k.w *= scale;
+        *reinterpret_cast<float4 *>(Ks + s * LD + c4) = k;
+        *reinterpret_cast<float4 *>(Vs + s * LD + c4) = v;
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int t0 = (blockIdx.y * (nthreads >> 6) + wave) * 16;
+    if (t0 >= T) return;
+
+    float qf[CH / 4];
+#pragma unroll
+    for (int kk = 0; kk < CH / 4; kk++) qf[kk] = base[(int64_t)(t0 + li) * rs + 4 * kk + lk] * scale;
+
+    // S^T tiles: acc[j][r] = S[t0 + li][16 j + 4 lk + r]
+    floatx4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < CH / 4; kk++) {
+            const float a = Ks[(16 * j + li) * LD + 4 * kk + lk];
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qf[kk], acc[j], 0, 0, 0);
+        }
+    }
+
+    // softmax over the key axis (registers j, r and the 4 lane groups lk)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) mx = fmaxf(mx, acc[j][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            acc[j][r] = expf(acc[j][r] - mx);
+            sum += acc[j][r];
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[j][r] = acc[j][r] / sum;
+
+    // O = P V: MFMA step (j, r) contracts the keys s = 16 j + 4 lk + r over the 4 lane groups
+    float *orow = out + ((int64_t)b * T + t0) * C + (int64_t)h * CH;
+#pragma unroll
+    for (int ct = 0; ct < CH / 16; ct++) {
+        floatx4 o = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float vb = Vs[(16 * j + 4 * lk + r) * LD + 16 * ct + li];
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[j][r], vb, o, 0, 0, 0);
+            }
+        // D layout: row = 4 lk + r (query), col = li (channel)
+#pragma unroll
+        for (int r = 0; r < 4; r++) orow[(int64_t)(4 * lk + r) * C + 16 * ct + li] = o[r];
+    }
+}
+
+template <int CH, int NT>
+int launch_t(const float *qkv, float *out, int B, int T, int C, int heads, hipStream_t st) {
+    const int nw = (T / 16) < 4 ? (T / 16) : 4;
+    const size_t shmem = (size_t)2 * T * (CH + 4) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && shmem > 64 * 1024) {
+        DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attention<CH, NT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        attr_set = true;
+    }
+    const float scale = (float)(1.0 / std::sqrt(std::sqrt((double)CH)));
+    dim3 grid((unsigned)(B * heads), (unsigned)ceil_div(T / 16, nw));
+    k_attention<CH, NT><<<grid, 64 * nw, shmem, st>>>(qkv, out, T, C, heads, scale);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+template <int CH>
+int launch_ch(const float *qkv, float *out, int B, int T, int C, int heads, hipStream_t st) {
+    switch (T) {
+        case 16: return launch_t<CH, 1>(qkv, out, B, T, C, heads, st);
+        case 64: return launch_t<CH, 4>(qkv, out, B, T, C, heads, st);
+        case 256: return launch_t<CH, 16>(qkv, out, B, T, C, heads, st);
+        default:
+            set_error("attention: unsupported sequence length T=%d (supported: 16, 64, 256)", T);
+            return DLPM_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace
+
+int launch_attention(const float *qkv, float *out, int B, int T, int C, int heads, hipStream_t st) {
+    if (heads <= 0 || C % heads != 0) {
+        set_error("attention: channels %d not divisible by heads %d", C, heads);
+        return DLPM_ERR_ARG;
+    }
+    const int ch = C / heads;
+    ProfScope ps("attention", 4.0 * B * (double)T * T * C, 4.0 * 4.0 * B * (double)T * C, st);
+    switch (ch) {
+        case 16: return launch_ch<16>(qkv, out, B, T, C, heads, st);
+        case 32: return launch_ch<32>(qkv, out, B, T, C, heads, st);
+        case 64: return launch_ch<64>(qkv, out, B, T, C, heads, st);
+        case 128: return launch_ch<128>(qkv, out, B, T, C, heads, st);
+        default:
+            set_error("attention: unsupported head dim %d (supported: 16, 32, 64, 128)", ch);
+            return DLPM_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace dlpm

@@ -1,0 +1,50 @@
+// common.h -- shared helpers for libdlpm_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/dlpm_amd.h"
+
+namespace dlpm {
+
+void set_error(const char *fmt, ...);
+
+inline hipStream_t as_stream(dlpm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define DLPM_CHECK_ARG(cond, ...)                 \
+    do {                                          \
+        if (!(cond)) {                            \
+            ::dlpm::set_error(__VA_ARGS__);       \
+            return DLPM_ERR_ARG;                  \
+        }                                         \
+    } while (0)
+
+#define DLPM_HIP(expr)                                                                        \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            ::dlpm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                              __LINE__);                                                      \
+            return DLPM_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+#define DLPM_LAUNCH_CHECK() DLPM_HIP(hipGetLastError())
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Optional per-launch timing (dlpm_prof_enable): brackets one launch with HIP events on its stream.
+bool prof_enabled();
+struct ProfScope {
+    const char *name;
+    double flops, bytes;
+    hipStream_t st;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(const char *n, double fl, double by, hipStream_t s);
+    ~ProfScope();
+};
+
+}  // namespace dlpm

@@ -1,0 +1,43 @@
+// conv.h -- launch descriptors shared by the convolution kernels and the UNet plan.
+#pragma once
+#include "common.h"
+
+namespace dlpm {
+
+// One conv2d / conv1d(k=1) / Linear launch over NHWC fp32 activations.
+struct ConvLaunch {
+    const float *src0 = nullptr, *src1 = nullptr;  // virtual channel concat [src0 | src1]
+    int C0 = 0, C1 = 0;
+    int B = 0, Hin = 0, Win = 0, Hout = 0, Wout = 0;
+    int ks = 1, stride = 1, ups = 0;
+    const float *w = nullptr;      // igemm: [ks*ks][Cout][Cin]   direct: [ks*ks][Cin][Cout]
+    const float *bias = nullptr;   // [Cout] or null
+    const float *coefA = nullptr, *coefB = nullptr;  // [B, Cin] fused GroupNorm affine, or null
+    int act_silu = 0;
+    const float *res0 = nullptr, *res1 = nullptr;    // residual (virtual concat), NHWC at output size
+    int R0 = 0;
+    float *out = nullptr;
+    int Cout = 0;
+    int in_nchw = 0, out_nchw = 0;  // direct kernel only
+};
+
+// true when the MFMA implicit-GEMM kernel covers this shape
+bool igemm_supported(const ConvLaunch &c);
+int launch_conv_igemm(const ConvLaunch &c, hipStream_t st);
+int launch_conv_direct(const ConvLaunch &c, hipStream_t st);
+
+// weight re-layout kernels: OIHW -> [tap][Cout][Cin] (igemm) or [tap][Cin][Cout] (direct)
+int relayout_weight(const float *oihw_dev, float *dst_dev, int Cout, int Cin, int ks, bool for_igemm, hipStream_t st);
+
+int launch_gn_coeffs(const float *src0, const float *src1, int C0, int C1, int B, int HW, int groups,
+                     const float *gamma, const float *beta, const float *ss, int64_t ss_stride, int64_t ss_offset,
+                     float *coefA, float *coefB, hipStream_t st);
+int launch_attention(const float *qkv, float *out, int B, int T, int C, int heads, hipStream_t st);
+int launch_timestep_embedding(const float *t, float *emb, int64_t B, int dim, hipStream_t st);
+
+__device__ __forceinline__ float silu_f(float v) {
+    // x * sigmoid(x), sigmoid = 1/(1+exp(-x))  (nn.py:12-14)
+    return v / (1.0f + __expf(-v));
+}
+
+}  // namespace dlpm

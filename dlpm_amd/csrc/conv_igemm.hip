@@ -1,0 +1,243 @@
+// conv_igemm.hip -- conv3x3 / conv1x1 / Linear as an implicit GEMM on the gfx950 fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32, bitwise a k-ordered fmaf chain).
+//
+// Replaces F.conv2d (3x3 s1/s2, 1x1), conv1d(k=1) and F.linear on the UNet path:
+// dlpm/models/unet.py:64,96,143,157,168,213,215,336-338 -- 99.8 % of the path's FLOPs.
+//
+// GEMM view:  Out[m, n] = sum_{tap, c} Act(In[pix(m) + tap, c]) * W[tap][n][c]
+//   m = output pixel (b, oy, ox) flattened over NHWC, n = output channel, K = taps * Cin.
+// Workgroup tile 128 (pixels) x BN (channels), 4 waves (one per SIMD), K consumed in steps of
+// one tap x 32 channels.  Per step the A tile (128 x 32) is gathered from global memory with
+// the tap's spatial shift -- zero padding, stride 2, nearest-x2 upsampling and the two-pointer
+// "virtual concat" of the skip connection are all just address arithmetic there -- and the fused
+// GroupNorm affine + SiLU is applied on the way into LDS, so the normalised tensor never exists
+// in HBM.  Loop order is channel-chunk outer / tap inner: the 9 taps of a chunk re-read the same
+// input lines from L2.  LDS rows are padded to 36 floats so that the ds_read_b128 fragment loads
+// (lane -> pixel row, 4 consecutive k) are bank-conflict free.  The k order inside a 32-channel
+// step is permuted identically for A and B (lane half h reads channels 8j+4h..8j+4h+3), which
+// lets every fragment load be one 16-byte LDS read feeding 4 MFMAs.
+#include "conv.h"
+
+namespace dlpm {
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;     // pixels per workgroup tile
+constexpr int KC = 32;      // channels per K step
+constexpr int LDS_LD = 36;  // padded row length (floats)
+
+template <int BN, int WAVES_M, int WAVES_N, int RM, int RN>
+__global__ void __launch_bounds__(256) k_conv_igemm(ConvLaunch p) {
+    static_assert(WAVES_M * WAVES_N == 4 && WAVES_M * RM * 32 == BM && WAVES_N * RN * 32 == BN, "tile shape");
+    constexpr int NBF = BN / 8;          // floats of the W tile staged per thread (BN*32/256)
+    constexpr int NBV = NBF / 4;         // ... as float4s
+    constexpr int TPR = KC / NBF;        // threads per W row
+    constexpr int BUF = (BM + BN) * LDS_LD;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    const int Cin = p.C0 + p.C1;
+    const int ntaps = p.ks * p.ks, pad = p.ks >> 1;
+    const int HWo = p.Hout * p.Wout;
+    const int64_t M = (int64_t)p.B * HWo;
+    const int ntile_n = (p.Cout + BN - 1) / BN;
+    const int64_t m0 = (int64_t)(blockIdx.x / ntile_n) * BM;
+    const int n0 = (blockIdx.x % ntile_n) * BN;
+    const int Hi = p.ups ? p.Hin * 2 : p.Hin, Wi = p.ups ? p.Win * 2 : p.Win;
+
+    // ---- staging assignment: A row (pixel) and 16-channel segment of this thread
+    const int ra = tid >> 1, sega = (tid & 1) * 16;
+    const int64_t ma = m0 + ra;
+    const bool row_ok = ma < M;
+    int pb = 0, oy = 0, ox = 0;
+    if (row_ok) {
+        pb = (int)(ma / HWo);
+        int rem = (int)(ma - (int64_t)pb * HWo);
+        oy = rem / p.Wout;
+        ox = rem - oy * p.Wout;
+    }
+    const int rb = tid / TPR, segb = (tid % TPR) * NBF;
+    const bool wrow_ok = (n0 + rb) < p.Cout;
+
+    float4 xa[4], ca[4], cb[4], wb[NBV];
+    bool a_ok = false;
+    const bool has_coef = p.coefA != nullptr;
+
+    auto load_step = [&](int s) {
+        const int chunk = s / ntaps, tap = s - chunk * ntaps;
+        const int c0 = chunk * KC;
+        const int ky = tap / p.ks, kx = tap - ky * p.ks;
+        const int iy = oy * p.stride + ky - pad, ix = ox * p.stride + kx - pad;
+        a_ok = row_ok && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
+        const int c = c0 + sega;
+        if (a_ok) {
+            const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
+            const int64_t pix = ((int64_t)pb * p.Hin + sy) * p.Win + sx;
+            const float *src = (c < p.C0) ? p.src0 + pix * p.C0 + c : p.src1 + pix * p.C1 + (c - p.C0);
+#pragma unroll
+            for (int v = 0; v < 4; v++) xa[v] = reinterpret_cast<const float4 *>(src)[v];
+            if (has_coef) {
+                const float *pa = p.coefA + (int64_t)pb * Cin + c, *pbq = p.coefB + (int64_t)pb * Cin + c;
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    ca[v] = reinterpret_cast<const float4 *>(pa)[v];
+                    cb[v] = reinterpret_cast<const float4 *>(pbq)[v];
+                }
+            }
+        }
+        if (wrow_ok) {
+            const float *wp = p.w + ((int64_t)tap * p.Cout + (n0 + rb)) * Cin + c0 + segb;
+#pragma unroll
+            for (int v = 0; v < NBV; v++) wb[v] = reinterpret_cast<const float4 *>(wp)[v];
+        }
+    };
+
+    auto store_step = [&](int buf) {
+        float *As = smem + buf * BUF, *Bs = As + BM * LDS_LD;
+        float4 *da = reinterpret_cast<float4 *>(As + ra * LDS_LD + sega);
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_ok) {
+                x = xa[v];
+                if (has_coef) {
+                    x.x = fmaf(x.x, ca[v].x, cb[v].x);
+                    x.y = fmaf(x.y, ca[v].y, cb[v].y);
+                    x.z = fmaf(x.z, ca[v].z, cb[v].z);
+                    x.w = fmaf(x.w, ca[v].w, cb[v].w);
+                }
+                if (p.act_silu) {
+                    x.x = silu_f(x.x);
+                    x.y = silu_f(x.y);
+                    x.z = silu_f(x.z);
+                    x.w = silu_f(x.w);
+                }
+            }
+            da[v] = x;
+        }
+        float4 *db = reinterpret_cast<float4 *>(Bs + rb * LDS_LD + segb);
+#pragma unroll
+        for (int v = 0; v < NBV; v++) db[v] = wrow_ok ? wb[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+
+    floatx16 acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; i++)
+#pragma unroll
+        for (int j = 0; j < RN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int nsteps = (Cin / KC) * ntaps;
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+
+    for (int s = 0; s < nsteps; s++) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) load_step(s + 1);  // global loads in flight under the MFMAs below
+
+        const float *As = smem + buf * BUF, *Bs = As + BM * LDS_LD;
+        const float *ap = As + (wm * RM * 32 + l31) * LDS_LD + kh * 4;
+        const float *bp = Bs + (wn * RN * 32 + l31) * LDS_LD + kh * 4;
+#pragma unroll
+        for (int kk = 0; kk < KC / 8; kk++) {
+            float4 af[RM], bf[RN];
+#pragma unroll
+            for (int i = 0; i < RM; i++) af[i] = *reinterpret_cast<const float4 *>(ap + i * 32 * LDS_LD + kk * 8);
+#pragma unroll
+            for (int j = 0; j < RN; j++) bf[j] = *reinterpret_cast<const float4 *>(bp + j * 32 * LDS_LD + kk * 8);
+#pragma unroll
+            for (int i = 0; i < RM; i++)
+#pragma unroll
+                for (int j = 0; j < RN; j++) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (s + 1 < nsteps) store_step(buf ^ 1);  // buf^1 was last read in step s-1 (barrier since)
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const int R1 = p.Cout - p.R0;
+#pragma unroll
+    for (int j = 0; j < RN; j++) {
+        const int n = n0 + (wn * RN + j) * 32 + l31;
+        if (n >= p.Cout) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < RM; i++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (wm * RM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int64_t m = m0 + row;
+                if (m >= M) continue;
+                float v = acc[i][j][r] + bias;
+                if (p.res0) v += (n < p.R0) ? p.res0[m * p.R0 + n] : p.res1[m * R1 + (n - p.R0)];
+                p.out[m * p.Cout + n] = v;
+            }
+        }
+    }
+}
+
+__global__ void k_relayout_weight(const float *oihw, float *dst, int Cout, int Cin, int ks, int for_igemm) {
+    const int64_t n = (int64_t)Cout * Cin * ks * ks;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int taps = ks * ks;
+    int tap = (int)(i % taps);
+    int64_t r = i / taps;
+    int ci = (int)(r % Cin);
+    int co = (int)(r / Cin);
+    int64_t d = for_igemm ? ((int64_t)tap * Cout + co) * Cin + ci : ((int64_t)tap * Cin + ci) * Cout + co;
+    dst[d] = oihw[i];
+}
+
+}  // namespace
+
+bool igemm_supported(const ConvLaunch &c) {
+    const int Cin = c.C0 + c.C1;
+    if (c.in_nchw || c.out_nchw) return false;
+    if (Cin % KC != 0 || c.C0 % KC != 0) return false;
+    if (c.Cout < 16) return false;
+    if (c.ks != 1 && c.ks != 3) return false;
+    if (c.Cout % 4 != 0) return false;
+    return true;
+}
+
+int launch_conv_igemm(const ConvLaunch &c, hipStream_t st) {
+    const int64_t M = (int64_t)c.B * c.Hout * c.Wout;
+    const int64_t mt = ceil_div(M, BM);
+    const double K = (double)(c.C0 + c.C1) * c.ks * c.ks;
+    // algorithmic bytes: input once + weights once + output once (+ residual)
+    const double bytes = 4.0 * ((double)c.B * c.Hin * c.Win * (c.C0 + c.C1) + K * c.Cout + (double)M * c.Cout * (c.res0 ? 2 : 1));
+    ProfScope ps(c.ks == 3 ? "conv3x3_igemm" : "conv1x1_igemm", 2.0 * M * c.Cout * K, bytes, st);
+    if (c.Cout > 64) {
+        const int64_t grid = mt * ceil_div(c.Cout, 128);
+        k_conv_igemm<128, 2, 2, 2, 2><<<(unsigned)grid, 256, 0, st>>>(c);
+    } else if (c.Cout > 32) {
+        const int64_t grid = mt * ceil_div(c.Cout, 64);
+        k_conv_igemm<64, 2, 2, 2, 1><<<(unsigned)grid, 256, 0, st>>>(c);
+    } else {
+        const int64_t grid = mt * ceil_div(c.Cout, 32);
+        k_conv_igemm<32, 4, 1, 1, 1><<<(unsigned)grid, 256, 0, st>>>(c);
+    }
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+int relayout_weight(const float *oihw_dev, float *dst_dev, int Cout, int Cin, int ks, bool for_igemm, hipStream_t st) {
+    const int64_t n = (int64_t)Cout * Cin * ks * ks;
+    k_relayout_weight<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin, ks, for_igemm ? 1 : 0);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+}  // namespace dlpm

@@ -1,0 +1,103 @@
+// groupnorm.hip -- GroupNorm32 statistics folded into per-(sample, channel) affine coefficients.
+//
+// Replaces GroupNorm32.forward (dlpm/models/nn.py:17-19; 32 groups or C if smaller, eps 1e-5) and
+// the scale-shift modulation of ResBlock._forward (unet.py:187-191):
+//     y = GN(x) * (1 + scale) + shift  ==  x * A[b,c] + Bc[b,c]
+// The consumer convolution applies (A, Bc) (+ SiLU) while staging its input tile, so the
+// normalised activation is never written to HBM: this kernel only READS x (4 B/element, HBM/L2
+// bound) and writes 2*B*C floats.  x is NHWC and may be a virtual concat of two tensors (the
+// UNet skip connection, unet.py:489), whose groups can straddle the two sources.
+// Statistics are two-pass (mean, then centred sum of squares) in fp32, one workgroup per sample;
+// wavefront-level parallelism is over channels (coalesced rows) x pixel slices.
+#include "conv.h"
+
+namespace dlpm {
+namespace {
+
+__global__ void __launch_bounds__(512) k_gn_coeffs(const float *__restrict__ src0, const float *__restrict__ src1, int C0,
+                                                   int C1, int HW, int G, const float *__restrict__ gamma,
+                                                   const float *__restrict__ beta, const float *__restrict__ ss,
+                                                   int64_t ss_stride, int64_t ss_offset, float *__restrict__ coefA,
+                                                   float *__restrict__ coefB, float eps) {
+    extern __shared__ float sh[];
+    const int C = C0 + C1, cg = C / G;
+    const int nt = blockDim.x, tid = threadIdx.x;
+    const int nsl = (C <= nt) ? nt / C : 1;  // pixel slices
+    const int nwork = nsl * C;
+    float *partial = sh;                               // [max(nt, C)]
+    float *chan = sh + (nwork > nt ? nwork : nt);      // [C]
+    float *mean = chan + C;                            // [G]
+    float *rstd = mean + G;                            // [G]
+    const int b = blockIdx.x;
+    const float *x0 = src0 + (int64_t)b * HW * C0;
+    const float *x1 = src1 ? src1 + (int64_t)b * HW * C1 : nullptr;
+    const float inv_n = 1.0f / (float)((int64_t)cg * HW);
+
+    for (int pass = 0; pass < 2; pass++) {
+        for (int idx = tid; idx < nwork; idx += nt) {
+            const int c = idx % C, sl = idx / C;
+            const float *xp = (c < C0) ? x0 + c : x1 + (c - C0);
+            const int ld = (c < C0) ? C0 : C1;
+            const float mu = pass ? mean[c / cg] : 0.f;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int p = sl;
+            for (; p + 3 * nsl < HW; p += 4 * nsl) {
+                float v0 = xp[(int64_t)p * ld] - mu, v1 = xp[(int64_t)(p + nsl) * ld] - mu;
+                float v2 = xp[(int64_t)(p + 2 * nsl) * ld] - mu, v3 = xp[(int64_t)(p + 3 * nsl) * ld] - mu;
+                if (pass) { a0 = fmaf(v0, v0, a0); a1 = fmaf(v1, v1, a1); a2 = fmaf(v2, v2, a2); a3 = fmaf(v3, v3, a3); }
+                else { a0 += v0; a1 += v1; a2 += v2; a3 += v3; }
+            }
+            for (; p < HW; p += nsl) {
+                float v = xp[(int64_t)p * ld] - mu;
+                a0 = pass ? fmaf(v, v, a0) : a0 + v;
+            }
+            partial[idx] = (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += nt) {
+            float s = 0.f;
+            for (int sl = 0; sl < nsl; sl++) s += partial[sl * C + c];
+            chan[c] = s;
+        }
+        __syncthreads();
+        for (int g = tid; g < G; g += nt) {
+            float s = 0.f;
+            for (int c = g * cg; c < (g + 1) * cg; c++) s += chan[c];
+            if (pass) rstd[g] = 1.0f / sqrtf(s * inv_n + eps);
+            else mean[g] = s * inv_n;
+        }
+        __syncthreads();
+    }
+    for (int c = tid; c < C; c += nt) {
+        const int g = c / cg;
+        float a = rstd[g] * gamma[c];
+        float bb = beta[c] - mean[g] * a;
+        if (ss) {
+            const float sc = 1.0f + ss[(int64_t)b * ss_stride + ss_offset + c];
+            const float sft = ss[(int64_t)b * ss_stride + ss_offset + C + c];
+            a = a * sc;
+            bb = fmaf(bb, sc, sft);
+        }
+        coefA[(int64_t)b * C + c] = a;
+        coefB[(int64_t)b * C + c] = bb;
+    }
+}
+
+}  // namespace
+
+int launch_gn_coeffs(const float *src0, const float *src1, int C0, int C1, int B, int HW, int groups, const float *gamma,
+                     const float *beta, const float *ss, int64_t ss_stride, int64_t ss_offset, float *coefA,
+                     float *coefB, hipStream_t st) {
+    const int C = C0 + C1;
+    const int nt = 512;
+    const int nsl = (C <= nt) ? nt / C : 1;
+    const int nwork = nsl * C;
+    const size_t shmem = (size_t)((nwork > nt ? nwork : nt) + C + 2 * groups) * sizeof(float);
+    ProfScope ps("groupnorm_coeffs", 0.0, 4.0 * ((double)B * HW * C + 2.0 * B * C), st);  // reads x once (algorithmic)
+    k_gn_coeffs<<<(unsigned)B, nt, shmem, st>>>(src0, src1, C0, C1, HW, groups, gamma, beta, ss, ss_stride, ss_offset,
+                                               coefA, coefB, 1e-5f);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+}  // namespace dlpm

@@ -1,0 +1,314 @@
+// noise.hip -- everything on the sampling path that is not the score network:
+//   * Philox4x32-10 counter-based noise keyed by the GLOBAL sample index (sharding-invariant)
+//   * device Chambers-Mallows-Stuck draws of the skewed alpha/2-stable a_t  (dlpm.py:226-227)
+//   * x_T initialisation                                                     (GenerativeLevyProcess.py:313)
+//   * Sigma recursion -> per-(t, sample) coefficient tables                  (dlpm.py:230-257)
+//   * the fused x_{t-1} update                                               (dlpm.py:272-297, GLP.py:225-239)
+// All kernels are HBM/latency bound: coalesced 16-byte accesses over the flattened (B, D) state,
+// one coefficient pair per sample fetched through the scalar/L1 path.
+#include "common.h"
+#include "philox.h"
+
+using namespace dlpm;
+
+namespace {
+
+constexpr int kPurposeA = 1;       // rows of A[T,B]
+constexpr int kPurposeInitA = 2;   // the unclamped a of gen_sas
+constexpr int kPurposeInitZ = 3;   // x_T normals
+constexpr int kPurposeStepZ = 4;   // per-step normals
+
+// CMS in fp64, S1 parameterisation, beta = 1, stability a = alpha/2, as scipy's _rvs_Z1 "otherwise"
+// branch; U uniform(0,1), W standard exponential.
+__device__ inline double cms_skewed(double a, double zeta, double th0, double scale, double U, double W) {
+    const double pi = 3.141592653589793;
+    double th = U * pi + (-pi / 2.0);
+    double ath = a * th, c = cos(th), tg = tan(th);
+    double lead = W / (c / tan(a * (th0 + th)) + sin(th));
+    double core = (cos(ath) + sin(ath) * tg - zeta * (sin(ath) - cos(ath) * tg)) / W;
+    return lead * pow(core, 1.0 / a) * scale;
+}
+
+__device__ inline float draw_skewed(uint64_t seed, uint64_t gidx, uint32_t row, uint32_t purpose, double a,
+                                    double zeta, double th0, double scale) {
+    uint4 r = philox4x32_10(make_uint4((uint32_t)gidx, (uint32_t)(gidx >> 32), row, purpose), seed);  // step field 0
+    // 53-bit uniforms in (0,1): never 0 or 1, so th stays inside (-pi/2, pi/2) and W is finite
+    double U = ((double)(((uint64_t)r.x << 21) ^ (r.y >> 11)) + 0.5) * (1.0 / 9007199254740992.0);
+    double V = ((double)(((uint64_t)r.z << 21) ^ (r.w >> 11)) + 0.5) * (1.0 / 9007199254740992.0);
+    return (float)cms_skewed(a, zeta, th0, scale, U, -log(V));
+}
+
+__global__ void k_skewed_levy(float *A, int T, int64_t B, double alpha, float clamp_a, int has_clamp, uint64_t seed,
+                              int64_t off) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)T * B) return;
+    int t = (int)(i / B);
+    int64_t b = i - (int64_t)t * B;
+    float v;
+    if (alpha == 2.0) {
+        v = 2.0f;
+    } else {
+        const double pi = 3.141592653589793;
+        double a = alpha * 0.5, zeta = tan(pi * a * 0.5), th0 = atan(zeta) / a;
+        double scale = 2.0 * pow(cos(pi * alpha * 0.25), 2.0 / alpha);
+        v = draw_skewed(seed, (uint64_t)(off + b), (uint32_t)t, kPurposeA, a, zeta, th0, scale);
+        if (has_clamp) v = fminf(fmaxf(v, 0.0f), clamp_a);
+    }
+    A[i] = v;
+}
+
+// x_T[b, :] = bs_last * clamp(sqrt(a0[b]) * z)
+__global__ void k_init_state(float *x, int64_t B, int64_t D, double alpha, float clamp_eps, int has_clamp,
+                             float bs_last, uint64_t seed, int64_t off) {
+    int64_t nq = (D + 3) / 4;  // quads per sample
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * nq) return;
+    int64_t b = i / nq, q = i - b * nq;
+    float a0;
+    if (alpha == 2.0) {
+        a0 = 2.0f;
+    } else {
+        const double pi = 3.141592653589793;
+        double a = alpha * 0.5, zeta = tan(pi * a * 0.5), th0 = atan(zeta) / a;
+        double scale = 2.0 * pow(cos(pi * alpha * 0.25), 2.0 / alpha);
+        a0 = draw_skewed(seed, (uint64_t)(off + b), 0u, kPurposeInitA, a, zeta, th0, scale);
+    }
+    float sa = sqrtf(a0);
+    float4 z = philox_normal4(seed, (uint64_t)(off + b), (uint32_t)q, kPurposeInitZ, 0u);
+    float zz[4] = {z.x, z.y, z.z, z.w};
+    for (int j = 0; j < 4; j++) {
+        int64_t e = q * 4 + j;
+        if (e < D) {
+            float v = sa * zz[j];
+            if (has_clamp) v = fminf(fmaxf(v, -clamp_eps), clamp_eps);
+            x[b * D + e] = bs_last * v;
+        }
+    }
+}
+
+// One thread per sample walks t = 0..T-1 (a scan over t; T*B FMAs in total).
+__global__ void k_coeff_tables(const float *A, const float *g, const float *s, const float *bs, int T, int64_t B,
+                               float *c_eps, float *c_noise, float *sig_out) {
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float prev = (s[0] * s[0]) * A[b];  // Sigma_0 = s_0^2 A_0
+    if (sig_out) sig_out[b] = prev;
+    c_eps[b] = 0.f;
+    c_noise[b] = 0.f;
+    for (int t = 1; t < T; t++) {
+        float gt = g[t], st = s[t];
+        float g2 = gt * gt;
+        // no contraction: the reference rounds each product (dlpm.py:238,253)
+        float cur = __fadd_rn(__fmul_rn(st * st, A[(int64_t)t * B + b]), __fmul_rn(g2, prev));
+        float Gam = 1.0f - __fdiv_rn(__fmul_rn(g2, prev), cur);
+        float var = __fmul_rn(Gam, prev);
+        c_eps[(int64_t)t * B + b] = __fmul_rn(bs[t], Gam);
+        c_noise[(int64_t)t * B + b] = (t == 1) ? 0.0f : __fsqrt_rn(var);
+        if (sig_out) sig_out[(int64_t)t * B + b] = cur;
+        prev = cur;
+    }
+}
+
+struct StepScalars {
+    float g, bg, bs, bs_prev;
+};
+
+__device__ inline float clip_eps(float x, float e, const StepScalars &c) {
+    // predict_xstart -> clamp -> predict_eps (dlpm.py:191-202)
+    float xs = __fdiv_rn(x - __fmul_rn(e, c.bs), c.bg);
+    xs = fminf(fmaxf(xs, -1.0f), 1.0f);
+    return __fdiv_rn(x - __fmul_rn(xs, c.bg), c.bs);
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) k_update(dlpm_update_args p) {
+    const int t = *p.t_dev;
+    StepScalars c{p.g_dev[t], p.bg_dev[t], p.bs_dev[t], p.bs_dev[t > 0 ? t - 1 : 0]};
+    const bool dlim = p.flags & DLPM_UPD_DLIM, clip = p.flags & DLPM_UPD_CLIP;
+    const int64_t D = p.D;
+    const int64_t nq = VEC ? D / 4 : D;          // work items per sample
+    const int64_t total = p.B * nq;
+    // DLIM eta > 0 extra mean coefficient: (bs_{t-1}^alpha - (eta bs_{t-1})^alpha)^(1/alpha)
+    float dl_mean = c.bs_prev, dl_sig = 0.f;
+    if (dlim && p.dlim_eta != 0.0f) {
+        dl_sig = p.dlim_eta * c.bs_prev;
+        dl_mean = powf(powf(c.bs_prev, p.alpha) - powf(dl_sig, p.alpha), 1.0f / p.alpha);
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / nq, q = i - b * nq;
+        float ce, cn;
+        if (!dlim) {
+            ce = p.c_eps_dev[(int64_t)t * p.B + b];
+            cn = p.c_noise_dev[(int64_t)t * p.B + b];
+        } else {
+            ce = c.bs;
+            cn = (p.dlim_eta != 0.0f && t != 1) ? dl_sig * sqrtf(p.A_dev[(int64_t)t * p.B + b]) : 0.0f;
+        }
+        if (VEC) {
+            const int64_t base = b * D + q * 4;
+            float4 x = *reinterpret_cast<const float4 *>(p.x_dev + base);
+            float4 e = *reinterpret_cast<const float4 *>(p.eps_dev + base);
+            float4 z;
+            if (p.z_dev) z = *reinterpret_cast<const float4 *>(p.z_dev + base);
+            else if (cn != 0.0f) z = philox_normal4(p.seed, (uint64_t)(p.sample_offset + b), (uint32_t)q, kPurposeStepZ, (uint32_t)t);
+            else z = make_float4(0.f, 0.f, 0.f, 0.f);
+            float xv[4] = {x.x, x.y, x.z, x.w}, ev[4] = {e.x, e.y, e.z, e.w}, zv[4] = {z.x, z.y, z.z, z.w}, o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float ee = clip ? clip_eps(xv[j], ev[j], c) : ev[j];
+                float m = __fdiv_rn(xv[j] - __fmul_rn(ce, ee), c.g);
+                if (dlim) m = __fadd_rn(m, __fmul_rn(dl_mean, ee));
+                o[j] = __fadd_rn(m, __fmul_rn(cn, zv[j]));
+            }
+            *reinterpret_cast<float4 *>(p.x_dev + base) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+            const int64_t idx = b * D + q;
+            float xv = p.x_dev[idx], ev = p.eps_dev[idx], zv;
+            if (p.z_dev) zv = p.z_dev[idx];
+            else if (cn == 0.0f) zv = 0.0f;
+            else {
+                float4 z = philox_normal4(p.seed, (uint64_t)(p.sample_offset + b), (uint32_t)(q >> 2), kPurposeStepZ, (uint32_t)t);
+                float zz[4] = {z.x, z.y, z.z, z.w};
+                zv = zz[q & 3];
+            }
+            float ee = clip ? clip_eps(xv, ev, c) : ev;
+            float m = __fdiv_rn(xv - __fmul_rn(ce, ee), c.g);
+            if (dlim) m = __fadd_rn(m, __fmul_rn(dl_mean, ee));
+            p.x_dev[idx] = __fadd_rn(m, __fmul_rn(cn, zv));
+        }
+    }
+}
+
+__global__ void k_advance(int32_t *t) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *t = *t - 1;
+}
+
+__global__ void k_fill_t(float *tv, const int32_t *t, int32_t T, int64_t B) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) tv[i] = __fmul_rn((float)(*t), 1.0f / (float)T);  // t.float() * (1.0 / T)
+}
+
+__global__ void k_postprocess(const float *x, float *o, int64_t n, float c, int affine) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = fminf(fmaxf(x[i], -c), c);
+    o[i] = affine ? __fdiv_rn(v + 1.0f, 2.0f) : v;
+}
+
+__global__ void k_nchw_to_nhwc(const float *src, float *dst, int B, int C, int HW) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t n = (int64_t)B * C * HW;
+    if (i >= n) return;
+    int c = (int)(i % C);
+    int64_t r = i / C;
+    int p = (int)(r % HW);
+    int64_t b = r / HW;
+    dst[i] = src[(b * C + c) * HW + p];
+}
+
+__global__ void k_nhwc_to_nchw(const float *src, float *dst, int B, int C, int HW) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t n = (int64_t)B * C * HW;
+    if (i >= n) return;
+    int p = (int)(i % HW);
+    int64_t r = i / HW;
+    int c = (int)(r % C);
+    int64_t b = r / C;
+    dst[i] = src[(b * HW + p) * C + c];
+}
+
+}  // namespace
+
+extern "C" int dlpm_skewed_levy_philox_f32(float *A_dev, int T, int64_t B, double alpha, double clamp_a, uint64_t seed,
+                                           int64_t sample_offset, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(A_dev && T > 0 && B > 0, "dlpm_skewed_levy_philox_f32: bad shape T=%d B=%lld", T, (long long)B);
+    DLPM_CHECK_ARG(alpha > 0.0 && alpha <= 2.0, "Wrong value of alpha (%g) for skewed levy r.v generation", alpha);
+    int64_t n = (int64_t)T * B;
+    k_skewed_levy<<<(unsigned)ceil_div(n, 256), 256, 0, as_stream(stream)>>>(A_dev, T, B, alpha, (float)clamp_a,
+                                                                            clamp_a >= 0.0, seed, sample_offset);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_init_state_philox_f32(float *x_dev, int64_t B, int64_t D, double alpha, double clamp_eps,
+                                          float barsigma_last, uint64_t seed, int64_t sample_offset,
+                                          dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(x_dev && B > 0 && D > 0, "dlpm_init_state_philox_f32: bad shape");
+    DLPM_CHECK_ARG(alpha > 0.0 && alpha <= 2.0, "Wrong value of alpha (%g) for skewed levy r.v generation", alpha);
+    int64_t n = B * ((D + 3) / 4);
+    k_init_state<<<(unsigned)ceil_div(n, 256), 256, 0, as_stream(stream)>>>(x_dev, B, D, alpha, (float)clamp_eps,
+                                                                           clamp_eps >= 0.0, barsigma_last, seed,
+                                                                           sample_offset);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_coeff_tables_f32(const float *A_dev, const float *g_dev, const float *s_dev, const float *bs_dev,
+                                     int T, int64_t B, float *c_eps_dev, float *c_noise_dev, float *sigmas_out_dev,
+                                     dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(A_dev && g_dev && s_dev && bs_dev && c_eps_dev && c_noise_dev, "dlpm_coeff_tables_f32: null pointer");
+    DLPM_CHECK_ARG(T >= 2 && B > 0, "dlpm_coeff_tables_f32: bad shape T=%d B=%lld", T, (long long)B);
+    k_coeff_tables<<<(unsigned)ceil_div(B, 64), 64, 0, as_stream(stream)>>>(A_dev, g_dev, s_dev, bs_dev, T, B, c_eps_dev,
+                                                                          c_noise_dev, sigmas_out_dev);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_update_f32(const dlpm_update_args *a, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(a && a->x_dev && a->eps_dev && a->t_dev && a->g_dev && a->bg_dev && a->bs_dev,
+                   "dlpm_update_f32: null pointer");
+    DLPM_CHECK_ARG(a->B > 0 && a->D > 0 && a->T >= 2, "dlpm_update_f32: bad shape");
+    if (!(a->flags & DLPM_UPD_DLIM))
+        DLPM_CHECK_ARG(a->c_eps_dev && a->c_noise_dev, "dlpm_update_f32: DLPM step needs the coefficient tables");
+    else if (a->dlim_eta != 0.0f)
+        DLPM_CHECK_ARG(a->A_dev, "dlpm_update_f32: DLIM with eta > 0 needs A");
+    const bool vec = (a->D % 4 == 0) && ((reinterpret_cast<uintptr_t>(a->x_dev) | reinterpret_cast<uintptr_t>(a->eps_dev) |
+                                          reinterpret_cast<uintptr_t>(a->z_dev)) % 16 == 0);
+    int64_t items = a->B * (vec ? a->D / 4 : a->D);
+    // memory-bound: cap the grid at 8 blocks per CU and grid-stride the rest
+    unsigned grid = (unsigned)std::min<int64_t>(ceil_div(items, 256), 256 * 8);
+    // algorithmic bytes: read x, read eps, write x (+ read z when injected)
+    ProfScope ps("update", 0.0, 4.0 * (double)a->B * a->D * (a->z_dev ? 4 : 3), as_stream(stream));
+    if (vec) k_update<true><<<grid, 256, 0, as_stream(stream)>>>(*a);
+    else k_update<false><<<grid, 256, 0, as_stream(stream)>>>(*a);
+    DLPM_LAUNCH_CHECK();
+    if (a->flags & DLPM_UPD_ADVANCE) {
+        k_advance<<<1, 64, 0, as_stream(stream)>>>(const_cast<int32_t *>(a->t_dev));
+        DLPM_LAUNCH_CHECK();
+    }
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_fill_scaled_t_f32(float *tvec_dev, const int32_t *t_dev, int32_t T, int64_t B, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(tvec_dev && t_dev && T > 0 && B > 0, "dlpm_fill_scaled_t_f32: bad argument");
+    k_fill_t<<<(unsigned)ceil_div(B, 256), 256, 0, as_stream(stream)>>>(tvec_dev, t_dev, T, B);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_postprocess_f32(const float *x_dev, float *out_dev, int64_t n, float clamp, int affine,
+                                    dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(x_dev && out_dev && n > 0, "dlpm_postprocess_f32: bad argument");
+    k_postprocess<<<(unsigned)ceil_div(n, 256), 256, 0, as_stream(stream)>>>(x_dev, out_dev, n, clamp, affine);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_nchw_to_nhwc_f32(const float *src, float *dst, int32_t B, int32_t C, int32_t H, int32_t W,
+                                     dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "dlpm_nchw_to_nhwc_f32: bad argument");
+    int64_t n = (int64_t)B * C * H * W;
+    k_nchw_to_nhwc<<<(unsigned)ceil_div(n, 256), 256, 0, as_stream(stream)>>>(src, dst, B, C, H * W);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_nhwc_to_nchw_f32(const float *src, float *dst, int32_t B, int32_t C, int32_t H, int32_t W,
+                                     dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "dlpm_nhwc_to_nchw_f32: bad argument");
+    int64_t n = (int64_t)B * C * H * W;
+    k_nhwc_to_nchw<<<(unsigned)ceil_div(n, 256), 256, 0, as_stream(stream)>>>(src, dst, B, C, H * W);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}

@@ -1,0 +1,219 @@
+// sampler.hip -- the reverse-time loop x_T -> x_0 as a replayed hipGraph.
+//
+// Replaces p_sample_loop_progressive / ddim_sample_loop_progressive
+// (dlpm/methods/GenerativeLevyProcess.py:291-330, 418-452).  One reverse step is
+//     tvec <- t/T ; eps <- model(x, tvec) ; x <- update(x, eps, tables[t]) ; t <- t - 1
+// Every per-step scalar is read from device tables indexed by a device-resident step counter, so
+// the captured graph of ONE step is replayed T-1 times with no host patching in between.
+#include <vector>
+
+#include "common.h"
+
+using namespace dlpm;
+
+extern "C" int dlpm_mlp_forward(dlpm_mlp *, const float *, const float *, float *, int64_t, dlpm_stream_t);
+
+struct dlpm_sampler {
+    dlpm_sampler_config cfg;
+    int64_t D = 0;
+    float *g = nullptr, *bg = nullptr, *s = nullptr, *bs = nullptr;  // device schedule [T]
+    float bs_last = 0.f;
+    float *A = nullptr, *c_eps = nullptr, *c_noise = nullptr;         // [T,B]
+    float *x = nullptr, *eps = nullptr, *tvec = nullptr;
+    int32_t *t_dev = nullptr;
+    void *ws = nullptr;
+    int64_t ws_bytes = 0;
+    int32_t t_host = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+namespace {
+
+__global__ void k_set_t(int32_t *t, int32_t v) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *t = v;
+}
+
+#define TRY(expr)                     \
+    do {                              \
+        int _r = (expr);              \
+        if (_r != DLPM_OK) return _r; \
+    } while (0)
+
+int model_forward(dlpm_sampler *s, hipStream_t st) {
+    if (s->cfg.unet)
+        return dlpm_unet_forward(s->cfg.unet, s->x, s->tvec, s->eps, s->cfg.B, s->ws, s->ws_bytes, st);
+    return dlpm_mlp_forward(s->cfg.mlp, s->x, s->tvec, s->eps, s->cfg.B, st);
+}
+
+int one_step(dlpm_sampler *s, const float *z, bool advance, hipStream_t st) {
+    TRY(dlpm_fill_scaled_t_f32(s->tvec, s->t_dev, s->cfg.T, s->cfg.B, st));
+    TRY(model_forward(s, st));
+    dlpm_update_args a{};
+    a.x_dev = s->x; a.eps_dev = s->eps; a.z_dev = z; a.t_dev = s->t_dev;
+    a.g_dev = s->g; a.bg_dev = s->bg; a.bs_dev = s->bs;
+    a.c_eps_dev = s->c_eps; a.c_noise_dev = s->c_noise; a.A_dev = s->A;
+    a.B = s->cfg.B; a.D = s->D; a.T = s->cfg.T;
+    a.flags = (s->cfg.flags & (DLPM_UPD_DLIM | DLPM_UPD_CLIP)) | (advance ? DLPM_UPD_ADVANCE : 0);
+    a.dlim_eta = s->cfg.dlim_eta; a.alpha = (float)s->cfg.alpha;
+    a.seed = s->cfg.seed; a.sample_offset = s->cfg.sample_offset;
+    return dlpm_update_f32(&a, st);
+}
+
+int build_tables(dlpm_sampler *s, hipStream_t st) {
+    TRY(dlpm_coeff_tables_f32(s->A, s->g, s->s, s->bs, s->cfg.T, s->cfg.B, s->c_eps, s->c_noise, nullptr, st));
+    k_set_t<<<1, 64, 0, st>>>(s->t_dev, s->cfg.T - 1);
+    DLPM_LAUNCH_CHECK();
+    s->t_host = s->cfg.T - 1;
+    return DLPM_OK;
+}
+
+}  // namespace
+
+extern "C" int dlpm_sampler_create(const dlpm_sampler_config *cfg, dlpm_sampler **out) {
+    DLPM_CHECK_ARG(cfg && out, "dlpm_sampler_create: null argument");
+    DLPM_CHECK_ARG((cfg->unet != nullptr) != (cfg->mlp != nullptr), "dlpm_sampler_create: exactly one of unet / mlp");
+    DLPM_CHECK_ARG(cfg->B > 0 && cfg->C > 0 && cfg->H > 0 && cfg->W > 0, "dlpm_sampler_create: bad shape");
+    DLPM_CHECK_ARG(cfg->T >= 2, "dlpm_sampler_create: reverse_steps must be >= 2, got %d", cfg->T);
+    DLPM_CHECK_ARG(cfg->alpha > 0.0 && cfg->alpha <= 2.0, "Wrong value of alpha (%g) for skewed levy r.v generation", cfg->alpha);
+    const bool have = cfg->g && cfg->bg && cfg->s && cfg->bs;
+    DLPM_CHECK_ARG(have || (!cfg->g && !cfg->bg && !cfg->s && !cfg->bs), "dlpm_sampler_create: give all four schedule arrays or none");
+    dlpm_sampler *s = new dlpm_sampler();
+    s->cfg = *cfg;
+    s->D = (int64_t)cfg->C * cfg->H * cfg->W;
+    const int T = cfg->T;
+    const int64_t B = cfg->B;
+    std::vector<float> hg(T), hbg(T), hs(T), hbs(T);
+    if (have) {
+        for (int i = 0; i < T; i++) { hg[i] = cfg->g[i]; hbg[i] = cfg->bg[i]; hs[i] = cfg->s[i]; hbs[i] = cfg->bs[i]; }
+    } else {
+        int r = dlpm_schedule_f32(T, cfg->alpha, hg.data(), hbg.data(), hs.data(), hbs.data());
+        if (r != DLPM_OK) { delete s; return r; }
+    }
+    s->cfg.g = s->cfg.bg = s->cfg.s = s->cfg.bs = nullptr;  // host pointers are not retained
+    s->bs_last = hbs[T - 1];
+    auto fail = [&](hipError_t e) {
+        set_error("dlpm_sampler_create: %s", hipGetErrorString(e));
+        dlpm_sampler_destroy(s);
+        return DLPM_ERR_HIP;
+    };
+    hipError_t e;
+    float **sched[4] = {&s->g, &s->bg, &s->s, &s->bs};
+    std::vector<float> *hsrc[4] = {&hg, &hbg, &hs, &hbs};
+    for (int i = 0; i < 4; i++) {
+        if ((e = hipMalloc(sched[i], T * sizeof(float))) != hipSuccess) return fail(e);
+        if ((e = hipMemcpy(*sched[i], hsrc[i]->data(), T * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    }
+    const size_t tb = (size_t)T * B * sizeof(float);
+    if ((e = hipMalloc(&s->A, tb)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&s->c_eps, tb)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&s->c_noise, tb)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&s->x, (size_t)B * s->D * sizeof(float))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&s->eps, (size_t)B * s->D * sizeof(float))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&s->tvec, (size_t)B * sizeof(float))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&s->t_dev, sizeof(int32_t))) != hipSuccess) return fail(e);
+    if (cfg->unet) {
+        s->ws_bytes = dlpm_unet_workspace_bytes(cfg->unet, B);
+        if (s->ws_bytes < 0) {
+            dlpm_sampler_destroy(s);
+            return DLPM_ERR_STATE;
+        }
+        if ((e = hipMalloc(&s->ws, (size_t)s->ws_bytes)) != hipSuccess) return fail(e);
+    }
+    *out = s;
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_sampler_reseed(dlpm_sampler *s, uint64_t seed, int64_t sample_offset) {
+    DLPM_CHECK_ARG(s, "dlpm_sampler_reseed: null handle");
+    if (seed == s->cfg.seed && sample_offset == s->cfg.sample_offset) return DLPM_OK;
+    s->cfg.seed = seed;
+    s->cfg.sample_offset = sample_offset;
+    // the Philox key is a kernel argument baked into the captured update node: recapture lazily
+    if (s->exec) (void)hipGraphExecDestroy(s->exec);
+    if (s->graph) (void)hipGraphDestroy(s->graph);
+    s->exec = nullptr;
+    s->graph = nullptr;
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_sampler_begin(dlpm_sampler *s, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(s, "dlpm_sampler_begin: null handle");
+    hipStream_t st = as_stream(stream);
+    const dlpm_sampler_config &c = s->cfg;
+    TRY(dlpm_skewed_levy_philox_f32(s->A, c.T, c.B, c.alpha, c.clamp_a, c.seed, c.sample_offset, st));
+    TRY(dlpm_init_state_philox_f32(s->x, c.B, s->D, c.alpha, c.clamp_eps, s->bs_last, c.seed, c.sample_offset, st));
+    return build_tables(s, st);
+}
+
+extern "C" int dlpm_sampler_begin_injected(dlpm_sampler *s, const float *A_dev, const float *xT_dev, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(s && A_dev && xT_dev, "dlpm_sampler_begin_injected: null argument");
+    hipStream_t st = as_stream(stream);
+    DLPM_HIP(hipMemcpyAsync(s->A, A_dev, (size_t)s->cfg.T * s->cfg.B * sizeof(float), hipMemcpyDeviceToDevice, st));
+    DLPM_HIP(hipMemcpyAsync(s->x, xT_dev, (size_t)s->cfg.B * s->D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return build_tables(s, st);
+}
+
+extern "C" int dlpm_sampler_step_injected(dlpm_sampler *s, const float *z_dev, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(s, "dlpm_sampler_step_injected: null handle");
+    if (s->t_host < 1) return DLPM_OK;
+    TRY(one_step(s, z_dev, true, as_stream(stream)));
+    s->t_host -= 1;
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_sampler_steps(dlpm_sampler *s, int32_t nsteps, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(s && nsteps >= 0, "dlpm_sampler_steps: bad argument");
+    hipStream_t st = as_stream(stream);
+    if (nsteps > s->t_host) nsteps = s->t_host;
+    if (nsteps == 0) return DLPM_OK;
+    if (s->cfg.use_graph && !s->exec && !prof_enabled()) {
+        // warm-up step outside capture (sets function attributes, pages code in) is step 1 itself
+        TRY(one_step(s, nullptr, true, st));
+        s->t_host -= 1;
+        nsteps -= 1;
+        DLPM_HIP(hipStreamSynchronize(st));
+        if (nsteps == 0) return DLPM_OK;
+        DLPM_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        int r = one_step(s, nullptr, true, st);
+        hipError_t e = hipStreamEndCapture(st, &s->graph);
+        if (r != DLPM_OK) return r;
+        DLPM_HIP(e);
+        DLPM_HIP(hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0));
+    }
+    for (int i = 0; i < nsteps; i++) {
+        if (s->exec && !prof_enabled()) DLPM_HIP(hipGraphLaunch(s->exec, st));
+        else TRY(one_step(s, nullptr, true, st));
+    }
+    s->t_host -= nsteps;
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_sampler_copy_state(dlpm_sampler *s, float *out_dev, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(s && out_dev, "dlpm_sampler_copy_state: null argument");
+    DLPM_HIP(hipMemcpyAsync(out_dev, s->x, (size_t)s->cfg.B * s->D * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
+    return DLPM_OK;
+}
+
+extern "C" float *dlpm_sampler_state(dlpm_sampler *s) { return s ? s->x : nullptr; }
+extern "C" int32_t dlpm_sampler_t(const dlpm_sampler *s) { return s ? s->t_host : -1; }
+extern "C" float *dlpm_sampler_table(dlpm_sampler *s, int which) {
+    if (!s) return nullptr;
+    switch (which) {
+        case 0: return s->A;
+        case 1: return s->c_eps;
+        case 2: return s->c_noise;
+        case 3: return s->eps;
+        default: return nullptr;
+    }
+}
+
+extern "C" void dlpm_sampler_destroy(dlpm_sampler *s) {
+    if (!s) return;
+    if (s->exec) (void)hipGraphExecDestroy(s->exec);
+    if (s->graph) (void)hipGraphDestroy(s->graph);
+    void *bufs[] = {s->g, s->bg, s->s, s->bs, s->A, s->c_eps, s->c_noise, s->x, s->eps, s->tvec, s->t_dev, s->ws};
+    for (void *p : bufs)
+        if (p) (void)hipFree(p);
+    delete s;
+}

@@ -1,0 +1,680 @@
+// unet.hip -- the improved-DDPM UNet score network as a launch plan over the HIP kernels.
+//
+// Replaces UNetModel.forward and its blocks (dlpm/models/unet.py:33-250,276-492) for the
+// constructor arguments of _unet_model (dlpm/dlpm_experiment.py:38-56: use_scale_shift_norm=True,
+// dims=2, no class conditioning, conv_resample=True).  Weights arrive under the reference's
+// state_dict keys, so reference checkpoints load unchanged.
+//
+// Data layout in HBM: activations NHWC fp32 in a caller-provided workspace carved by a bump
+// allocator (no reuse: at B = 1024 the CIFAR net needs ~45 GB of the 288 GB); the (B,C,H,W)
+// boundary tensors are read/written in place by the stem/head kernels.  Fusions:
+//   GroupNorm(+scale-shift)+SiLU  -> coefficient kernel + the consumer conv's tile staging
+//   cat([h, skip])                -> two-pointer reads in the conv / GroupNorm kernels
+//   nearest upsample              -> index arithmetic in the conv
+//   bias, residual add            -> conv epilogue
+//   22 per-ResBlock Linear(4mc -> 2C) -> one GEMM against the row-concatenated weights
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "conv.h"
+
+using namespace dlpm;
+
+namespace {
+
+struct Param {
+    std::string key;
+    int64_t numel = 0;
+    float *dev = nullptr;   // reference layout
+    bool set = false;
+};
+
+enum LayerKind { L_STEM, L_RES, L_ATTN, L_DOWN, L_UP };
+
+struct ConvW {            // one convolution's weights
+    int p_w = -1, p_b = -1;  // param indices
+    int cout = 0, cin = 0, ks = 1;
+    bool use_igemm = false;
+    float *w_dev = nullptr;  // re-laid-out copy (or the original for 1x1 igemm)
+    bool owns = false;
+};
+
+struct Layer {
+    LayerKind kind;
+    std::string pre;
+    int cin = 0, cout = 0;       // RES: cin = total input channels
+    int emb_off = 0;             // RES: column offset into the fused emb GEMM output
+    ConvW c1, c2, skip;          // RES: in conv, out conv, 1x1 skip | ATTN: c1 = qkv, c2 = proj | STEM/DOWN/UP: c1
+    bool has_skip = false;
+    int p_gn1_w = -1, p_gn1_b = -1, p_gn2_w = -1, p_gn2_b = -1;
+    int p_emb_w = -1, p_emb_b = -1;
+};
+
+struct Tensor4 {
+    float *p = nullptr;
+    int C = 0, H = 0, W = 0;
+};
+
+struct Bump {
+    char *base = nullptr;
+    int64_t cap = 0, off = 0;
+    bool dry = false, overflow = false;
+    float *alloc(int64_t nfloats) {
+        int64_t bytes = (nfloats * 4 + 255) / 256 * 256;
+        float *r = dry ? nullptr : reinterpret_cast<float *>(base + off);
+        off += bytes;
+        if (!dry && off > cap) overflow = true;
+        return r;
+    }
+};
+
+}  // namespace
+
+struct dlpm_unet {
+    dlpm_unet_config cfg;
+    std::vector<Param> params;
+    std::map<std::string, int> index;
+    std::vector<std::vector<Layer>> in_blocks, out_blocks;
+    std::vector<Layer> mid;
+    std::vector<int> skip_ch;        // channels pushed by each input block
+    ConvW te0, te2, embcat, head;
+    int p_head_gn_w = -1, p_head_gn_b = -1;
+    float *embcat_w = nullptr, *embcat_b = nullptr;
+    int emb_total = 0, ted = 0, final_ch = 0;
+    bool finalized = false;
+    std::vector<Tensor4> feats;      // block outputs of the last forward
+    int64_t flops = 0;
+
+    int add(const std::string &key, int64_t numel) {
+        Param p;
+        p.key = key;
+        p.numel = numel;
+        params.push_back(p);
+        index[key] = (int)params.size() - 1;
+        return (int)params.size() - 1;
+    }
+    ConvW conv(const std::string &pre, int cout, int cin, int ks) {
+        ConvW c;
+        c.cout = cout; c.cin = cin; c.ks = ks;
+        c.p_w = add(pre + "weight", (int64_t)cout * cin * ks * ks);
+        c.p_b = add(pre + "bias", cout);
+        return c;
+    }
+    Layer res(const std::string &pre, int cin, int cout) {
+        Layer L;
+        L.kind = L_RES; L.pre = pre; L.cin = cin; L.cout = cout;
+        L.p_gn1_w = add(pre + "in_layers.0.weight", cin);
+        L.p_gn1_b = add(pre + "in_layers.0.bias", cin);
+        L.c1 = conv(pre + "in_layers.2.", cout, cin, 3);
+        L.p_emb_w = add(pre + "emb_layers.1.weight", (int64_t)2 * cout * ted);
+        L.p_emb_b = add(pre + "emb_layers.1.bias", 2 * cout);
+        L.p_gn2_w = add(pre + "out_layers.0.weight", cout);
+        L.p_gn2_b = add(pre + "out_layers.0.bias", cout);
+        L.c2 = conv(pre + "out_layers.3.", cout, cout, 3);
+        L.has_skip = cin != cout;
+        if (L.has_skip) L.skip = conv(pre + "skip_connection.", cout, cin, 1);
+        L.emb_off = emb_total;
+        emb_total += 2 * cout;
+        return L;
+    }
+    Layer attn(const std::string &pre, int ch) {
+        Layer L;
+        L.kind = L_ATTN; L.pre = pre; L.cin = L.cout = ch;
+        L.p_gn1_w = add(pre + "norm.weight", ch);
+        L.p_gn1_b = add(pre + "norm.bias", ch);
+        L.c1 = conv(pre + "qkv.", 3 * ch, ch, 1);
+        L.c2 = conv(pre + "proj_out.", ch, ch, 1);
+        return L;
+    }
+    bool has_attn(int ds) const {
+        for (int i = 0; i < cfg.n_attn; i++)
+            if (cfg.attention_resolutions[i] == ds) return true;
+        return false;
+    }
+};
+
+namespace {
+
+// The block structure the reference constructor produces (unet.py:334-436).
+void build_arch(dlpm_unet *u) {
+    const dlpm_unet_config &c = u->cfg;
+    const int mc = c.model_channels;
+    u->ted = 4 * mc;
+    u->te0 = u->conv("time_embed.0.", u->ted, mc, 1);
+    u->te2 = u->conv("time_embed.2.", u->ted, u->ted, 1);
+    {
+        Layer L;
+        L.kind = L_STEM; L.pre = "input_blocks.0.0."; L.cin = c.in_channels; L.cout = mc;
+        L.c1 = u->conv(L.pre, mc, c.in_channels, 3);
+        u->in_blocks.push_back({L});
+        u->skip_ch.push_back(mc);
+    }
+    int ch = mc, ds = 1;
+    for (int level = 0; level < c.n_mult; level++) {
+        const int mult = c.channel_mult[level];
+        for (int r = 0; r < c.num_res_blocks; r++) {
+            const std::string pre = "input_blocks." + std::to_string(u->in_blocks.size()) + ".";
+            std::vector<Layer> seq;
+            seq.push_back(u->res(pre + "0.", ch, mult * mc));
+            ch = mult * mc;
+            if (u->has_attn(ds)) seq.push_back(u->attn(pre + "1.", ch));
+            u->in_blocks.push_back(seq);
+            u->skip_ch.push_back(ch);
+        }
+        if (level != c.n_mult - 1) {
+            Layer L;
+            L.kind = L_DOWN; L.pre = "input_blocks." + std::to_string(u->in_blocks.size()) + ".0.op.";
+            L.cin = L.cout = ch;
+            L.c1 = u->conv(L.pre, ch, ch, 3);
+            u->in_blocks.push_back({L});
+            u->skip_ch.push_back(ch);
+            ds *= 2;
+        }
+    }
+    u->mid.push_back(u->res("middle_block.0.", ch, ch));
+    u->mid.push_back(u->attn("middle_block.1.", ch));
+    u->mid.push_back(u->res("middle_block.2.", ch, ch));
+    std::vector<int> stack = u->skip_ch;
+    for (int level = c.n_mult - 1; level >= 0; level--) {
+        const int mult = c.channel_mult[level];
+        for (int i = 0; i <= c.num_res_blocks; i++) {
+            const std::string pre = "output_blocks." + std::to_string(u->out_blocks.size()) + ".";
+            const int ich = stack.back();
+            stack.pop_back();
+            std::vector<Layer> seq;
+            seq.push_back(u->res(pre + "0.", ch + ich, mc * mult));
+            ch = mc * mult;
+            int k = 1;
+            if (u->has_attn(ds)) seq.push_back(u->attn(pre + std::to_string(k++) + ".", ch));
+            if (level && i == c.num_res_blocks) {
+                Layer L;
+                L.kind = L_UP; L.pre = pre + std::to_string(k++) + ".conv.";
+                L.cin = L.cout = ch;
+                L.c1 = u->conv(L.pre, ch, ch, 3);
+                seq.push_back(L);
+                ds /= 2;
+            }
+            u->out_blocks.push_back(seq);
+        }
+    }
+    u->final_ch = ch;
+    u->p_head_gn_w = u->add("out.0.weight", ch);
+    u->p_head_gn_b = u->add("out.0.bias", ch);
+    u->head = u->conv("out.2.", c.out_channels, mc, 3);
+}
+
+int prep_conv(dlpm_unet *u, ConvW &c, int C0, bool boundary) {
+    ConvLaunch probe;
+    probe.C0 = C0; probe.C1 = c.cin - C0; probe.Cout = c.cout; probe.ks = c.ks;
+    probe.in_nchw = probe.out_nchw = boundary;
+    c.use_igemm = igemm_supported(probe);
+    const float *src = u->params[c.p_w].dev;
+    if (c.use_igemm && c.ks == 1) {  // [O][I] row-major is already the igemm layout
+        c.w_dev = const_cast<float *>(src);
+        return DLPM_OK;
+    }
+    DLPM_HIP(hipMalloc(&c.w_dev, (size_t)c.cout * c.cin * c.ks * c.ks * sizeof(float)));
+    c.owns = true;
+    return relayout_weight(src, c.w_dev, c.cout, c.cin, c.ks, c.use_igemm, nullptr);
+}
+
+int run_conv(const ConvW &c, ConvLaunch L, hipStream_t st) {
+    L.w = c.w_dev;
+    L.ks = c.ks;
+    L.Cout = c.cout;
+    return c.use_igemm ? launch_conv_igemm(L, st) : launch_conv_direct(L, st);
+}
+
+#define TRY(expr)                  \
+    do {                           \
+        int _r = (expr);           \
+        if (_r != DLPM_OK) return _r; \
+    } while (0)
+
+struct Ctx {
+    dlpm_unet *u;
+    int B;
+    Bump ws;
+    hipStream_t st;
+    float *embout = nullptr;
+    bool dry() const { return ws.dry; }
+};
+
+int run_res(Ctx &cx, const Layer &L, Tensor4 x0, Tensor4 x1, Tensor4 *out) {
+    dlpm_unet *u = cx.u;
+    const int B = cx.B, H = x0.H, W = x0.W, HW = H * W;
+    const int C0 = x0.C, C1 = x1.C, Cin = C0 + C1, Co = L.cout;
+    float *cA1 = cx.ws.alloc((int64_t)B * Cin), *cB1 = cx.ws.alloc((int64_t)B * Cin);
+    float *h1 = cx.ws.alloc((int64_t)B * HW * Co);
+    float *cA2 = cx.ws.alloc((int64_t)B * Co), *cB2 = cx.ws.alloc((int64_t)B * Co);
+    float *sk = L.has_skip ? cx.ws.alloc((int64_t)B * HW * Co) : nullptr;
+    float *o = cx.ws.alloc((int64_t)B * HW * Co);
+    out->p = o; out->C = Co; out->H = H; out->W = W;
+    if (cx.dry()) return DLPM_OK;
+    const int G1 = Cin < 32 ? Cin : 32, G2 = Co < 32 ? Co : 32;
+    TRY(launch_gn_coeffs(x0.p, x1.p, C0, C1, B, HW, G1, u->params[L.p_gn1_w].dev, u->params[L.p_gn1_b].dev, nullptr, 0, 0,
+                         cA1, cB1, cx.st));
+    ConvLaunch a;
+    a.src0 = x0.p; a.src1 = x1.p; a.C0 = C0; a.C1 = C1; a.B = B; a.Hin = a.Hout = H; a.Win = a.Wout = W;
+    a.bias = u->params[L.c1.p_b].dev; a.coefA = cA1; a.coefB = cB1; a.act_silu = 1; a.out = h1;
+    TRY(run_conv(L.c1, a, cx.st));
+    TRY(launch_gn_coeffs(h1, nullptr, Co, 0, B, HW, G2, u->params[L.p_gn2_w].dev, u->params[L.p_gn2_b].dev, cx.embout,
+                         u->emb_total, L.emb_off, cA2, cB2, cx.st));
+    ConvLaunch b;
+    b.src0 = h1; b.C0 = Co; b.B = B; b.Hin = b.Hout = H; b.Win = b.Wout = W;
+    b.bias = u->params[L.c2.p_b].dev; b.coefA = cA2; b.coefB = cB2; b.act_silu = 1; b.out = o;
+    if (L.has_skip) {
+        ConvLaunch s;
+        s.src0 = x0.p; s.src1 = x1.p; s.C0 = C0; s.C1 = C1; s.B = B; s.Hin = s.Hout = H; s.Win = s.Wout = W;
+        s.bias = u->params[L.skip.p_b].dev; s.out = sk;
+        TRY(run_conv(L.skip, s, cx.st));
+        b.res0 = sk; b.R0 = Co;
+    } else {
+        b.res0 = x0.p; b.res1 = x1.p; b.R0 = C0;
+    }
+    return run_conv(L.c2, b, cx.st);
+}
+
+int run_attn(Ctx &cx, const Layer &L, Tensor4 x, Tensor4 *out) {
+    dlpm_unet *u = cx.u;
+    const int B = cx.B, C = x.C, T = x.H * x.W;
+    float *cA = cx.ws.alloc((int64_t)B * C), *cB = cx.ws.alloc((int64_t)B * C);
+    float *qkv = cx.ws.alloc((int64_t)B * T * 3 * C);
+    float *av = cx.ws.alloc((int64_t)B * T * C);
+    float *o = cx.ws.alloc((int64_t)B * T * C);
+    *out = x;
+    out->p = o;
+    if (cx.dry()) return DLPM_OK;
+    TRY(launch_gn_coeffs(x.p, nullptr, C, 0, B, T, C < 32 ? C : 32, u->params[L.p_gn1_w].dev, u->params[L.p_gn1_b].dev,
+                         nullptr, 0, 0, cA, cB, cx.st));
+    ConvLaunch q;
+    q.src0 = x.p; q.C0 = C; q.B = B; q.Hin = q.Hout = x.H; q.Win = q.Wout = x.W;
+    q.bias = u->params[L.c1.p_b].dev; q.coefA = cA; q.coefB = cB; q.out = qkv;
+    TRY(run_conv(L.c1, q, cx.st));
+    TRY(launch_attention(qkv, av, B, T, C, u->cfg.num_heads, cx.st));
+    ConvLaunch p;
+    p.src0 = av; p.C0 = C; p.B = B; p.Hin = p.Hout = x.H; p.Win = p.Wout = x.W;
+    p.bias = u->params[L.c2.p_b].dev; p.res0 = x.p; p.R0 = C; p.out = o;
+    return run_conv(L.c2, p, cx.st);
+}
+
+int run_seq(Ctx &cx, const std::vector<Layer> &seq, Tensor4 x0, Tensor4 x1, const float *x_nchw, Tensor4 *out) {
+    dlpm_unet *u = cx.u;
+    const int B = cx.B;
+    Tensor4 h = x0;
+    for (size_t i = 0; i < seq.size(); i++) {
+        const Layer &L = seq[i];
+        Tensor4 o;
+        switch (L.kind) {
+            case L_STEM: {
+                const int S = u->cfg.image_size;
+                o.C = L.cout; o.H = S; o.W = S;
+                o.p = cx.ws.alloc((int64_t)B * S * S * L.cout);
+                if (!cx.dry()) {
+                    ConvLaunch a;
+                    a.src0 = x_nchw; a.C0 = L.cin; a.B = B; a.Hin = a.Hout = S; a.Win = a.Wout = S;
+                    a.bias = u->params[L.c1.p_b].dev; a.out = o.p; a.in_nchw = 1;
+                    TRY(run_conv(L.c1, a, cx.st));
+                }
+                break;
+            }
+            case L_RES:
+                TRY(run_res(cx, L, h, (i == 0) ? x1 : Tensor4(), &o));
+                break;
+            case L_ATTN:
+                TRY(run_attn(cx, L, h, &o));
+                break;
+            case L_DOWN:
+            case L_UP: {
+                const bool up = L.kind == L_UP;
+                o.C = h.C;
+                o.H = up ? h.H * 2 : (h.H - 1) / 2 + 1;
+                o.W = up ? h.W * 2 : (h.W - 1) / 2 + 1;
+                o.p = cx.ws.alloc((int64_t)B * o.H * o.W * o.C);
+                if (!cx.dry()) {
+                    ConvLaunch a;
+                    a.src0 = h.p; a.C0 = h.C; a.B = B; a.Hin = h.H; a.Win = h.W; a.Hout = o.H; a.Wout = o.W;
+                    a.stride = up ? 1 : 2; a.ups = up ? 1 : 0;
+                    a.bias = u->params[L.c1.p_b].dev; a.out = o.p;
+                    TRY(run_conv(L.c1, a, cx.st));
+                }
+                break;
+            }
+        }
+        h = o;
+    }
+    *out = h;
+    return DLPM_OK;
+}
+
+int walk(dlpm_unet *u, Ctx &cx, const float *x, const float *t, float *eps) {
+    const int B = cx.B, mc = u->cfg.model_channels, ted = u->ted;
+    float *e0 = cx.ws.alloc((int64_t)B * mc), *e1 = cx.ws.alloc((int64_t)B * ted), *e2 = cx.ws.alloc((int64_t)B * ted);
+    cx.embout = cx.ws.alloc((int64_t)B * u->emb_total);
+    if (!cx.dry()) {
+        TRY(launch_timestep_embedding(t, e0, B, mc, cx.st));
+        ConvLaunch g;
+        g.B = B; g.Hin = g.Win = g.Hout = g.Wout = 1;
+        g.src0 = e0; g.C0 = mc; g.bias = u->params[u->te0.p_b].dev; g.out = e1;
+        TRY(run_conv(u->te0, g, cx.st));
+        g.src0 = e1; g.C0 = ted; g.bias = u->params[u->te2.p_b].dev; g.out = e2; g.act_silu = 1;
+        TRY(run_conv(u->te2, g, cx.st));
+        g.src0 = e2; g.bias = u->embcat_b; g.out = cx.embout;
+        TRY(run_conv(u->embcat, g, cx.st));
+    }
+    u->feats.clear();
+    std::vector<Tensor4> hs;
+    Tensor4 h;
+    for (auto &seq : u->in_blocks) {
+        TRY(run_seq(cx, seq, h, Tensor4(), x, &h));
+        hs.push_back(h);
+        u->feats.push_back(h);
+    }
+    TRY(run_seq(cx, u->mid, h, Tensor4(), nullptr, &h));
+    u->feats.push_back(h);
+    for (auto &seq : u->out_blocks) {
+        Tensor4 skip = hs.back();
+        hs.pop_back();
+        if (skip.H != h.H || skip.W != h.W) {
+            set_error("unet: skip connection %dx%d does not match %dx%d (image_size must be divisible by 2^(levels-1))",
+                      skip.H, skip.W, h.H, h.W);
+            return DLPM_ERR_ARG;
+        }
+        TRY(run_seq(cx, seq, h, skip, nullptr, &h));
+        u->feats.push_back(h);
+    }
+    float *cA = cx.ws.alloc((int64_t)B * h.C), *cB = cx.ws.alloc((int64_t)B * h.C);
+    if (!cx.dry()) {
+        TRY(launch_gn_coeffs(h.p, nullptr, h.C, 0, B, h.H * h.W, h.C < 32 ? h.C : 32, u->params[u->p_head_gn_w].dev,
+                             u->params[u->p_head_gn_b].dev, nullptr, 0, 0, cA, cB, cx.st));
+        ConvLaunch a;
+        a.src0 = h.p; a.C0 = h.C; a.B = B; a.Hin = a.Hout = h.H; a.Win = a.Wout = h.W;
+        a.bias = u->params[u->head.p_b].dev; a.coefA = cA; a.coefB = cB; a.act_silu = 1; a.out = eps; a.out_nchw = 1;
+        TRY(run_conv(u->head, a, cx.st));
+    }
+    return DLPM_OK;
+}
+
+int64_t count_flops(dlpm_unet *u) {
+    // 2*MAC per sample: conv / linear / attention matmuls
+    int64_t f = 0;
+    const int S = u->cfg.image_size;
+    auto convf = [&](const ConvW &c, int H, int W) { f += 2LL * c.cout * c.cin * c.ks * c.ks * H * W; };
+    convf(u->te0, 1, 1);
+    convf(u->te2, 1, 1);
+    f += 2LL * u->emb_total * u->ted;
+    int H = S;
+    auto seqf = [&](const std::vector<Layer> &seq) {
+        for (auto &L : seq) {
+            switch (L.kind) {
+                case L_STEM: convf(L.c1, H, H); break;
+                case L_RES:
+                    convf(L.c1, H, H); convf(L.c2, H, H);
+                    if (L.has_skip) convf(L.skip, H, H);
+                    break;
+                case L_ATTN:
+                    convf(L.c1, H, H); convf(L.c2, H, H);
+                    f += 4LL * (H * H) * (H * H) * L.cin;
+                    break;
+                case L_DOWN: H = (H - 1) / 2 + 1; convf(L.c1, H, H); break;
+                case L_UP: H *= 2; convf(L.c1, H, H); break;
+            }
+        }
+    };
+    for (auto &s : u->in_blocks) seqf(s);
+    seqf(u->mid);
+    for (auto &s : u->out_blocks) seqf(s);
+    convf(u->head, H, H);
+    return f;
+}
+
+}  // namespace
+
+extern "C" int dlpm_unet_create(const dlpm_unet_config *cfg, dlpm_unet **out) {
+    DLPM_CHECK_ARG(cfg && out, "dlpm_unet_create: null argument");
+    DLPM_CHECK_ARG(cfg->in_channels > 0 && cfg->model_channels > 0 && cfg->out_channels > 0 && cfg->num_res_blocks > 0,
+                   "dlpm_unet_create: channels / res blocks must be positive");
+    DLPM_CHECK_ARG(cfg->n_mult > 0 && cfg->n_mult <= 8 && cfg->n_attn >= 0 && cfg->n_attn <= 8,
+                   "dlpm_unet_create: bad channel_mult / attention_resolutions length");
+    DLPM_CHECK_ARG(cfg->num_heads > 0 && cfg->image_size > 0, "dlpm_unet_create: bad num_heads / image_size");
+    DLPM_CHECK_ARG(cfg->image_size % (1 << (cfg->n_mult - 1)) == 0,
+                   "dlpm_unet_create: image_size %d not divisible by 2^%d (the reference UNet fails on such sizes too)",
+                   cfg->image_size, cfg->n_mult - 1);
+    dlpm_unet *u = new dlpm_unet();
+    u->cfg = *cfg;
+    build_arch(u);
+    *out = u;
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_unet_num_params(const dlpm_unet *net) { return net ? (int)net->params.size() : 0; }
+
+extern "C" const char *dlpm_unet_param_key(const dlpm_unet *net, int i, int64_t *numel_out) {
+    if (!net || i < 0 || i >= (int)net->params.size()) return nullptr;
+    if (numel_out) *numel_out = net->params[i].numel;
+    return net->params[i].key.c_str();
+}
+
+extern "C" int dlpm_unet_set_param(dlpm_unet *net, const char *key, const float *host, int64_t numel) {
+    DLPM_CHECK_ARG(net && key && host, "dlpm_unet_set_param: null argument");
+    auto it = net->index.find(key);
+    DLPM_CHECK_ARG(it != net->index.end(), "dlpm_unet_set_param: unexpected key '%s' for this architecture", key);
+    Param &p = net->params[it->second];
+    DLPM_CHECK_ARG(p.numel == numel, "dlpm_unet_set_param: '%s' has %lld elements, expected %lld", key, (long long)numel,
+                   (long long)p.numel);
+    if (!p.dev) DLPM_HIP(hipMalloc(&p.dev, (size_t)numel * sizeof(float)));
+    DLPM_HIP(hipMemcpy(p.dev, host, (size_t)numel * sizeof(float), hipMemcpyHostToDevice));
+    p.set = true;
+    net->finalized = false;
+    return DLPM_OK;
+}
+
+static void free_conv(ConvW &c) {
+    if (c.owns && c.w_dev) (void)hipFree(c.w_dev);
+    c.w_dev = nullptr;
+    c.owns = false;
+}
+
+static void for_each_conv(dlpm_unet *u, void (*fn)(ConvW &)) {
+    auto seq = [&](std::vector<Layer> &s) {
+        for (auto &L : s) {
+            fn(L.c1);
+            if (L.kind == L_RES || L.kind == L_ATTN) fn(L.c2);
+            if (L.kind == L_RES && L.has_skip) fn(L.skip);
+        }
+    };
+    for (auto &s : u->in_blocks) seq(s);
+    seq(u->mid);
+    for (auto &s : u->out_blocks) seq(s);
+    fn(u->te0);
+    fn(u->te2);
+    fn(u->head);
+}
+
+extern "C" int dlpm_unet_finalize(dlpm_unet *u) {
+    DLPM_CHECK_ARG(u, "dlpm_unet_finalize: null handle");
+    for (auto &p : u->params)
+        if (!p.set) {
+            set_error("dlpm_unet_finalize: parameter '%s' was never set", p.key.c_str());
+            return DLPM_ERR_STATE;
+        }
+    for_each_conv(u, free_conv);
+    // per-conv weight layouts; C0 matters only for the concat inputs of the output blocks
+    auto prep_seq = [&](std::vector<Layer> &s, int C0_first) -> int {
+        for (size_t i = 0; i < s.size(); i++) {
+            Layer &L = s[i];
+            const bool cat = (i == 0 && L.kind == L_RES && C0_first > 0);
+            const int C0 = cat ? C0_first : L.c1.cin;
+            TRY(prep_conv(u, L.c1, L.kind == L_STEM ? L.c1.cin : C0, L.kind == L_STEM));
+            if (L.kind == L_RES || L.kind == L_ATTN) TRY(prep_conv(u, L.c2, L.c2.cin, false));
+            if (L.kind == L_RES && L.has_skip) TRY(prep_conv(u, L.skip, cat ? C0_first : L.skip.cin, false));
+        }
+        return DLPM_OK;
+    };
+    for (auto &s : u->in_blocks) TRY(prep_seq(s, 0));
+    TRY(prep_seq(u->mid, 0));
+    {
+        // channels of h entering each output block = previous block's cout (or the middle's)
+        int ch = u->mid.back().cout;
+        for (auto &s : u->out_blocks) {
+            TRY(prep_seq(s, ch));
+            ch = s[0].cout;
+        }
+    }
+    TRY(prep_conv(u, u->te0, u->te0.cin, false));
+    TRY(prep_conv(u, u->te2, u->te2.cin, false));
+    TRY(prep_conv(u, u->head, u->head.cin, true));
+    // fused emb GEMM: rows of every emb_layers.1.weight stacked in ResBlock order
+    if (u->embcat_w) (void)hipFree(u->embcat_w);
+    if (u->embcat_b) (void)hipFree(u->embcat_b);
+    DLPM_HIP(hipMalloc(&u->embcat_w, (size_t)u->emb_total * u->ted * sizeof(float)));
+    DLPM_HIP(hipMalloc(&u->embcat_b, (size_t)u->emb_total * sizeof(float)));
+    auto cat_seq = [&](std::vector<Layer> &s) -> int {
+        for (auto &L : s)
+            if (L.kind == L_RES) {
+                DLPM_HIP(hipMemcpy(u->embcat_w + (size_t)L.emb_off * u->ted, u->params[L.p_emb_w].dev,
+                                   (size_t)2 * L.cout * u->ted * sizeof(float), hipMemcpyDeviceToDevice));
+                DLPM_HIP(hipMemcpy(u->embcat_b + L.emb_off, u->params[L.p_emb_b].dev, (size_t)2 * L.cout * sizeof(float),
+                                   hipMemcpyDeviceToDevice));
+            }
+        return DLPM_OK;
+    };
+    for (auto &s : u->in_blocks) TRY(cat_seq(s));
+    TRY(cat_seq(u->mid));
+    for (auto &s : u->out_blocks) TRY(cat_seq(s));
+    u->embcat.cout = u->emb_total; u->embcat.cin = u->ted; u->embcat.ks = 1;
+    {
+        ConvLaunch probe;
+        probe.C0 = u->ted; probe.Cout = u->emb_total; probe.ks = 1;
+        u->embcat.use_igemm = igemm_supported(probe);
+        if (u->embcat.use_igemm) {
+            u->embcat.w_dev = u->embcat_w;
+        } else {
+            DLPM_HIP(hipMalloc(&u->embcat.w_dev, (size_t)u->emb_total * u->ted * sizeof(float)));
+            u->embcat.owns = true;
+            TRY(relayout_weight(u->embcat_w, u->embcat.w_dev, u->emb_total, u->ted, 1, false, nullptr));
+        }
+    }
+    DLPM_HIP(hipDeviceSynchronize());
+    u->flops = count_flops(u);
+    u->finalized = true;
+    return DLPM_OK;
+}
+
+extern "C" int64_t dlpm_unet_workspace_bytes(const dlpm_unet *net, int64_t B) {
+    if (!net || B <= 0) return -1;
+    Ctx cx;
+    cx.u = const_cast<dlpm_unet *>(net);
+    cx.B = (int)B;
+    cx.ws.dry = true;
+    cx.st = nullptr;
+    std::vector<Tensor4> keep = net->feats;
+    int r = walk(cx.u, cx, nullptr, nullptr, nullptr);
+    cx.u->feats = keep;
+    return r == DLPM_OK ? cx.ws.off : -1;
+}
+
+extern "C" int dlpm_unet_forward(dlpm_unet *net, const float *x_dev, const float *t_dev, float *eps_dev, int64_t B,
+                                 void *workspace_dev, int64_t workspace_bytes, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(net && x_dev && t_dev && eps_dev && workspace_dev, "dlpm_unet_forward: null argument");
+    DLPM_CHECK_ARG(B > 0 && B < (1 << 24), "dlpm_unet_forward: bad batch %lld", (long long)B);
+    if (!net->finalized) {
+        set_error("dlpm_unet_forward: call dlpm_unet_finalize first");
+        return DLPM_ERR_STATE;
+    }
+    const int64_t need = dlpm_unet_workspace_bytes(net, B);
+    if (need < 0) return DLPM_ERR_ARG;
+    if (workspace_bytes < need) {
+        set_error("dlpm_unet_forward: workspace of %lld bytes, need %lld", (long long)workspace_bytes, (long long)need);
+        return DLPM_ERR_NOMEM;
+    }
+    Ctx cx;
+    cx.u = net;
+    cx.B = (int)B;
+    cx.ws.base = static_cast<char *>(workspace_dev);
+    cx.ws.cap = workspace_bytes;
+    cx.st = as_stream(stream);
+    return walk(net, cx, x_dev, t_dev, eps_dev);
+}
+
+extern "C" int dlpm_unet_num_features(const dlpm_unet *net) {
+    return net ? (int)(net->in_blocks.size() + 1 + net->out_blocks.size()) : 0;
+}
+
+extern "C" int dlpm_unet_feature_shape(const dlpm_unet *net, int i, int32_t *C, int32_t *H, int32_t *W) {
+    DLPM_CHECK_ARG(net && i >= 0 && i < (int)net->feats.size(), "dlpm_unet_feature_shape: no such feature (run a forward first)");
+    if (C) *C = net->feats[i].C;
+    if (H) *H = net->feats[i].H;
+    if (W) *W = net->feats[i].W;
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_unet_get_feature(dlpm_unet *net, int i, float *out_nchw_dev, int64_t B, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(net && out_nchw_dev && i >= 0 && i < (int)net->feats.size() && net->feats[i].p,
+                   "dlpm_unet_get_feature: no such feature (run a forward first)");
+    const Tensor4 &f = net->feats[i];
+    return dlpm_nhwc_to_nchw_f32(f.p, out_nchw_dev, (int32_t)B, f.C, f.H, f.W, stream);
+}
+
+extern "C" int64_t dlpm_unet_flops_per_sample(const dlpm_unet *net) { return net ? net->flops : 0; }
+
+extern "C" void dlpm_unet_destroy(dlpm_unet *u) {
+    if (!u) return;
+    for_each_conv(u, free_conv);
+    if (u->embcat.owns && u->embcat.w_dev) (void)hipFree(u->embcat.w_dev);
+    if (u->embcat_w) (void)hipFree(u->embcat_w);
+    if (u->embcat_b) (void)hipFree(u->embcat_b);
+    for (auto &p : u->params)
+        if (p.dev) (void)hipFree(p.dev);
+    delete u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// building-block entry points (parity tests call each kernel through the C ABI)
+// ---------------------------------------------------------------------------------------------
+extern "C" int dlpm_conv2d_f32(const dlpm_conv_args *a, float *scratch_dev, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(a && a->src0 && a->weight && a->out && scratch_dev, "dlpm_conv2d_f32: null argument");
+    DLPM_CHECK_ARG(a->ksize == 1 || a->ksize == 3, "dlpm_conv2d_f32: ksize must be 1 or 3");
+    DLPM_CHECK_ARG(a->stride == 1 || a->stride == 2, "dlpm_conv2d_f32: stride must be 1 or 2");
+    DLPM_CHECK_ARG((a->C1 == 0) == (a->src1 == nullptr), "dlpm_conv2d_f32: src1/C1 mismatch");
+    ConvLaunch L;
+    L.src0 = a->src0; L.src1 = a->src1; L.C0 = a->C0; L.C1 = a->C1; L.B = a->B;
+    L.Hin = a->Hin; L.Win = a->Win; L.Hout = a->Hout; L.Wout = a->Wout;
+    L.ks = a->ksize; L.stride = a->stride; L.ups = a->upsample;
+    L.bias = a->bias; L.coefA = a->coefA; L.coefB = a->coefB; L.act_silu = a->act_silu;
+    L.res0 = a->res0; L.res1 = a->res1; L.R0 = a->R0; L.out = a->out; L.Cout = a->Cout;
+    L.in_nchw = a->in_nchw; L.out_nchw = a->out_nchw;
+    const bool ig = !a->force_direct && igemm_supported(L);
+    if ((a->in_nchw || a->out_nchw) && a->C1 != 0) {
+        set_error("dlpm_conv2d_f32: NCHW boundary layouts do not combine with a concat input");
+        return DLPM_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = as_stream(stream);
+    TRY(relayout_weight(a->weight, scratch_dev, a->Cout, a->C0 + a->C1, a->ksize, ig, st));
+    L.w = scratch_dev;
+    return ig ? launch_conv_igemm(L, st) : launch_conv_direct(L, st);
+}
+
+extern "C" int dlpm_groupnorm_coeffs_f32(const float *src0, const float *src1, int32_t C0, int32_t C1, int32_t B, int32_t HW,
+                                         int32_t groups, const float *gamma, const float *beta, const float *ss,
+                                         int64_t ss_stride, int64_t ss_offset, float *coefA, float *coefB,
+                                         dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(src0 && gamma && beta && coefA && coefB, "dlpm_groupnorm_coeffs_f32: null argument");
+    DLPM_CHECK_ARG(groups > 0 && (C0 + C1) % groups == 0, "dlpm_groupnorm_coeffs_f32: %d channels not divisible by %d groups",
+                   C0 + C1, groups);
+    return launch_gn_coeffs(src0, src1, C0, C1, B, HW, groups, gamma, beta, ss, ss_stride, ss_offset, coefA, coefB,
+                            as_stream(stream));
+}
+
+extern "C" int dlpm_attention_f32(const float *qkv, float *out, int32_t B, int32_t T, int32_t C, int32_t heads,
+                                  dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(qkv && out && B > 0, "dlpm_attention_f32: null argument");
+    return launch_attention(qkv, out, B, T, C, heads, as_stream(stream));
+}
+
+extern "C" int dlpm_timestep_embedding_f32(const float *t, float *emb, int64_t B, int32_t dim, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(t && emb && B > 0 && dim > 0, "dlpm_timestep_embedding_f32: bad argument");
+    return launch_timestep_embedding(t, emb, B, dim, as_stream(stream));
+}

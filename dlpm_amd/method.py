@@ -1,0 +1,322 @@
+"""GenerativeLevyProcess: the sampling entry point, drop-in for the reference's method object.
+
+Mirrors the constructor and `sample(...)` signature of
+dlpm/methods/GenerativeLevyProcess.py:48-90,512-569 (what `GenerationManager.generate` and
+`eval.py --generate` call).  The loop itself runs in libdlpm_amd:
+
+  * `models['default']` is a dlpm_amd.UNetModel / MLPModel  -> dlpm_sampler_* (one reverse step
+    captured as a hipGraph and replayed T-1 times);
+  * any other callable `model(x, t)` on the GPU                -> the same noise / table / update
+    kernels, with the model called from Python between them.
+
+Two RNG modes:
+  rng='philox'     device Philox4x32-10 keyed by (seed, GLOBAL sample index, step, element): the
+                   samples do not depend on how a batch is sharded over GPUs (default);
+  rng='reference'  the reference's CPU streams (numpy MT19937 -> scipy-style CMS, torch MT19937 ->
+                   randn) regenerated on the host by libdlpm_amd and uploaded, for parity with the
+                   reference CPU path on identical seeds.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .process import DLPM
+
+
+class ModelMeanType:
+    EPSILON = 'EPSILON'
+
+
+class ModelVarType:
+    FIXED = 'FIXED'
+
+
+class ReferenceStreams:
+    """Stream N (numpy global RandomState, consumed by scipy's levy_stable.rvs) and stream P (torch's
+    default CPU generator), as libdlpm_amd MT19937 states."""
+
+    def __init__(self, np_seed=0, torch_seed=0):
+        self.N, self.P = _lib.MT19937(), _lib.MT19937()
+        L = _lib.lib()
+        _lib.check(L.dlpm_mt19937_seed(C.byref(self.N), np_seed & 0xFFFFFFFF))
+        _lib.check(L.dlpm_mt19937_seed(C.byref(self.P), torch_seed & 0xFFFFFFFF))
+
+    @classmethod
+    def from_global_numpy(cls, torch_seed):
+        """Continue numpy's process-global stream exactly where it stands (write back with
+        `store_global_numpy`)."""
+        s = cls(0, torch_seed)
+        kind, key, pos, _, _ = np.random.get_state()
+        assert kind == 'MT19937'
+        for i in range(624):
+            s.N.key[i] = int(key[i])
+        s.N.pos = int(pos)
+        return s
+
+    def store_global_numpy(self):
+        key = np.array([self.N.key[i] for i in range(624)], dtype=np.uint32)
+        np.random.set_state(('MT19937', key, int(self.N.pos), 0, 0.0))
+
+    def skewed_levy(self, alpha, n, clamp_a=None):
+        out = np.empty(n, np.float32)
+        _lib.check(_lib.lib().dlpm_skewed_levy_host_f32(C.byref(self.N), float(alpha), n,
+                                                       -1.0 if clamp_a is None else float(clamp_a), out.ctypes.data))
+        return torch.from_numpy(out)
+
+    def randn(self, shape):
+        n = int(np.prod(shape))
+        out = np.empty(n, np.float32)
+        _lib.check(_lib.lib().dlpm_randn_host_f32(C.byref(self.P), n, out.ctypes.data))
+        return torch.from_numpy(out).reshape(list(shape))
+
+
+class GenerativeLevyProcess:
+    def __init__(self, alpha, device, reverse_steps, model_mean_type=ModelMeanType.EPSILON,
+                 model_var_type=ModelVarType.FIXED, time_spacing='linear', rescale_timesteps=False, isotropic=True,
+                 LIM=False, scale='scale_preserving', input_scaling=False,
+                 rng='philox', seed=0, sample_offset=0, use_graph=True, reference_streams=None):
+        assert (model_mean_type == ModelMeanType.EPSILON) and (model_var_type == ModelVarType.FIXED), \
+            'Only epsilon prediction and fixed variance are supported for the moment'
+        if LIM:
+            raise NotImplementedError("method='lim' (continuous-time LIM sampler) is outside this build's "
+                                      'hot path (SURVEY.md 8f rank 4)')
+        if input_scaling and scale == 'scale_exploding':
+            raise NotImplementedError('input_scaling is only active for scale_exploding, which is not implemented')
+        assert rng in ('philox', 'reference')
+        self.alpha, self.device, self.reverse_steps = alpha, device, reverse_steps
+        self.model_mean_type, self.model_var_type = model_mean_type, model_var_type
+        self.time_spacing, self.rescale_timesteps, self.isotropic = time_spacing, rescale_timesteps, isotropic
+        self.LIM, self.input_scaling = LIM, input_scaling
+        self.rng, self.seed, self.sample_offset, self.use_graph = rng, seed, sample_offset, use_graph
+        self.reference_streams = reference_streams
+        self.dlpm = DLPM(alpha, device, diffusion_steps=reverse_steps, time_spacing=time_spacing, isotropic=isotropic,
+                         scale=scale)
+        self._samplers = {}
+        self.calls = 0          # number of sample() calls so far: folded into the Philox key
+
+    # -------------------------------------------------------------------------------- helpers
+    def _scale_timesteps(self, t):
+        if self.rescale_timesteps:
+            return t.float() * (1.0 / self.reverse_steps)
+        return t
+
+    def get_timesteps(self, N, **kwargs):
+        return self.dlpm.get_timesteps(N)
+
+    def _streams(self):
+        if self.reference_streams is None:
+            self.reference_streams = ReferenceStreams(self.seed, self.seed)
+        return self.reference_streams
+
+    def _native_sampler(self, model, shape, flags, eta, clamp_a, clamp_eps, seed):
+        from .unet import UNetModel
+        B = shape[0]
+        if isinstance(model, UNetModel):
+            assert len(shape) == 4 and shape[2] == shape[3], shape
+            dims = (shape[1], shape[2], shape[3])
+            handles = dict(unet=model.native_handle(shape[2]), mlp=None)
+        else:
+            assert len(shape) == 3 and shape[1] == 1, shape
+            dims = (1, 1, shape[2])
+            handles = dict(unet=None, mlp=model.native_handle())
+        key = (id(model), handles['unet'].value if handles['unet'] else handles['mlp'].value, tuple(shape),
+               self.reverse_steps, self.alpha, flags, eta, clamp_a, clamp_eps, self.sample_offset, self.use_graph)
+        ent = self._samplers.get(key)
+        if ent is not None:
+            _lib.check(_lib.lib().dlpm_sampler_reseed(ent['h'], seed, self.sample_offset))
+            return ent['h']
+        # one live native sampler per method object: they own activation workspaces sized for B
+        for k in list(self._samplers):
+            _lib.lib().dlpm_sampler_destroy(self._samplers.pop(k)['h'])
+        cfg = _lib.SamplerConfig()
+        cfg.unet, cfg.mlp = handles['unet'], handles['mlp']
+        cfg.B, (cfg.C, cfg.H, cfg.W), cfg.T = B, dims, self.reverse_steps
+        cfg.alpha = float(self.alpha)
+        cfg.clamp_a = -1.0 if clamp_a is None else float(clamp_a)
+        cfg.clamp_eps = -1.0 if clamp_eps is None else float(clamp_eps)
+        cfg.flags, cfg.dlim_eta, cfg.seed = flags, float(eta), seed
+        cfg.sample_offset, cfg.use_graph = self.sample_offset, int(self.use_graph and self.rng == 'philox')
+        sched = self.dlpm.host_schedule
+        cfg.g, cfg.bg, cfg.s, cfg.bs = (v.data_ptr() for v in sched)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().dlpm_sampler_create(C.byref(cfg), C.byref(h)))
+        self._samplers[key] = dict(h=h)
+        return h
+
+    def close(self):
+        for k in list(self._samplers):
+            _lib.lib().dlpm_sampler_destroy(self._samplers.pop(k)['h'])
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -------------------------------------------------------------------------------- loops
+    def _host_noise_prologue(self, shape, clamp_a, clamp_eps, noise):
+        """A[T,B] and x_T from the reference's CPU streams, in its draw order."""
+        st = self._streams()
+        T, B = self.reverse_steps, shape[0]
+        A = torch.stack([st.skewed_levy(self.alpha, B, clamp_a) for _ in range(T)])       # dlpm.py:226-227
+        if noise is not None:
+            xT = noise.detach().to('cpu', torch.float32)
+        else:                                                                             # GLP.py:313
+            a0 = st.skewed_levy(self.alpha, B, None)           # gen_sas draws its own UNclamped a
+            e = torch.sqrt(a0.view(-1, *([1] * (len(shape) - 1)))) * st.randn(shape)
+            if clamp_eps is not None:
+                e = torch.clamp(e, -clamp_eps, clamp_eps)
+            xT = self.dlpm.host_schedule[3][-1] * e
+        return A.contiguous(), xT.contiguous()
+
+    def _run_native(self, model, shape, flags, eta, clamp_a, clamp_eps, noise, history, progress):
+        L, st = _lib.lib(), _lib.stream_ptr()
+        T = self.reverse_steps
+        seed = (self.seed + 0x9E3779B97F4A7C15 * self.calls) & 0xFFFFFFFFFFFFFFFF
+        h = self._native_sampler(model, shape, flags, eta, clamp_a, clamp_eps, seed)
+        dev = torch.device(self.device)
+        x = torch.empty(shape, dtype=torch.float32, device=dev)
+        hist = []
+
+        def snap():
+            _lib.check(L.dlpm_sampler_copy_state(h, x.data_ptr(), st))
+            return x.clone()
+
+        pbar = None
+        if progress:
+            from tqdm import tqdm
+            pbar = tqdm(total=T)
+        if self.rng == 'reference' or noise is not None:
+            A, xT = self._host_noise_prologue(shape, clamp_a, clamp_eps, noise)
+            A_d, xT_d = A.to(dev), xT.to(dev)
+            _lib.check(L.dlpm_sampler_begin_injected(h, A_d.data_ptr(), xT_d.data_ptr(), st))
+            if history:
+                hist.append(snap())
+            need_z = not (flags & _lib.UPD_DLIM) or eta != 0.0
+            for _ in range(T - 1):
+                z_d = self._streams().randn(shape).to(dev) if (need_z and self.rng == 'reference') else None
+                if z_d is None and need_z:
+                    z_d = torch.randn(shape, device=dev)
+                _lib.check(L.dlpm_sampler_step_injected(h, z_d.data_ptr() if z_d is not None else None, st))
+                if history:
+                    hist.append(snap())
+                if pbar:
+                    pbar.update(1)
+        else:
+            _lib.check(L.dlpm_sampler_begin(h, st))
+            if history or pbar:
+                if history:
+                    hist.append(snap())
+                for _ in range(T - 1):
+                    _lib.check(L.dlpm_sampler_steps(h, 1, st))
+                    if history:
+                        hist.append(snap())
+                    if pbar:
+                        pbar.update(1)
+            else:
+                _lib.check(L.dlpm_sampler_steps(h, T - 1, st))
+        if pbar:
+            pbar.close()
+        _lib.check(L.dlpm_sampler_copy_state(h, x.data_ptr(), st))
+        return (x, torch.stack(hist)) if history else x
+
+    def _run_callable(self, model, shape, flags, eta, clamp_a, clamp_eps, noise, history, progress):
+        """Generic `model(x, t)` (any torch callable on the GPU): same kernels, Python between them."""
+        L, st = _lib.lib(), _lib.stream_ptr()
+        T, B = self.reverse_steps, shape[0]
+        D = int(np.prod(shape[1:]))
+        dev = torch.device(self.device)
+        seed = (self.seed + 0x9E3779B97F4A7C15 * self.calls) & 0xFFFFFFFFFFFFFFFF
+        g, bg, s, bs = (v.to(dev) for v in self.dlpm.host_schedule)
+        ca = -1.0 if clamp_a is None else float(clamp_a)
+        ce = -1.0 if clamp_eps is None else float(clamp_eps)
+        host = self.rng == 'reference' or noise is not None
+        if host:
+            A, xT = self._host_noise_prologue(shape, clamp_a, clamp_eps, noise)
+            A, x = A.to(dev), xT.to(dev).reshape(shape).contiguous()
+        else:
+            A = torch.empty((T, B), dtype=torch.float32, device=dev)
+            x = torch.empty(shape, dtype=torch.float32, device=dev)
+            _lib.check(L.dlpm_skewed_levy_philox_f32(A.data_ptr(), T, B, float(self.alpha), ca, seed, self.sample_offset, st))
+            _lib.check(L.dlpm_init_state_philox_f32(x.data_ptr(), B, D, float(self.alpha), ce,
+                                                   float(self.dlpm.host_schedule[3][-1]), seed, self.sample_offset, st))
+        c_eps, c_noise = torch.empty_like(A), torch.empty_like(A)
+        _lib.check(L.dlpm_coeff_tables_f32(A.data_ptr(), g.data_ptr(), s.data_ptr(), bs.data_ptr(), T, B,
+                                          c_eps.data_ptr(), c_noise.data_ptr(), None, st))
+        t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        tvec = torch.empty(B, dtype=torch.float32, device=dev)
+        hist = [x.clone()] if history else []
+        need_z = not (flags & _lib.UPD_DLIM) or eta != 0.0
+        args = _lib.UpdateArgs()
+        args.t_dev, args.g_dev, args.bg_dev, args.bs_dev = t_dev.data_ptr(), g.data_ptr(), bg.data_ptr(), bs.data_ptr()
+        args.c_eps_dev, args.c_noise_dev, args.A_dev = c_eps.data_ptr(), c_noise.data_ptr(), A.data_ptr()
+        args.B, args.D, args.T, args.flags, args.dlim_eta, args.alpha = B, D, T, flags, float(eta), float(self.alpha)
+        args.seed, args.sample_offset = seed, self.sample_offset
+        pbar = None
+        if progress:
+            from tqdm import tqdm
+            pbar = tqdm(total=T)
+        for i in range(T - 1, 0, -1):
+            t_dev.fill_(i)
+            _lib.check(L.dlpm_fill_scaled_t_f32(tvec.data_ptr(), t_dev.data_ptr(), T, B, st))
+            eps = model(x, tvec if self.rescale_timesteps else torch.full((B,), i, device=dev))
+            eps = eps.contiguous().float()
+            z = None
+            if host and need_z:
+                z = (self._streams().randn(shape) if self.rng == 'reference' else torch.randn(shape)).to(dev)
+            args.x_dev, args.eps_dev = x.data_ptr(), eps.data_ptr()
+            args.z_dev = z.data_ptr() if z is not None else None
+            _lib.check(L.dlpm_update_f32(C.byref(args), st))
+            if history:
+                hist.append(x.clone())
+            if pbar:
+                pbar.update(1)
+        if pbar:
+            pbar.close()
+        return (x, torch.stack(hist)) if history else x
+
+    # -------------------------------------------------------------------------------- BEM: SAMPLING
+    def sample(self, models, shape, reverse_steps, time_spacing=None, initial_data=None, clip_denoised=False,
+               deterministic=False, dlim_eta=1.0, print_progression=False, get_sample_history=False, clamp_a=None,
+               clamp_eps=None):
+        """GenerativeLevyProcess.sample: dlpm/methods/GenerativeLevyProcess.py:512-569."""
+        from .unet import UNetModel
+        from .mlp import MLPModel
+        self.dlpm.gen_a.setParams(clamp_a=clamp_a)          # stateful, as in the reference (:526-527)
+        self.dlpm.gen_eps.setParams(clamp_eps=clamp_eps)
+        model = models['default']
+        assert time_spacing is None, 'Specific time spacing is not yet supported for diffusion reverse sampling'
+        if self.reverse_steps != reverse_steps:
+            assert self.rescale_timesteps, 'Rescaling only works when rescale_timesteps is True'
+            self.dlpm.rescale_diffusion(reverse_steps, time_spacing=time_spacing)
+            self.reverse_steps = reverse_steps            # (the reference never restores it: SURVEY.md 3.4)
+        if hasattr(model, 'eval'):
+            model.eval()
+        shape = list(initial_data.shape) if (deterministic and initial_data is not None) else list(shape)
+        noise = initial_data if deterministic else None
+        flags = (_lib.UPD_DLIM if deterministic else 0) | (_lib.UPD_CLIP if clip_denoised else 0)
+        eta = dlim_eta if deterministic else 0.0
+        native = isinstance(model, (UNetModel, MLPModel)) and self.rescale_timesteps
+        run = self._run_native if native else self._run_callable
+        with torch.inference_mode():
+            out = run(model, shape, flags, eta, clamp_a, clamp_eps, noise, get_sample_history, print_progression)
+        self.calls += 1
+        return out
+
+    def training_losses(self, *a, **k):
+        raise NotImplementedError('training is outside the sampling hot path this build covers (SURVEY.md 2b)')
+
+
+def init_method_by_parameter(p, **kw):
+    """dlpm/dlpm_experiment.py:103-131 for method == 'dlpm'."""
+    m = p['method']
+    assert m in ['dlpm', 'lim'], "chosen_gen_model should be in ['dlpm', 'lim'], got {}".format(m)
+    q = p[m]
+    return GenerativeLevyProcess(alpha=q['alpha'], device=p['device'], reverse_steps=q['reverse_steps'],
+                                 model_mean_type=q.get('mean_predict', 'EPSILON'),
+                                 model_var_type=q.get('var_predict', 'FIXED'),
+                                 rescale_timesteps=q['rescale_timesteps'], isotropic=q['isotropic'], LIM=(m == 'lim'),
+                                 scale=q.get('scale', 'scale_preserving'), input_scaling=q.get('input_scaling', False),
+                                 **kw)

@@ -1,0 +1,290 @@
+/*
+ * dlpm_amd.h -- C ABI of libdlpm_amd.so: the MI355X-native (gfx950) implementation of DLPM's
+ * reverse-time sampling hot path.
+ *
+ * The reference (darioShar/DLPM) has no FFI layer: its boundary is Python duck typing
+ * (`model(x, t)`, `method.sample(...)`).  This header is the boundary a
+ * maintainer would bind (ctypes stubs in INTEGRATION.md); every entry point cites the
+ * reference code it replaces.  Plain pointers and sizes only -- no torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative dlpm_status otherwise;
+ *     dlpm_last_error() returns a thread-local message for the last failure.
+ *   - `*_dev` pointers are device (HBM) pointers owned by the caller; `stream` is a
+ *     hipStream_t passed as void* (NULL = the default stream).  Nothing here allocates on
+ *     the caller's behalf except the opaque handles, which own their weights.
+ *   - launch functions never synchronise and never allocate, so they may be captured into a
+ *     hipGraph by the caller (dlpm_sampler_* does exactly that).
+ *   - state tensors cross the boundary in the reference's layout: fp32, (B, C, H, W)
+ *     contiguous (or (B, 1, 2) for the toy data), D = C*H*W elements per sample.
+ */
+#ifndef DLPM_AMD_H
+#define DLPM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *dlpm_stream_t;
+
+enum dlpm_status {
+    DLPM_OK = 0,
+    DLPM_ERR_ARG = -1,     /* bad argument (the reference would raise AssertionError/Exception) */
+    DLPM_ERR_HIP = -2,     /* HIP runtime error; message carries hipGetErrorString */
+    DLPM_ERR_UNSUPPORTED = -3,
+    DLPM_ERR_STATE = -4,   /* call order (e.g. forward before finalize) */
+    DLPM_ERR_NOMEM = -5    /* workspace too small */
+};
+
+const char *dlpm_last_error(void);
+int dlpm_abi_version(void);
+
+/* Per-kernel-class timing with HIP events on the launch stream (eager launches only; the sampler
+ * does not replay its graph while profiling is on).  dlpm_prof_report synchronises, then writes one
+ * line per class: "name launches total_ms flops bytes" (flops/bytes = algorithmic totals). */
+int dlpm_prof_enable(int on);
+int dlpm_prof_report(char *buf, int64_t buf_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Host side: schedule and the reference-compatible ("identical seeds") random streams
+ * ------------------------------------------------------------------------------------------ */
+
+/* Cosine schedule -> gammas, bargammas, sigmas, barsigmas, each [T] fp32 (host buffers).
+ * Replaces DLPM.gen_noise_schedule('scale_preserving') + get_timesteps('linear'):
+ * dlpm/methods/dlpm.py:103-156; also what rescale_diffusion (:176-185) recomputes. */
+int dlpm_schedule_f32(int T, double alpha, float *g, float *bg, float *s, float *bs);
+
+/* MT19937 stream with numpy/torch semantics.  `cached`/`has_cached` is the spare double normal
+ * torch's CPU generator keeps for its scalar (n < 16) path. */
+typedef struct dlpm_mt19937 {
+    uint32_t key[624];
+    int32_t pos;
+    int32_t has_cached;
+    double cached;
+} dlpm_mt19937;
+
+/* np.random.seed(int) / torch.manual_seed(int) (low 32 bits): init_genrand. */
+int dlpm_mt19937_seed(dlpm_mt19937 *st, uint32_t seed);
+
+/* Isotropic totally-skewed alpha/2-stable draws a[n] (fp32), consuming n uniforms THEN n
+ * exponentials from a numpy-compatible stream, Chambers-Mallows-Stuck in fp64, cast to fp32,
+ * optional clamp to [0, clamp_a] (clamp_a < 0: none); alpha == 2 returns the constant 2 and
+ * consumes nothing.  Replaces gen_skewed_levy: bem/datasets/Distributions.py:33-51
+ * (scipy.stats.levy_stable.rvs(alpha/2, 1, loc=0, scale=2cos(pi alpha/4)^(2/alpha))). */
+int dlpm_skewed_levy_host_f32(dlpm_mt19937 *np_stream, double alpha, int64_t n, double clamp_a, float *out);
+
+/* torch.randn(n) on the CPU generator (fp32): 24-bit uniforms + Box-Muller in blocks of 16 for
+ * n >= 16, scalar double path with the cached spare for n < 16.  Replaces torch.randn /
+ * randn_like at Distributions.py:65 and GenerativeLevyProcess.py:236 for CPU-seed parity. */
+int dlpm_randn_host_f32(dlpm_mt19937 *torch_stream, int64_t n, float *out);
+
+/* ------------------------------------------------------------------------------------------
+ * Device side: noise, coefficient tables, fused update
+ * ------------------------------------------------------------------------------------------ */
+
+/* A_dev[T,B] <- skewed-Levy draws from Philox4x32-10 keyed by (seed, global sample index
+ * sample_offset + b, row t): results do not depend on how the batch is sharded over GPUs.
+ * CMS evaluated in fp64 like scipy, stored fp32, clamped to [0, clamp_a] if clamp_a >= 0.
+ * Replaces DLPM.sample_A: dlpm/methods/dlpm.py:226-227 (keeps [T,B], not [T,B,C,H,W]). */
+int dlpm_skewed_levy_philox_f32(float *A_dev, int T, int64_t B, double alpha, double clamp_a,
+                                uint64_t seed, int64_t sample_offset, dlpm_stream_t stream);
+
+/* x_dev[B,D] <- barsigma_last * clamp(sqrt(a0[b]) * z, +-clamp_eps), a0 an UNclamped skewed-Levy
+ * draw, z ~ N(0,1) (Philox).  Replaces the x_T init: GenerativeLevyProcess.py:313 -> gen_sas,
+ * Distributions.py:57-73. */
+int dlpm_init_state_philox_f32(float *x_dev, int64_t B, int64_t D, double alpha, double clamp_eps,
+                               float barsigma_last, uint64_t seed, int64_t sample_offset,
+                               dlpm_stream_t stream);
+
+/* Sigma recursion + per-step coefficients from A[T,B] and the schedule (device pointers, [T]):
+ *   Sigma_t = s_t^2 A_t + g_t^2 Sigma_{t-1};  Gamma_t = 1 - g_t^2 Sigma_{t-1}/Sigma_t
+ *   c_eps[t,b] = bs_t * Gamma_t ;  c_noise[t,b] = 1[t != 1] * sqrt(Gamma_t * Sigma_{t-1})
+ * rows t = 1..T-1 are written (row 0 is zeroed).  sigmas_out_dev (nullable) receives Sigma[T,B].
+ * Replaces compute_Sigmas / compute_Gamma_t / compute_Sigma_tilde_t_1: dlpm.py:230-257. */
+int dlpm_coeff_tables_f32(const float *A_dev, const float *g_dev, const float *s_dev, const float *bs_dev,
+                          int T, int64_t B, float *c_eps_dev, float *c_noise_dev, float *sigmas_out_dev,
+                          dlpm_stream_t stream);
+
+enum dlpm_update_flags {
+    DLPM_UPD_DLIM = 1,        /* deterministic / DLIM step instead of the stochastic DLPM step */
+    DLPM_UPD_CLIP = 2,        /* clip_denoised: eps <- predict_eps(clamp(predict_xstart)) first  */
+    DLPM_UPD_ADVANCE = 4      /* after the update, thread 0 decrements *t_dev (graph replay)     */
+};
+
+typedef struct dlpm_update_args {
+    float *x_dev;             /* [B,D] state, updated in place                                   */
+    const float *eps_dev;     /* [B,D] model output                                              */
+    const float *z_dev;       /* [B,D] injected N(0,1) noise, or NULL = in-kernel Philox         */
+    const int32_t *t_dev;     /* device scalar: current step index t in [1, T-1]                 */
+    const float *g_dev, *bg_dev, *bs_dev;      /* schedule, [T]                                  */
+    const float *c_eps_dev, *c_noise_dev;      /* [T,B] from dlpm_coeff_tables_f32               */
+    const float *A_dev;       /* [T,B], only read for DLIM with eta > 0                          */
+    int64_t B, D;
+    int32_t T;
+    int32_t flags;            /* dlpm_update_flags                                               */
+    float dlim_eta;
+    float alpha;
+    uint64_t seed;            /* Philox key                                                      */
+    int64_t sample_offset;    /* global index of sample 0 of this shard                          */
+} dlpm_update_args;
+
+/* One reverse step on the whole batch:
+ *   DLPM: x <- (x - c_eps[t,b] eps)/g_t + c_noise[t,b] z     dlpm.py:272-278, GenerativeLevyProcess.py:225-239
+ *   DLIM: x <- (x - bs_t eps)/g_t + bs_{t-1} eps  (eta = 0)   dlpm.py:281-297
+ *   CLIP: eps <- (x - clamp((x - eps bs_t)/bg_t, -1, 1) bg_t)/bs_t first   GenerativeLevyProcess.py:186-207
+ * HBM-bound: 12 B/element with Philox noise, 16 B/element with injected z. */
+int dlpm_update_f32(const dlpm_update_args *args, dlpm_stream_t stream);
+
+/* tvec_dev[b] = float(*t_dev) * (1/T): the `t/T` the reference feeds the net
+ * (GenerativeLevyProcess._scale_timesteps, :92-96). */
+int dlpm_fill_scaled_t_f32(float *tvec_dev, const int32_t *t_dev, int32_t T, int64_t B, dlpm_stream_t stream);
+
+/* samples_dev <- clamp(x, -c, c) then (x+1)/2 for images: GenerationManager.generate post-processing,
+ * bem/GenerationManager.py:50-63, bem/datasets/__init__.py:108-109. */
+int dlpm_postprocess_f32(const float *x_dev, float *out_dev, int64_t n, float clamp, int affine, dlpm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Score networks
+ * ------------------------------------------------------------------------------------------ */
+
+typedef struct dlpm_unet_config {
+    int32_t in_channels, model_channels, out_channels, num_res_blocks;
+    int32_t num_heads, image_size;
+    int32_t n_mult, channel_mult[8];
+    int32_t n_attn, attention_resolutions[8];
+} dlpm_unet_config;                 /* = the arguments of _unet_model: dlpm/dlpm_experiment.py:38-56 */
+
+typedef struct dlpm_unet dlpm_unet; /* opaque; owns device copies of the weights */
+
+int dlpm_unet_create(const dlpm_unet_config *cfg, dlpm_unet **out);
+/* Upload one tensor by its reference state_dict key (e.g. "input_blocks.7.1.qkv.weight"), from a
+ * host fp32 buffer in the reference's layout (OIHW conv weights etc.); the library re-lays it out. */
+int dlpm_unet_set_param(dlpm_unet *net, const char *key, const float *host_data, int64_t numel);
+/* Number of parameter tensors the architecture expects / a key by index (for loaders). */
+int dlpm_unet_num_params(const dlpm_unet *net);
+const char *dlpm_unet_param_key(const dlpm_unet *net, int index, int64_t *numel_out);
+int dlpm_unet_finalize(dlpm_unet *net);     /* all params set -> build the launch plan */
+int64_t dlpm_unet_workspace_bytes(const dlpm_unet *net, int64_t B);
+/* eps_dev[B,C,H,W] = UNet(x_dev[B,C,H,W], t_dev[B]) -- UNetModel.forward, dlpm/models/unet.py:463-492,
+ * with t already scaled (i/T floats).  Activations live in workspace_dev (NHWC, fp32). */
+int dlpm_unet_forward(dlpm_unet *net, const float *x_dev, const float *t_dev, float *eps_dev, int64_t B,
+                      void *workspace_dev, int64_t workspace_bytes, dlpm_stream_t stream);
+/* After a forward: copy block output `index` (0..n_in-1 down, then middle, then up blocks) to a
+ * device buffer as NCHW for bisecting against UNetModel.get_feature_vectors (unet.py:494-524). */
+int dlpm_unet_num_features(const dlpm_unet *net);
+int dlpm_unet_feature_shape(const dlpm_unet *net, int index, int32_t *C, int32_t *H, int32_t *W);
+int dlpm_unet_get_feature(dlpm_unet *net, int index, float *out_nchw_dev, int64_t B, dlpm_stream_t stream);
+int64_t dlpm_unet_flops_per_sample(const dlpm_unet *net);   /* 2*MAC, conv/linear/attention */
+void dlpm_unet_destroy(dlpm_unet *net);
+
+typedef struct dlpm_mlp dlpm_mlp;   /* MLPModel of 2d_data.yml: dlpm/models/Model.py:17-211 */
+int dlpm_mlp_create(int32_t nfeatures, int32_t nunits, int32_t nblocks, int32_t time_emb_size, dlpm_mlp **out);
+int dlpm_mlp_set_param(dlpm_mlp *net, const char *key, const float *host_data, int64_t numel);
+int dlpm_mlp_finalize(dlpm_mlp *net);
+/* eps_dev[B,1,F] = MLP(x_dev[B,1,F], t_dev[B]) -- MLPModel.forward, Model.py:148-211. */
+int dlpm_mlp_forward(dlpm_mlp *net, const float *x_dev, const float *t_dev, float *eps_dev, int64_t B,
+                     dlpm_stream_t stream);
+void dlpm_mlp_destroy(dlpm_mlp *net);
+
+/* ------------------------------------------------------------------------------------------
+ * Building-block launches (exported so each kernel can be parity-tested through the C ABI)
+ * ------------------------------------------------------------------------------------------ */
+
+typedef struct dlpm_conv_args {
+    const float *src0, *src1;   /* NHWC inputs [B,Hin,Win,C0] and [B,Hin,Win,C1] (virtual channel concat; src1 may be NULL) */
+    int32_t C0, C1;
+    int32_t B, Hin, Win, Hout, Wout;
+    int32_t ksize;              /* 1 or 3 (padding = ksize/2) */
+    int32_t stride;             /* 1 or 2 */
+    int32_t upsample;           /* 1: nearest x2 upsample fused into the loads (Upsample, unet.py:73) */
+    const float *weight;        /* OIHW, as in the reference state_dict, on the DEVICE */
+    const float *bias;          /* [Cout] or NULL */
+    const float *coefA, *coefB; /* [B, C0+C1] fused normalisation y = x*A + B (NULL: none) */
+    int32_t act_silu;           /* apply SiLU after the affine (GN -> SiLU -> conv) */
+    const float *res0, *res1;   /* residual added in the epilogue, NHWC at output size (virtual concat) */
+    int32_t R0;
+    float *out;                 /* NHWC [B,Hout,Wout,Cout] */
+    int32_t Cout;
+    int32_t in_nchw, out_nchw;  /* boundary layouts (direct kernel only) */
+    int32_t force_direct;       /* 1: use the direct (non-MFMA) kernel regardless of shape */
+} dlpm_conv_args;
+
+/* conv2d / conv1d(k=1) / Linear as implicit GEMM on the fp32 MFMA (or the direct kernel for
+ * channel counts the MFMA tiling does not cover).  Takes OIHW weights and re-lays them out into a
+ * scratch buffer (scratch_dev, >= 2*weight bytes) -- test/bring-up entry point; the UNet handle
+ * pre-transforms its weights once.  Replaces F.conv2d / conv1d / linear: unet.py:64,96,143,157,168,213,215. */
+int dlpm_conv2d_f32(const dlpm_conv_args *args, float *scratch_dev, dlpm_stream_t stream);
+
+/* GroupNorm statistics -> per-(sample, channel) affine coefficients, optionally folding the
+ * ResBlock scale/shift: y = GN(x)*(1+scale)+shift == x*A + B.  x is NHWC (virtual concat).
+ * ss_dev: [B, ss_stride] rows holding [scale(C) | shift(C)] at column ss_offset, or NULL.
+ * Replaces GroupNorm32 + the scale-shift of ResBlock._forward: nn.py:17-19, unet.py:187-191. */
+int dlpm_groupnorm_coeffs_f32(const float *src0, const float *src1, int32_t C0, int32_t C1, int32_t B, int32_t HW,
+                              int32_t groups, const float *gamma_dev, const float *beta_dev,
+                              const float *ss_dev, int64_t ss_stride, int64_t ss_offset,
+                              float *coefA_dev, float *coefB_dev, dlpm_stream_t stream);
+
+/* QKVAttention over qkv[B,T,3C] (NHWC; channel layout head-major [head][q|k|v][C/heads] as produced
+ * by the reference's reshape) -> out[B,T,C].  QK^T and PV on the fp32 MFMA, softmax in fp32.
+ * Replaces QKVAttention.forward: unet.py:236-250. */
+int dlpm_attention_f32(const float *qkv_dev, float *out_dev, int32_t B, int32_t T, int32_t C, int32_t heads,
+                       dlpm_stream_t stream);
+
+/* emb_dev[B,dim] = [cos(t f_i) | sin(t f_i)]: timestep_embedding, nn.py:103-121. */
+int dlpm_timestep_embedding_f32(const float *t_dev, float *emb_dev, int64_t B, int32_t dim, dlpm_stream_t stream);
+
+/* layout helpers */
+int dlpm_nchw_to_nhwc_f32(const float *src, float *dst, int32_t B, int32_t C, int32_t H, int32_t W, dlpm_stream_t stream);
+int dlpm_nhwc_to_nchw_f32(const float *src, float *dst, int32_t B, int32_t C, int32_t H, int32_t W, dlpm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sampler: the T-step loop as a replayed hipGraph
+ * ------------------------------------------------------------------------------------------ */
+
+typedef struct dlpm_sampler_config {
+    dlpm_unet *unet;            /* exactly one of unet / mlp is non-NULL */
+    dlpm_mlp *mlp;
+    int64_t B;                  /* samples on this GPU */
+    int32_t C, H, W;            /* per-sample shape (toy data: C=1, H=1, W=nfeatures) */
+    int32_t T;                  /* reverse steps */
+    double alpha;
+    double clamp_a, clamp_eps;  /* < 0: none */
+    int32_t flags;              /* DLPM_UPD_DLIM | DLPM_UPD_CLIP */
+    float dlim_eta;
+    uint64_t seed;
+    int64_t sample_offset;      /* global index of this shard's first sample */
+    int32_t use_graph;          /* 1: capture one step into a hipGraph and replay it */
+    const float *g, *bg, *s, *bs; /* host schedule [T] each, or all NULL = dlpm_schedule_f32(T, alpha) */
+} dlpm_sampler_config;
+
+typedef struct dlpm_sampler dlpm_sampler;
+
+int dlpm_sampler_create(const dlpm_sampler_config *cfg, dlpm_sampler **out);
+/* New Philox key / shard offset for the next begin() (drops the captured graph, keeps the buffers). */
+int dlpm_sampler_reseed(dlpm_sampler *s, uint64_t seed, int64_t sample_offset);
+/* Draw A (Philox), build the tables, draw x_T; sets t = T-1.  p_sample_loop_progressive prologue:
+ * GenerativeLevyProcess.py:306-315. */
+int dlpm_sampler_begin(dlpm_sampler *s, dlpm_stream_t stream);
+/* Same prologue with caller-provided noise (parity with the CPU reference on identical seeds):
+ * A_dev[T,B] and xT_dev[B,C,H,W] are copied in; the tables are built from A. */
+int dlpm_sampler_begin_injected(dlpm_sampler *s, const float *A_dev, const float *xT_dev, dlpm_stream_t stream);
+/* One reverse step with caller-provided N(0,1) noise z_dev[B,C,H,W] (eager, no graph). */
+int dlpm_sampler_step_injected(dlpm_sampler *s, const float *z_dev, dlpm_stream_t stream);
+/* Run `nsteps` reverse steps (model forward + fused update), stopping at t == 0.  Loop body of
+ * p_sample_loop_progressive: GenerativeLevyProcess.py:317-330. */
+int dlpm_sampler_steps(dlpm_sampler *s, int32_t nsteps, dlpm_stream_t stream);
+/* Copy the current state x[B,C,H,W] into a caller buffer (device to device, on `stream`). */
+int dlpm_sampler_copy_state(dlpm_sampler *s, float *out_dev, dlpm_stream_t stream);
+/* Device pointer to the current state x[B,C,H,W] and the current t (host copy). */
+float *dlpm_sampler_state(dlpm_sampler *s);
+int32_t dlpm_sampler_t(const dlpm_sampler *s);
+/* Device pointers to the sampler's tables (for tests): which = 0 A, 1 c_eps, 2 c_noise, 3 eps. */
+float *dlpm_sampler_table(dlpm_sampler *s, int which);
+void dlpm_sampler_destroy(dlpm_sampler *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DLPM_AMD_H */

@@ -1,0 +1,387 @@
+"""Parity of each HIP kernel, called through the C ABI, against the oracle (CPU) on seeded inputs.
+
+fp32 tolerances are written at each assert.  Marked gpu: runs on the MI355X box only."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden
+from dlpm_amd import _lib
+from oracle import nets, process as P
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def L():
+    return _lib.lib()
+
+
+def st():
+    return _lib.stream_ptr()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def run_conv(x0, w, bias=None, x1=None, stride=1, ups=0, coef=None, silu=False, res=None, in_nchw=False,
+             out_nchw=False, force_direct=False):
+    """x0/x1: NCHW cpu tensors; returns NCHW cpu output of the HIP conv."""
+    B, C0, Hin, Win = x0.shape
+    Cout, Cin, ks, _ = w.shape
+    Hi, Wi = (Hin * 2, Win * 2) if ups else (Hin, Win)
+    pad = ks // 2
+    Hout, Wout = (Hi + 2 * pad - ks) // stride + 1, (Wi + 2 * pad - ks) // stride + 1
+    a = _lib.ConvArgs()
+    keep = []
+
+    def dev(t):
+        t = t.to(DEV).contiguous()
+        keep.append(t)
+        return t.data_ptr()
+    a.src0 = dev(x0 if in_nchw else nhwc(x0))
+    a.C0 = C0
+    if x1 is not None:
+        a.src1, a.C1 = dev(nhwc(x1)), x1.shape[1]
+    a.B, a.Hin, a.Win, a.Hout, a.Wout = B, Hin, Win, Hout, Wout
+    a.ksize, a.stride, a.upsample = ks, stride, ups
+    a.weight = dev(w)
+    if bias is not None:
+        a.bias = dev(bias)
+    if coef is not None:
+        a.coefA, a.coefB = dev(coef[0]), dev(coef[1])
+    a.act_silu = int(silu)
+    if res is not None:
+        a.res0, a.R0 = dev(nhwc(res)), Cout
+    out = torch.empty((B, Cout, Hout, Wout) if out_nchw else (B, Hout, Wout, Cout), device=DEV)
+    a.out, a.Cout = out.data_ptr(), Cout
+    a.in_nchw, a.out_nchw, a.force_direct = int(in_nchw), int(out_nchw), int(force_direct)
+    scratch = torch.empty(2 * w.numel() + 64, device=DEV)
+    _lib.check(L().dlpm_conv2d_f32(C.byref(a), scratch.data_ptr(), st()))
+    torch.cuda.synchronize()
+    return (out if out_nchw else nchw(out)).cpu()
+
+
+def ref_conv(x0, w, bias=None, x1=None, stride=1, ups=0, coef=None, silu=False, res=None):
+    x = x0 if x1 is None else torch.cat([x0, x1], 1)
+    if coef is not None:
+        x = x * coef[0][:, :, None, None] + coef[1][:, :, None, None]
+    if silu:
+        x = nets.silu(x)
+    if ups:
+        x = F.interpolate(x, scale_factor=2, mode='nearest')
+    y = F.conv2d(x.double(), w.double(), None if bias is None else bias.double(), stride=stride, padding=w.shape[2] // 2)
+    if res is not None:
+        y = y + res.double()
+    return y.float()
+
+
+def conv_tol(w, Cin):
+    # fp32 accumulation over K = taps*Cin terms of O(1) magnitude: error ~ sqrt(K) * 1e-7 * |terms|
+    return 3e-6 * math.sqrt(w.shape[2] * w.shape[3] * Cin)
+
+
+CONV_CASES = [
+    # name, B, C0, C1, H, Cout, ks, stride, ups, coef, silu, res
+    ('igemm_3x3_128', 2, 128, 0, 8, 128, 3, 1, 0, False, False, False),
+    ('igemm_3x3_fused_gn_silu_res', 3, 64, 0, 8, 64, 3, 1, 0, True, True, True),
+    ('igemm_3x3_concat', 2, 64, 32, 8, 64, 3, 1, 0, True, True, False),
+    ('igemm_1x1_concat_skip', 2, 64, 32, 4, 32, 1, 1, 0, False, False, False),
+    ('igemm_3x3_stride2', 2, 32, 0, 16, 32, 3, 2, 0, False, False, False),
+    ('igemm_3x3_upsample', 2, 64, 0, 4, 64, 3, 1, 1, False, False, False),
+    ('igemm_cout_256_tail', 1, 128, 0, 4, 256, 3, 1, 0, False, False, True),
+    ('igemm_cout_96', 2, 32, 0, 8, 96, 1, 1, 0, True, False, False),
+    ('igemm_ragged_m', 3, 32, 0, 4, 32, 3, 1, 0, False, True, False),     # M = 48 < one 128-pixel tile
+    ('igemm_32x32_rows', 1, 32, 0, 32, 64, 3, 1, 0, True, True, True),
+    ('direct_odd_channels', 2, 24, 0, 8, 40, 3, 1, 0, True, True, True),
+    ('direct_concat_1x1', 2, 8, 16, 4, 8, 1, 1, 0, False, False, False),
+    ('direct_stride2', 2, 8, 0, 8, 8, 3, 2, 0, False, False, False),
+    ('direct_upsample', 2, 8, 0, 4, 8, 3, 1, 1, False, False, False),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv(case):
+    name, B, C0, C1, H, Cout, ks, stride, ups, use_coef, silu, use_res = case
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    Cin = C0 + C1
+    x0 = torch.randn(B, C0, H, H, generator=g)
+    x1 = torch.randn(B, C1, H, H, generator=g) if C1 else None
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)
+    bias = torch.randn(Cout, generator=g)
+    coef = (1 + 0.3 * torch.randn(B, Cin, generator=g), 0.3 * torch.randn(B, Cin, generator=g)) if use_coef else None
+    Ho = (H * (2 if ups else 1) + 2 * (ks // 2) - ks) // stride + 1
+    res = torch.randn(B, Cout, Ho, Ho, generator=g) if use_res else None
+    want = ref_conv(x0, w, bias, x1, stride, ups, coef, silu, res)
+    got = run_conv(x0, w, bias, x1, stride, ups, coef, silu, res)
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() < conv_tol(w, Cin), name
+    if 'igemm' in name:  # same shape through the direct kernel: the two kernels agree with each other
+        got_d = run_conv(x0, w, bias, x1, stride, ups, coef, silu, res, force_direct=True)
+        assert (got_d - want).abs().max().item() < conv_tol(w, Cin), name + ' (direct)'
+
+
+def test_conv_boundary_layouts():
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 8, 8, generator=g)
+    w = torch.randn(32, 3, 3, 3, generator=g) / 5
+    b = torch.randn(32, generator=g)
+    got = run_conv(x, w, b, in_nchw=True)          # stem: reads the caller's NCHW state
+    assert (got - ref_conv(x, w, b)).abs().max().item() < 1e-5
+    h = torch.randn(2, 32, 8, 8, generator=g)
+    w2 = torch.randn(3, 32, 3, 3, generator=g) / 17
+    b2 = torch.randn(3, generator=g)
+    coef = (1 + 0.3 * torch.randn(2, 32, generator=g), 0.3 * torch.randn(2, 32, generator=g))
+    got = run_conv(h, w2, b2, coef=coef, silu=True, out_nchw=True)   # head: writes NCHW eps
+    assert (got - ref_conv(h, w2, b2, coef=coef, silu=True)).abs().max().item() < 2e-5
+
+
+def test_linear_as_conv():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(37, 128, generator=g)
+    w = torch.randn(512, 128, generator=g) / 11
+    b = torch.randn(512, generator=g)
+    got = run_conv(x[:, :, None, None], w[:, :, None, None], b, silu=True)
+    want = F.linear(nets.silu(x).double(), w.double(), b.double()).float()
+    assert (got[:, :, 0, 0] - want).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize('C,hw', [(32, 8), (96, 4), (128, 8), (384, 4)])
+def test_groupnorm_coeffs_against_reference_fixture(C, hw):
+    f = golden('f7_layers')
+    tag = 'gn_C%d_hw%d' % (C, hw)
+    x = torch.from_numpy(f[tag + '_x'])
+    B = x.shape[0]
+    xd = nhwc(x).to(DEV)
+    gam, bet = torch.from_numpy(f[tag + '_w']).to(DEV), torch.from_numpy(f[tag + '_b']).to(DEV)
+    cA, cB = torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV)
+    _lib.check(L().dlpm_groupnorm_coeffs_f32(xd.data_ptr(), None, C, 0, B, hw * hw, 32, gam.data_ptr(), bet.data_ptr(),
+                                            None, 0, 0, cA.data_ptr(), cB.data_ptr(), st()))
+    y = x * cA.cpu()[:, :, None, None] + cB.cpu()[:, :, None, None]
+    # GroupNorm output is O(1); fp32 statistics over (C/32)*hw*hw elements
+    np.testing.assert_allclose(y.numpy(), f[tag + '_y'], atol=3e-6)
+    # scale/shift folded in, virtual concat split at a point that cuts a group when C/32 does not divide it
+    ss = torch.cat([torch.from_numpy(f[tag + '_sc']).reshape(B, C), torch.from_numpy(f[tag + '_sh']).reshape(B, C)], 1)
+    ss_pad = torch.zeros(B, 2 * C + 7)
+    ss_pad[:, 5:5 + 2 * C] = ss
+    ssd = ss_pad.to(DEV)
+    c0 = 64 if C == 96 else (256 if C == 384 else C // 2)
+    x0, x1 = nhwc(x[:, :c0]).to(DEV), nhwc(x[:, c0:]).to(DEV)
+    _lib.check(L().dlpm_groupnorm_coeffs_f32(x0.data_ptr(), x1.data_ptr(), c0, C - c0, B, hw * hw, 32, gam.data_ptr(),
+                                            bet.data_ptr(), ssd.data_ptr(), 2 * C + 7, 5, cA.data_ptr(), cB.data_ptr(), st()))
+    y = nets.silu(x * cA.cpu()[:, :, None, None] + cB.cpu()[:, :, None, None])
+    np.testing.assert_allclose(y.numpy(), f[tag + '_y_ss_silu'], atol=4e-6)
+
+
+@pytest.mark.parametrize('ch,T', [(16, 64), (64, 16), (16, 256), (64, 64)])
+def test_attention_against_reference_fixture(ch, T):
+    f = golden('f7_layers')
+    qkv = torch.from_numpy(f['qkv_ch%d_T%d_in' % (ch, T)])      # [N = b*heads, 3ch, T], b = 1, heads = 3
+    heads = qkv.shape[0]
+    Cc = heads * ch
+    # [heads, 3ch, T] -> NHWC [1, T, heads*3ch] (head-major channels)
+    x = qkv.permute(2, 0, 1).reshape(1, T, heads * 3 * ch).contiguous().to(DEV)
+    out = torch.empty(1, T, Cc, device=DEV)
+    _lib.check(L().dlpm_attention_f32(x.data_ptr(), out.data_ptr(), 1, T, Cc, heads, st()))
+    got = out.cpu().reshape(T, heads, ch).permute(1, 2, 0)       # [heads, ch, T]
+    np.testing.assert_allclose(got.numpy(), f['qkv_ch%d_T%d_out' % (ch, T)], atol=3e-6)
+
+
+def test_attention_batched_heads():
+    g = torch.Generator().manual_seed(6)
+    B, heads, ch, T = 5, 4, 16, 64
+    qkv = torch.randn(B * heads, 3 * ch, T, generator=g)
+    want = nets.qkv_attention(qkv).reshape(B, heads * ch, T)
+    x = qkv.reshape(B, heads * 3 * ch, T).permute(0, 2, 1).contiguous().to(DEV)
+    out = torch.empty(B, T, heads * ch, device=DEV)
+    _lib.check(L().dlpm_attention_f32(x.data_ptr(), out.data_ptr(), B, T, heads * ch, heads, st()))
+    np.testing.assert_allclose(out.cpu().permute(0, 2, 1).numpy(), want.numpy(), atol=3e-6)
+
+
+def test_timestep_embedding():
+    f = golden('f7_layers')
+    t = torch.from_numpy(f['temb_t']).to(DEV)
+    for dim in (32, 128):
+        e = torch.empty(t.numel(), dim, device=DEV)
+        _lib.check(L().dlpm_timestep_embedding_f32(t.data_ptr(), e.data_ptr(), t.numel(), dim, st()))
+        # arguments up to 17 rad: sin/cos abs error ~ ulp(arg)
+        np.testing.assert_allclose(e.cpu().numpy(), f['temb_dim%d' % dim], atol=2e-6)
+
+
+def test_layout_roundtrip():
+    x = torch.randn(3, 5, 4, 6)
+    xd = x.to(DEV)
+    a, b = torch.empty(3, 4, 6, 5, device=DEV), torch.empty_like(xd)
+    _lib.check(L().dlpm_nchw_to_nhwc_f32(xd.data_ptr(), a.data_ptr(), 3, 5, 4, 6, st()))
+    _lib.check(L().dlpm_nhwc_to_nchw_f32(a.data_ptr(), b.data_ptr(), 3, 5, 4, 6, st()))
+    assert torch.equal(a.cpu(), nhwc(x)) and torch.equal(b.cpu(), x)
+
+
+# ------------------------------------------------------------------------------ noise / tables / update
+def test_coeff_tables_bit_exact():
+    f = golden('f3_sigma_tables')
+    A, g, s, bs = (torch.from_numpy(f[k]).to(DEV) for k in ['A', 'g', 's', 'bs'])
+    T, B = A.shape
+    ce, cn, sig = torch.empty_like(A), torch.empty_like(A), torch.empty_like(A)
+    _lib.check(L().dlpm_coeff_tables_f32(A.data_ptr(), g.data_ptr(), s.data_ptr(), bs.data_ptr(), T, B, ce.data_ptr(),
+                                        cn.data_ptr(), sig.data_ptr(), st()))
+    assert np.array_equal(sig.cpu().numpy(), f['Sigmas'])                       # same fp32 op order: bit-exact
+    Gam, var = f['Gamma_1_to_T'], f['var_1_to_T']
+    assert np.array_equal(ce.cpu().numpy()[1:], (f['bs'][1:, None] * Gam).astype(np.float32))
+    want_cn = np.sqrt(var)
+    want_cn[0] = 0.0                                                             # t == 1: no noise
+    np.testing.assert_allclose(cn.cpu().numpy()[1:], want_cn, rtol=1.2e-7)
+
+
+def _update(x, eps, z, t, tabs, flags=0, eta=0.0, alpha=1.7, seed=0, offset=0):
+    g, bg, bs, ce, cn, A = tabs
+    T, B = A.shape
+    a = _lib.UpdateArgs()
+    xd = x.to(DEV).contiguous()
+    ed = eps.to(DEV).contiguous()
+    zd = z.to(DEV).contiguous() if z is not None else None
+    td = torch.tensor([t], dtype=torch.int32, device=DEV)
+    a.x_dev, a.eps_dev, a.z_dev, a.t_dev = xd.data_ptr(), ed.data_ptr(), zd.data_ptr() if zd is not None else None, td.data_ptr()
+    a.g_dev, a.bg_dev, a.bs_dev = g.data_ptr(), bg.data_ptr(), bs.data_ptr()
+    a.c_eps_dev, a.c_noise_dev, a.A_dev = ce.data_ptr(), cn.data_ptr(), A.data_ptr()
+    a.B, a.D, a.T, a.flags, a.dlim_eta, a.alpha = B, x[0].numel(), T, flags, eta, alpha
+    a.seed, a.sample_offset = seed, offset
+    _lib.check(L().dlpm_update_f32(C.byref(a), st()))
+    torch.cuda.synchronize()
+    return xd.cpu(), td.cpu().item()
+
+
+def _tables(f):
+    A, g, bg, s, bs = (torch.from_numpy(f[k]).to(DEV) for k in ['A', 'g', 'bg', 's', 'bs'])
+    T, B = A.shape
+    ce, cn = torch.empty_like(A), torch.empty_like(A)
+    _lib.check(L().dlpm_coeff_tables_f32(A.data_ptr(), g.data_ptr(), s.data_ptr(), bs.data_ptr(), T, B, ce.data_ptr(),
+                                        cn.data_ptr(), None, st()))
+    return g, bg, bs, ce, cn, A
+
+
+def test_update_against_reference_single_step():
+    f = golden('f4_single_step')
+    tabs = _tables(f)
+    x, eps = torch.from_numpy(f['x']), torch.from_numpy(f['eps'])
+    z = torch.randn(x.shape, generator=torch.Generator().manual_seed(1))
+    for t in (1, 2, 17, 49):
+        mean = torch.from_numpy(f['dlpm_mean_t%d' % t])
+        var = torch.from_numpy(f['dlpm_var_t%d' % t]).view(-1, 1, 1, 1)
+        want = mean + (0.0 if t == 1 else 1.0) * torch.sqrt(var) * z
+        got, _ = _update(x, eps, z, t, tabs)
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=3e-7, atol=1e-6)   # same op order, 1-2 ulp
+        got, tn = _update(x, eps, None, t, tabs, flags=_lib.UPD_DLIM | _lib.UPD_ADVANCE)
+        assert tn == t - 1
+        np.testing.assert_allclose(got.numpy(), f['dlim0_t%d' % t], rtol=3e-7, atol=1e-6)
+        z0 = torch.zeros_like(x)
+        got, _ = _update(x, eps, z0, t, tabs, flags=_lib.UPD_DLIM, eta=0.5)
+        np.testing.assert_allclose(got.numpy(), f['dlim05_mean_t%d' % t], rtol=2e-6, atol=2e-6)
+        # clip branch: eps' then the DLPM mean
+        e2 = torch.from_numpy(f['eps_from_clipped_xstart_t%d' % t])
+        Sig = P.sigma_table(tabs[5].cpu(), tabs[0].cpu(), torch.from_numpy(f['s']))
+        want, _, _ = P.dlpm_step(x, e2, t, Sig, tabs[0].cpu(), tabs[2].cpu(), z)
+        got, _ = _update(x, eps, z, t, tabs, flags=_lib.UPD_CLIP)
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-6, atol=2e-6)
+
+
+def test_update_scalar_path_toy_shape():
+    """D = 2 (toy data) takes the non-vectorised path."""
+    f = golden('f5_traj_synth_toy')
+    T, alpha = int(f['meta'][0]), float(f['meta'][1])
+    g, bg, s, bs = P.schedule(T, alpha)
+    ff = dict(A=f['A'], g=g.numpy(), bg=bg.numpy(), s=s.numpy(), bs=bs.numpy())
+    tabs = _tables(ff)
+    hist, z = torch.from_numpy(f['history']), torch.from_numpy(f['z'])
+    for k, t in [(0, T - 1), (40, T - 41), (98, 1)]:
+        x = hist[k]
+        eps = 0.5 * x + float(t) * (1.0 / T)
+        got, _ = _update(x, eps, z[k], t, tabs)
+        want = hist[k + 1]
+        assert (got - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item())
+
+
+def test_philox_noise_statistics_and_sharding():
+    B, D, T, alpha = 4096, 64, 8, 1.7
+    A = torch.empty(T, B, device=DEV)
+    _lib.check(L().dlpm_skewed_levy_philox_f32(A.data_ptr(), T, B, alpha, -1.0, 123, 0, st()))
+    a = A.cpu().numpy().ravel().astype(np.float64)
+    assert np.all(a > 0) and np.all(np.isfinite(a))
+    import scipy.stats
+    scale = 2 * np.cos(np.pi * alpha / 4) ** (2 / alpha)
+    qs = np.array([0.1, 0.25, 0.5, 0.75, 0.9])
+    want_q = scipy.stats.levy_stable.ppf(qs, alpha / 2, 1, loc=0, scale=scale)
+    # (= [1.18521284, 1.37370291, 1.75562623, 2.67362479, 5.30812354] with scipy 1.15.3)
+    got_q = np.quantile(a, qs)
+    # 32768 draws: quantile standard error ~ sqrt(q(1-q)/n)/pdf ~ 1-2 %
+    np.testing.assert_allclose(got_q, want_q, rtol=0.06)
+    # clamp and the alpha == 2 constant
+    _lib.check(L().dlpm_skewed_levy_philox_f32(A.data_ptr(), T, B, alpha, 10.0, 123, 0, st()))
+    assert A.max().item() <= 10.0 and A.min().item() >= 0.0
+    _lib.check(L().dlpm_skewed_levy_philox_f32(A.data_ptr(), T, B, 2.0, -1.0, 123, 0, st()))
+    assert torch.all(A == 2.0).item()
+    # sharding invariance: rows [b0, b1) drawn with sample_offset = b0 equal the slice of the full draw
+    full = torch.empty(T, B, device=DEV)
+    _lib.check(L().dlpm_skewed_levy_philox_f32(full.data_ptr(), T, B, alpha, -1.0, 9, 0, st()))
+    part = torch.empty(T, B // 4, device=DEV)
+    _lib.check(L().dlpm_skewed_levy_philox_f32(part.data_ptr(), T, B // 4, alpha, -1.0, 9, B // 2, st()))
+    assert torch.equal(part.cpu(), full.cpu()[:, B // 2:B // 2 + B // 4])
+    # x_T init: z statistics (alpha = 2 -> a0 = 2, x = bs * sqrt(2) z)
+    x = torch.empty(B, D, device=DEV)
+    _lib.check(L().dlpm_init_state_philox_f32(x.data_ptr(), B, D, 2.0, -1.0, 1.0, 5, 0, st()))
+    zz = (x.cpu().numpy().ravel() / math.sqrt(2.0)).astype(np.float64)
+    n = zz.size
+    assert abs(zz.mean()) < 5 / math.sqrt(n) and abs(zz.var() - 1) < 5 * math.sqrt(2 / n)
+    assert abs((zz ** 4).mean() - 3) < 0.1 and scipy.stats.kstest(zz[:20000], 'norm').pvalue > 1e-4
+    xs = torch.empty(B // 2, D, device=DEV)
+    _lib.check(L().dlpm_init_state_philox_f32(xs.data_ptr(), B // 2, D, 2.0, -1.0, 1.0, 5, B // 2, st()))
+    assert torch.equal(xs.cpu(), x.cpu()[B // 2:])
+
+
+def test_update_philox_is_linear_and_shard_invariant_at_full_size():
+    """BASELINE config 3 size (B=1024, D=3072): properties that need no oracle at this size.
+    x' = (x - c_eps eps)/g + c_noise z(seed, sample, t): affine in (x, eps) for fixed noise."""
+    B, D, T, alpha = 1024, 3072, 1000, 1.7
+    g, bg, s, bs = (v.to(DEV) for v in P.schedule(T, alpha))
+    A = torch.empty(T, B, device=DEV)
+    _lib.check(L().dlpm_skewed_levy_philox_f32(A.data_ptr(), T, B, alpha, 10.0, 7, 0, st()))
+    ce, cn = torch.empty_like(A), torch.empty_like(A)
+    _lib.check(L().dlpm_coeff_tables_f32(A.data_ptr(), g.data_ptr(), s.data_ptr(), bs.data_ptr(), T, B, ce.data_ptr(),
+                                        cn.data_ptr(), None, st()))
+    tabs = (g, bg, bs, ce, cn, A)
+    gen = torch.Generator().manual_seed(3)
+    x, e = torch.randn(B, D, generator=gen), torch.randn(B, D, generator=gen)
+    t = 500
+    zero = torch.zeros(B, D)
+    n0, _ = _update(zero, zero, None, t, tabs, seed=11)          # pure noise term
+    full, _ = _update(x, e, None, t, tabs, seed=11)
+    det, _ = _update(x, e, zero, t, tabs, seed=11)               # injected z = 0: deterministic part
+    assert (full - (det + n0)).abs().max().item() <= 1e-5 * full.abs().max().item()
+    # noise term has the right per-sample scale
+    ratio = n0.std(dim=1) / cn[t].cpu()
+    assert (ratio - 1).abs().max().item() < 0.08
+    # shard invariance: the second half processed alone with sample_offset = B/2
+    tabs_h = (g, bg, bs, ce[:, B // 2:].contiguous(), cn[:, B // 2:].contiguous(), A[:, B // 2:].contiguous())
+    half, _ = _update(x[B // 2:], e[B // 2:], None, t, tabs_h, seed=11, offset=B // 2)
+    assert torch.equal(half, full[B // 2:])
+    # a different seed or step gives different noise
+    other, _ = _update(zero, zero, None, t, tabs, seed=12)
+    assert not torch.equal(other, n0)
+
+
+def test_postprocess_matches_generation_manager_fixture():
+    f = golden('f8_generation_manager')
+    for tag, clamp, aff in (('img', 1.0, 1), ('toy', 6.0, 0)):
+        x = torch.from_numpy(f[tag + '_x']).to(DEV)
+        o = torch.empty_like(x)
+        _lib.check(L().dlpm_postprocess_f32(x.data_ptr(), o.data_ptr(), x.numel(), clamp, aff, st()))
+        assert np.array_equal(o.cpu().numpy(), f[tag + '_samples'])
