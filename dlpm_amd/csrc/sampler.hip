@@ -26,6 +26,11 @@ struct dlpm_sampler {
     int32_t t_host = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    // Graph capture is illegal on the legacy default stream (which is what torch hands out by
+    // default), so graph work runs on a private non-blocking stream fenced to the caller's stream
+    // with events at both ends of every dlpm_sampler_steps call.
+    hipStream_t own = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
 };
 
 namespace {
@@ -162,31 +167,51 @@ extern "C" int dlpm_sampler_step_injected(dlpm_sampler *s, const float *z_dev, d
     return DLPM_OK;
 }
 
+static int steps_on(dlpm_sampler *s, int32_t nsteps, hipStream_t st, bool graph) {
+    if (graph && !s->exec) {
+        // the first step runs eagerly (sets function attributes, pages code in), the second is captured
+        TRY(one_step(s, nullptr, true, st));
+        s->t_host -= 1;
+        nsteps -= 1;
+        if (nsteps == 0) return DLPM_OK;
+        DLPM_HIP(hipStreamSynchronize(st));
+        DLPM_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        int r = one_step(s, nullptr, true, st);
+        hipError_t e = hipStreamEndCapture(st, &s->graph);
+        if (r != DLPM_OK) {
+            if (s->graph) (void)hipGraphDestroy(s->graph);
+            s->graph = nullptr;
+            return r;
+        }
+        DLPM_HIP(e);
+        DLPM_HIP(hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0));
+    }
+    for (int i = 0; i < nsteps; i++) {
+        if (graph) DLPM_HIP(hipGraphLaunch(s->exec, st));
+        else TRY(one_step(s, nullptr, true, st));
+    }
+    s->t_host -= nsteps;
+    return DLPM_OK;
+}
+
 extern "C" int dlpm_sampler_steps(dlpm_sampler *s, int32_t nsteps, dlpm_stream_t stream) {
     DLPM_CHECK_ARG(s && nsteps >= 0, "dlpm_sampler_steps: bad argument");
     hipStream_t st = as_stream(stream);
     if (nsteps > s->t_host) nsteps = s->t_host;
     if (nsteps == 0) return DLPM_OK;
-    if (s->cfg.use_graph && !s->exec && !prof_enabled()) {
-        // warm-up step outside capture (sets function attributes, pages code in) is step 1 itself
-        TRY(one_step(s, nullptr, true, st));
-        s->t_host -= 1;
-        nsteps -= 1;
-        DLPM_HIP(hipStreamSynchronize(st));
-        if (nsteps == 0) return DLPM_OK;
-        DLPM_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-        int r = one_step(s, nullptr, true, st);
-        hipError_t e = hipStreamEndCapture(st, &s->graph);
-        if (r != DLPM_OK) return r;
-        DLPM_HIP(e);
-        DLPM_HIP(hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0));
+    const bool graph = s->cfg.use_graph && !prof_enabled();
+    if (!graph) return steps_on(s, nsteps, st, false);
+    if (!s->own) {
+        DLPM_HIP(hipStreamCreateWithFlags(&s->own, hipStreamNonBlocking));
+        DLPM_HIP(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
+        DLPM_HIP(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
     }
-    for (int i = 0; i < nsteps; i++) {
-        if (s->exec && !prof_enabled()) DLPM_HIP(hipGraphLaunch(s->exec, st));
-        else TRY(one_step(s, nullptr, true, st));
-    }
-    s->t_host -= nsteps;
-    return DLPM_OK;
+    DLPM_HIP(hipEventRecord(s->ev_in, st));            // everything the caller queued so far ...
+    DLPM_HIP(hipStreamWaitEvent(s->own, s->ev_in, 0)); // ... precedes the replayed steps
+    int r = steps_on(s, nsteps, s->own, true);
+    DLPM_HIP(hipEventRecord(s->ev_out, s->own));
+    DLPM_HIP(hipStreamWaitEvent(st, s->ev_out, 0));    // and the caller's later work follows them
+    return r;
 }
 
 extern "C" int dlpm_sampler_copy_state(dlpm_sampler *s, float *out_dev, dlpm_stream_t stream) {
@@ -212,6 +237,9 @@ extern "C" void dlpm_sampler_destroy(dlpm_sampler *s) {
     if (!s) return;
     if (s->exec) (void)hipGraphExecDestroy(s->exec);
     if (s->graph) (void)hipGraphDestroy(s->graph);
+    if (s->ev_in) (void)hipEventDestroy(s->ev_in);
+    if (s->ev_out) (void)hipEventDestroy(s->ev_out);
+    if (s->own) (void)hipStreamDestroy(s->own);
     void *bufs[] = {s->g, s->bg, s->s, s->bs, s->A, s->c_eps, s->c_noise, s->x, s->eps, s->tvec, s->t_dev, s->ws};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
