@@ -38,8 +38,9 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Optional per-launch timing (dlpm_prof_enable): brackets one launch with HIP events on its stream.
 bool prof_enabled();
+bool prof_detail();   // DLPM_PROF_DETAIL=1: one class per distinct launch shape
 struct ProfScope {
-    const char *name;
+    std::string name;
     double flops, bytes;
     hipStream_t st;
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -25,6 +25,14 @@ struct ConvLaunch {
 bool igemm_supported(const ConvLaunch &c);
 int launch_conv_igemm(const ConvLaunch &c, hipStream_t st);
 int launch_conv_direct(const ConvLaunch &c, hipStream_t st);
+int launch_conv_stem(const ConvLaunch &c, hipStream_t st);
+// non-MFMA shapes: the stem kernel when it applies, the generic direct kernel otherwise
+inline int launch_conv_fallback(const ConvLaunch &L, hipStream_t st) {
+    if (L.in_nchw && !L.out_nchw && L.ks == 3 && L.stride == 1 && !L.ups && L.C1 == 0 && L.Cout % 4 == 0 && !L.coefA &&
+        !L.act_silu && !L.res0 && L.bias)
+        return launch_conv_stem(L, st);
+    return launch_conv_direct(L, st);
+}  // NCHW in, 3x3 s1, Cout % 4 == 0, direct weight layout
 
 // weight re-layout kernels: OIHW -> [tap][Cout][Cin] (igemm) or [tap][Cin][Cout] (direct)
 int relayout_weight(const float *oihw_dev, float *dst_dev, int Cout, int Cin, int ks, bool for_igemm, hipStream_t st);

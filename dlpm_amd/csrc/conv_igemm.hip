@@ -16,6 +16,8 @@
 // (lane -> pixel row, 4 consecutive k) are bank-conflict free.  The k order inside a 32-channel
 // step is permuted identically for A and B (lane half h reads channels 8j+4h..8j+4h+3), which
 // lets every fragment load be one 16-byte LDS read feeding 4 MFMAs.
+#include <cstdlib>
+
 #include "conv.h"
 
 namespace dlpm {
@@ -181,10 +183,231 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvLaunch p) {
                 if (m >= M) continue;
                 float v = acc[i][j][r] + bias;
                 if (p.res0) v += (n < p.R0) ? p.res0[m * p.R0 + n] : p.res1[m * R1 + (n - p.R0)];
+                if (p.out_nchw) {  // boundary tensor (the head's eps): (b, n, oy, ox)
+                    const int64_t bb = m / HWo;
+                    p.out[(bb * p.Cout + n) * HWo + (m - bb * HWo)] = v;
+                } else {
+                    p.out[m * p.Cout + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 / stride 1 convolution with a HALO tile: the (th+2) x (W+2) x 32-channel input patch of a
+// 128-pixel tile (th full image rows) is staged into LDS ONCE per channel chunk -- GroupNorm
+// affine + SiLU applied once per element instead of once per tap -- and the 9 taps read it at
+// shifted LDS addresses; only the 16-KB weight tile streams per tap (double-buffered).  Compared
+// with the shifted-GEMM kernel above this removes 8/9 of the global loads, address arithmetic and
+// activation math from the MFMA loop.
+// ---------------------------------------------------------------------------------------------
+constexpr int HALO_NIT = 9;  // float4 items per thread per chunk, upper bound ((th+2)(W+2) <= 288)
+
+template <int BN, int WAVES_M, int WAVES_N, int RM, int RN>
+__global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th) {
+    static_assert(WAVES_M * WAVES_N == 4 && WAVES_M * RM * 32 == BM && WAVES_N * RN * 32 == BN, "tile shape");
+    constexpr int NBF = BN / 8, NBV = NBF / 4, TPR = KC / NBF;
+    extern __shared__ __attribute__((aligned(16))) float hsm[];
+    const int W = p.Wout, H = p.Hout, Wp = W + 2;
+    const int hp = (th + 2) * Wp;                 // halo pixels
+    float *Ah = hsm;
+    float *Bsb = hsm + ((hp + 3) & ~3) * LDS_LD;   // two weight buffers of BN x LDS_LD
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int Cin = p.C0 + p.C1;
+    const int HWo = H * W;
+    const int ntile_n = (p.Cout + BN - 1) / BN;
+    const int64_t m0 = (int64_t)(blockIdx.x / ntile_n) * BM;
+    const int n0 = (blockIdx.x % ntile_n) * BN;
+    const int pb = (int)(m0 / HWo);
+    const int y0 = (int)((m0 - (int64_t)pb * HWo) / W);
+
+    // ---- halo staging: this thread owns channels c4..c4+3 of halo pixels it*32 + (tid >> 3)
+    const int c4 = (tid & 7) * 4;
+    const int nit = (hp * 8 + 255) / 256;
+    int off[HALO_NIT];  // source pixel index, -1: zero padding, -2: beyond the halo
+#pragma unroll
+    for (int it = 0; it < HALO_NIT; it++) {
+        const int hpix = it * 32 + (tid >> 3);
+        const int hy = hpix / Wp, hx = hpix - hy * Wp;
+        const int iy = y0 + hy - 1, ix = hx - 1;
+        off[it] = (it >= nit || hpix >= hp) ? -2 : ((iy < 0 || iy >= H || ix < 0 || ix >= W) ? -1 : ((pb * H + iy) * W + ix));
+    }
+    float4 xh[HALO_NIT], ca, cb;
+    const bool has_coef = p.coefA != nullptr;
+
+    auto load_halo = [&](int chunk) {
+        const int c = chunk * KC + c4;
+        const bool first = c < p.C0;
+        const float *sb = first ? p.src0 + c : p.src1 + (c - p.C0);
+        const int ld = first ? p.C0 : p.C1;
+#pragma unroll
+        for (int it = 0; it < HALO_NIT; it++)
+            if (off[it] >= 0) xh[it] = *reinterpret_cast<const float4 *>(sb + (int64_t)off[it] * ld);
+        if (has_coef) {
+            ca = *reinterpret_cast<const float4 *>(p.coefA + (int64_t)pb * Cin + c);
+            cb = *reinterpret_cast<const float4 *>(p.coefB + (int64_t)pb * Cin + c);
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int it = 0; it < HALO_NIT; it++) {
+            if (off[it] == -2) continue;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (off[it] >= 0) {
+                x = xh[it];
+                if (has_coef) {
+                    x.x = fmaf(x.x, ca.x, cb.x);
+                    x.y = fmaf(x.y, ca.y, cb.y);
+                    x.z = fmaf(x.z, ca.z, cb.z);
+                    x.w = fmaf(x.w, ca.w, cb.w);
+                }
+                if (p.act_silu) {
+                    x.x = silu_f(x.x);
+                    x.y = silu_f(x.y);
+                    x.z = silu_f(x.z);
+                    x.w = silu_f(x.w);
+                }
+            }
+            *reinterpret_cast<float4 *>(Ah + (it * 32 + (tid >> 3)) * LDS_LD + c4) = x;
+        }
+    };
+
+    // ---- weight tile staging (per tap, double-buffered)
+    const int rb = tid / TPR, segb = (tid % TPR) * NBF;
+    const bool wrow_ok = (n0 + rb) < p.Cout;
+    float4 wb[NBV];
+    auto load_w = [&](int chunk, int tap) {
+        if (wrow_ok) {
+            const float *wp = p.w + ((int64_t)tap * p.Cout + (n0 + rb)) * Cin + chunk * KC + segb;
+#pragma unroll
+            for (int v = 0; v < NBV; v++) wb[v] = reinterpret_cast<const float4 *>(wp)[v];
+        }
+    };
+    auto store_w = [&](int buf) {
+        float4 *db = reinterpret_cast<float4 *>(Bsb + buf * BN * LDS_LD + rb * LDS_LD + segb);
+#pragma unroll
+        for (int v = 0; v < NBV; v++) db[v] = wrow_ok ? wb[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+
+    // ---- A fragment base addresses: output pixel -> halo coordinates of tap (0, 0)
+    int abase[RM];
+#pragma unroll
+    for (int i = 0; i < RM; i++) {
+        const int mloc = (wm * RM + i) * 32 + l31;
+        const int yy = mloc / W, xx = mloc - yy * W;
+        abase[i] = (yy * Wp + xx) * LDS_LD + kh * 4;
+    }
+    const float *bpw = Bsb + (wn * RN * 32 + l31) * LDS_LD + kh * 4;
+
+    floatx16 acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; i++)
+#pragma unroll
+        for (int j = 0; j < RN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int nch = Cin / KC;
+    load_halo(0);
+    load_w(0, 0);
+    store_halo();
+    store_w(0);
+    __syncthreads();
+
+    int s = 0;
+    for (int chunk = 0; chunk < nch; chunk++) {
+#pragma unroll 1
+        for (int tap = 0; tap < 9; tap++, s++) {
+            const int buf = s & 1;
+            const bool last_tap = tap == 8, more = (chunk + 1 < nch);
+            if (!last_tap) load_w(chunk, tap + 1);
+            else if (more) { load_w(chunk + 1, 0); load_halo(chunk + 1); }
+
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int toff = (ky * Wp + kx) * LDS_LD;
+            const float *bp = bpw + buf * BN * LDS_LD;
+#pragma unroll
+            for (int kk = 0; kk < KC / 8; kk++) {
+                float4 af[RM], bf[RN];
+#pragma unroll
+                for (int i = 0; i < RM; i++) af[i] = *reinterpret_cast<const float4 *>(Ah + abase[i] + toff + kk * 8);
+#pragma unroll
+                for (int j = 0; j < RN; j++) bf[j] = *reinterpret_cast<const float4 *>(bp + j * 32 * LDS_LD + kk * 8);
+#pragma unroll
+                for (int i = 0; i < RM; i++)
+#pragma unroll
+                    for (int j = 0; j < RN; j++) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+            if (!last_tap || more) store_w(buf ^ 1);
+            if (last_tap && more) {
+                __syncthreads();  // every wave has finished reading this chunk's halo
+                store_halo();
+            }
+            __syncthreads();
+        }
+    }
+
+    const int R1 = p.Cout - p.R0;
+#pragma unroll
+    for (int j = 0; j < RN; j++) {
+        const int n = n0 + (wn * RN + j) * 32 + l31;
+        if (n >= p.Cout) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < RM; i++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (wm * RM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int64_t m = m0 + row;
+                float v = acc[i][j][r] + bias;
+                if (p.res0) v += (n < p.R0) ? p.res0[m * p.R0 + n] : p.res1[m * R1 + (n - p.R0)];
                 p.out[m * p.Cout + n] = v;
             }
         }
     }
+}
+
+// stem: Cin = image channels read from the caller's NCHW state, 3x3 stride 1, writes NHWC.
+// One thread = one pixel x 4 output channels; the 9*Cin taps are broadcast across the 32 threads
+// of a pixel, weight rows are coalesced float4 loads.
+__global__ void __launch_bounds__(256) k_conv_stem(ConvLaunch p) {
+    const int Cin = p.C0, Cq = p.Cout / 4;
+    const int HWo = p.Hout * p.Wout;
+    const int64_t total = (int64_t)p.B * HWo * Cq;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int nq = (int)(i % Cq);
+    const int64_t m = i / Cq;
+    const int b = (int)(m / HWo);
+    const int rem = (int)(m - (int64_t)b * HWo);
+    const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+    float4 acc = reinterpret_cast<const float4 *>(p.bias)[nq];
+    for (int ky = 0; ky < 3; ky++) {
+        const int iy = oy + ky - 1;
+        if (iy < 0 || iy >= p.Hin) continue;
+        for (int kx = 0; kx < 3; kx++) {
+            const int ix = ox + kx - 1;
+            if (ix < 0 || ix >= p.Win) continue;
+            for (int c = 0; c < Cin; c++) {
+                const float v = p.src0[(((int64_t)b * Cin + c) * p.Hin + iy) * p.Win + ix];
+                const float4 w = reinterpret_cast<const float4 *>(p.w + ((int64_t)(ky * 3 + kx) * Cin + c) * p.Cout)[nq];
+                acc.x = fmaf(v, w.x, acc.x);
+                acc.y = fmaf(v, w.y, acc.y);
+                acc.z = fmaf(v, w.z, acc.z);
+                acc.w = fmaf(v, w.w, acc.w);
+            }
+        }
+    }
+    reinterpret_cast<float4 *>(p.out + m * p.Cout)[nq] = acc;
 }
 
 __global__ void k_relayout_weight(const float *oihw, float *dst, int Cout, int Cin, int ks, int for_igemm) {
@@ -204,12 +427,43 @@ __global__ void k_relayout_weight(const float *oihw, float *dst, int Cout, int C
 
 bool igemm_supported(const ConvLaunch &c) {
     const int Cin = c.C0 + c.C1;
-    if (c.in_nchw || c.out_nchw) return false;
+    if (c.in_nchw) return false;
     if (Cin % KC != 0 || c.C0 % KC != 0) return false;
-    if (c.Cout < 16) return false;
+    if (c.Cout < 16 && !c.out_nchw) return false;
     if (c.ks != 1 && c.ks != 3) return false;
-    if (c.Cout % 4 != 0) return false;
     return true;
+}
+
+static bool halo_ok(const ConvLaunch &c, int *th) {
+    static int disabled = -1;
+    if (disabled < 0) { const char *e = getenv("DLPM_NO_HALO"); disabled = (e && e[0] == '1') ? 1 : 0; }
+    if (disabled || c.ks != 3 || c.stride != 1 || c.ups || c.out_nchw) return false;
+    const int W = c.Wout, HW = c.Hout * c.Wout;
+    if (W < 8 || W > 64 || BM % W != 0 || HW % BM != 0) return false;
+    *th = BM / W;
+    return (*th + 2) * (W + 2) * 8 <= HALO_NIT * 256;
+}
+
+template <int BN, int WAVES_M, int WAVES_N, int RM, int RN>
+static int launch_halo(const ConvLaunch &c, int th, int64_t grid, hipStream_t st) {
+    const int hp = (th + 2) * (c.Wout + 2);
+    const size_t shmem = (size_t)(((hp + 3) & ~3) + 2 * BN) * LDS_LD * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo<BN, WAVES_M, WAVES_N, RM, RN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr = true;
+    }
+    k_conv3x3_halo<BN, WAVES_M, WAVES_N, RM, RN><<<(unsigned)grid, 256, shmem, st>>>(c, th);
+    return DLPM_OK;
+}
+
+int launch_conv_stem(const ConvLaunch &c, hipStream_t st) {
+    const int64_t total = (int64_t)c.B * c.Hout * c.Wout * (c.Cout / 4);
+    ProfScope ps("conv_stem", 2.0 * total * 4 * c.C0 * 9, 4.0 * ((double)c.B * c.Hin * c.Win * c.C0 + total * 4.0), st);
+    k_conv_stem<<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(c);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
 }
 
 int launch_conv_igemm(const ConvLaunch &c, hipStream_t st) {
@@ -218,7 +472,23 @@ int launch_conv_igemm(const ConvLaunch &c, hipStream_t st) {
     const double K = (double)(c.C0 + c.C1) * c.ks * c.ks;
     // algorithmic bytes: input once + weights once + output once (+ residual)
     const double bytes = 4.0 * ((double)c.B * c.Hin * c.Win * (c.C0 + c.C1) + K * c.Cout + (double)M * c.Cout * (c.res0 ? 2 : 1));
-    ProfScope ps(c.ks == 3 ? "conv3x3_igemm" : "conv1x1_igemm", 2.0 * M * c.Cout * K, bytes, st);
+    char pname[96];
+    if (prof_enabled() && prof_detail())
+        snprintf(pname, sizeof(pname), "conv%dx%d_igemm:H%d:Cin%d+%d:Cout%d:s%d:u%d:coef%d", c.ks, c.ks, c.Hout, c.C0, c.C1, c.Cout,
+                 c.stride, c.ups, c.coefA ? 1 : 0);
+    else
+        snprintf(pname, sizeof(pname), "%s", c.ks == 3 ? "conv3x3_igemm" : "conv1x1_igemm");
+    ProfScope ps(pname, 2.0 * M * c.Cout * K, bytes, st);
+    int th = 0;
+    if (halo_ok(c, &th)) {
+        int r;
+        if (c.Cout > 64) r = launch_halo<128, 2, 2, 2, 2>(c, th, mt * ceil_div(c.Cout, 128), st);
+        else if (c.Cout > 32) r = launch_halo<64, 2, 2, 2, 1>(c, th, mt * ceil_div(c.Cout, 64), st);
+        else r = launch_halo<32, 4, 1, 1, 1>(c, th, mt * ceil_div(c.Cout, 32), st);
+        if (r != DLPM_OK) return r;
+        DLPM_LAUNCH_CHECK();
+        return DLPM_OK;
+    }
     if (c.Cout > 64) {
         const int64_t grid = mt * ceil_div(c.Cout, 128);
         k_conv_igemm<128, 2, 2, 2, 2><<<(unsigned)grid, 256, 0, st>>>(c);

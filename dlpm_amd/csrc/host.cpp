@@ -1,6 +1,7 @@
 // host.cpp -- host-side pieces of the sampling path: error channel, noise schedule and the
 // reference-compatible MT19937 streams used for "identical seeds" parity with the CPU reference.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -21,7 +22,7 @@ void set_error(const char *fmt, ...) {
 namespace dlpm {
 namespace {
 struct ProfRec {
-    const char *name;
+    std::string name;
     double flops, bytes;
     hipEvent_t e0, e1;
 };
@@ -29,6 +30,11 @@ bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 }  // namespace
 bool prof_enabled() { return g_prof_on; }
+bool prof_detail() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DLPM_PROF_DETAIL"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
 ProfScope::ProfScope(const char *n, double fl, double by, hipStream_t s) : name(n), flops(fl), bytes(by), st(s) {
     if (!g_prof_on) return;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }

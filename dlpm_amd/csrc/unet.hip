@@ -205,10 +205,10 @@ void build_arch(dlpm_unet *u) {
     u->head = u->conv("out.2.", c.out_channels, mc, 3);
 }
 
-int prep_conv(dlpm_unet *u, ConvW &c, int C0, bool boundary) {
+int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 none, 1 NCHW input (stem), 2 NCHW output (head)
     ConvLaunch probe;
     probe.C0 = C0; probe.C1 = c.cin - C0; probe.Cout = c.cout; probe.ks = c.ks;
-    probe.in_nchw = probe.out_nchw = boundary;
+    probe.in_nchw = boundary == 1; probe.out_nchw = boundary == 2;
     c.use_igemm = igemm_supported(probe);
     const float *src = u->params[c.p_w].dev;
     if (c.use_igemm && c.ks == 1) {  // [O][I] row-major is already the igemm layout
@@ -224,7 +224,7 @@ int run_conv(const ConvW &c, ConvLaunch L, hipStream_t st) {
     L.w = c.w_dev;
     L.ks = c.ks;
     L.Cout = c.cout;
-    return c.use_igemm ? launch_conv_igemm(L, st) : launch_conv_direct(L, st);
+    return c.use_igemm ? launch_conv_igemm(L, st) : launch_conv_fallback(L, st);
 }
 
 #define TRY(expr)                  \
@@ -507,9 +507,9 @@ extern "C" int dlpm_unet_finalize(dlpm_unet *u) {
             Layer &L = s[i];
             const bool cat = (i == 0 && L.kind == L_RES && C0_first > 0);
             const int C0 = cat ? C0_first : L.c1.cin;
-            TRY(prep_conv(u, L.c1, L.kind == L_STEM ? L.c1.cin : C0, L.kind == L_STEM));
-            if (L.kind == L_RES || L.kind == L_ATTN) TRY(prep_conv(u, L.c2, L.c2.cin, false));
-            if (L.kind == L_RES && L.has_skip) TRY(prep_conv(u, L.skip, cat ? C0_first : L.skip.cin, false));
+            TRY(prep_conv(u, L.c1, L.kind == L_STEM ? L.c1.cin : C0, L.kind == L_STEM ? 1 : 0));
+            if (L.kind == L_RES || L.kind == L_ATTN) TRY(prep_conv(u, L.c2, L.c2.cin, 0));
+            if (L.kind == L_RES && L.has_skip) TRY(prep_conv(u, L.skip, cat ? C0_first : L.skip.cin, 0));
         }
         return DLPM_OK;
     };
@@ -523,9 +523,9 @@ extern "C" int dlpm_unet_finalize(dlpm_unet *u) {
             ch = s[0].cout;
         }
     }
-    TRY(prep_conv(u, u->te0, u->te0.cin, false));
-    TRY(prep_conv(u, u->te2, u->te2.cin, false));
-    TRY(prep_conv(u, u->head, u->head.cin, true));
+    TRY(prep_conv(u, u->te0, u->te0.cin, 0));
+    TRY(prep_conv(u, u->te2, u->te2.cin, 0));
+    TRY(prep_conv(u, u->head, u->head.cin, 2));
     // fused emb GEMM: rows of every emb_layers.1.weight stacked in ResBlock order
     if (u->embcat_w) (void)hipFree(u->embcat_w);
     if (u->embcat_b) (void)hipFree(u->embcat_b);
@@ -654,7 +654,8 @@ extern "C" int dlpm_conv2d_f32(const dlpm_conv_args *a, float *scratch_dev, dlpm
     hipStream_t st = as_stream(stream);
     TRY(relayout_weight(a->weight, scratch_dev, a->Cout, a->C0 + a->C1, a->ksize, ig, st));
     L.w = scratch_dev;
-    return ig ? launch_conv_igemm(L, st) : launch_conv_direct(L, st);
+    if (ig) return launch_conv_igemm(L, st);
+    return a->force_direct ? launch_conv_direct(L, st) : launch_conv_fallback(L, st);
 }
 
 extern "C" int dlpm_groupnorm_coeffs_f32(const float *src0, const float *src1, int32_t C0, int32_t C1, int32_t B, int32_t HW,

@@ -102,6 +102,10 @@ CONV_CASES = [
     ('igemm_cout_96', 2, 32, 0, 8, 96, 1, 1, 0, True, False, False),
     ('igemm_ragged_m', 3, 32, 0, 4, 32, 3, 1, 0, False, True, False),     # M = 48 < one 128-pixel tile
     ('igemm_32x32_rows', 1, 32, 0, 32, 64, 3, 1, 0, True, True, True),
+    ('igemm_halo_32x32_concat_res', 2, 64, 32, 32, 128, 3, 1, 0, True, True, True),
+    ('igemm_halo_16x16', 3, 64, 0, 16, 64, 3, 1, 0, True, True, False),
+    ('igemm_halo_16x16_noact_cout32', 2, 32, 0, 16, 32, 3, 1, 0, False, False, True),
+    ('igemm_halo_64x64', 1, 32, 0, 64, 32, 3, 1, 0, True, True, False),
     ('direct_odd_channels', 2, 24, 0, 8, 40, 3, 1, 0, True, True, True),
     ('direct_concat_1x1', 2, 8, 16, 4, 8, 1, 1, 0, False, False, False),
     ('direct_stride2', 2, 8, 0, 8, 8, 3, 2, 0, False, False, False),
@@ -141,8 +145,12 @@ def test_conv_boundary_layouts():
     w2 = torch.randn(3, 32, 3, 3, generator=g) / 17
     b2 = torch.randn(3, generator=g)
     coef = (1 + 0.3 * torch.randn(2, 32, generator=g), 0.3 * torch.randn(2, 32, generator=g))
-    got = run_conv(h, w2, b2, coef=coef, silu=True, out_nchw=True)   # head: writes NCHW eps
+    got = run_conv(h, w2, b2, coef=coef, silu=True, out_nchw=True)   # head: writes NCHW eps (MFMA kernel, 32-wide N tile)
     assert (got - ref_conv(h, w2, b2, coef=coef, silu=True)).abs().max().item() < 2e-5
+    got = run_conv(h, w2, b2, coef=coef, silu=True, out_nchw=True, force_direct=True)
+    assert (got - ref_conv(h, w2, b2, coef=coef, silu=True)).abs().max().item() < 2e-5
+    got = run_conv(x, w, b, in_nchw=True, force_direct=True)
+    assert (got - ref_conv(x, w, b)).abs().max().item() < 1e-5
 
 
 def test_linear_as_conv():
@@ -180,6 +188,20 @@ def test_groupnorm_coeffs_against_reference_fixture(C, hw):
                                             bet.data_ptr(), ssd.data_ptr(), 2 * C + 7, 5, cA.data_ptr(), cB.data_ptr(), st()))
     y = nets.silu(x * cA.cpu()[:, :, None, None] + cB.cpu()[:, :, None, None])
     np.testing.assert_allclose(y.numpy(), f[tag + '_y_ss_silu'], atol=4e-6)
+
+
+def test_groupnorm_scalar_kernel_odd_channels():
+    """C = 30 (not a multiple of 4) takes the scalar kernel; checked against the oracle."""
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(3, 30, 5, 5, generator=g) * 1.5 + 0.3
+    gam, bet = 1 + 0.2 * torch.randn(30, generator=g), 0.2 * torch.randn(30, generator=g)
+    want = nets.group_norm(x, gam, bet)
+    xd, gd, bd = nhwc(x).to(DEV), gam.to(DEV), bet.to(DEV)
+    cA, cB = torch.empty(3, 30, device=DEV), torch.empty(3, 30, device=DEV)
+    _lib.check(L().dlpm_groupnorm_coeffs_f32(xd.data_ptr(), None, 30, 0, 3, 25, 30, gd.data_ptr(), bd.data_ptr(),
+                                            None, 0, 0, cA.data_ptr(), cB.data_ptr(), st()))
+    y = x * cA.cpu()[:, :, None, None] + cB.cpu()[:, :, None, None]
+    np.testing.assert_allclose(y.numpy(), want.numpy(), atol=3e-6)
 
 
 @pytest.mark.parametrize('ch,T', [(16, 64), (64, 16), (16, 256), (64, 64)])
