@@ -205,14 +205,16 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvLaunch p) {
 constexpr int HALO_NIT = 9;  // float4 items per thread per chunk, upper bound ((th+2)(W+2) <= 288)
 
 template <int BN, int WAVES_M, int WAVES_N, int RM, int RN>
-__global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th) {
+__global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th, int nimg) {
     static_assert(WAVES_M * WAVES_N == 4 && WAVES_M * RM * 32 == BM && WAVES_N * RN * 32 == BN, "tile shape");
     constexpr int NBF = BN / 8, NBV = NBF / 4, TPR = KC / NBF;
     extern __shared__ __attribute__((aligned(16))) float hsm[];
     const int W = p.Wout, H = p.Hout, Wp = W + 2;
-    const int hp = (th + 2) * Wp;                 // halo pixels
+    const int hpi = (th + 2) * Wp;                // halo pixels per image
+    const int hp = nimg * hpi;                    // halo pixels of the tile (nimg > 1: whole small images)
     float *Ah = hsm;
     float *Bsb = hsm + ((hp + 3) & ~3) * LDS_LD;   // two weight buffers of BN x LDS_LD
+    float *Cf = Bsb + 2 * BN * LDS_LD;             // fused-norm coefficients of this chunk: [nimg][A(32) | B(32)]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -220,10 +222,11 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th) {
     const int Cin = p.C0 + p.C1;
     const int HWo = H * W;
     const int ntile_n = (p.Cout + BN - 1) / BN;
+    const int64_t M = (int64_t)p.B * HWo;
     const int64_t m0 = (int64_t)(blockIdx.x / ntile_n) * BM;
     const int n0 = (blockIdx.x % ntile_n) * BN;
-    const int pb = (int)(m0 / HWo);
-    const int y0 = (int)((m0 - (int64_t)pb * HWo) / W);
+    const int pb = (int)(m0 / HWo);               // first image of the tile
+    const int y0 = (nimg > 1) ? 0 : (int)((m0 - (int64_t)pb * HWo) / W);
 
     // ---- halo staging: this thread owns channels c4..c4+3 of halo pixels it*32 + (tid >> 3)
     const int c4 = (tid & 7) * 4;
@@ -232,12 +235,17 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th) {
 #pragma unroll
     for (int it = 0; it < HALO_NIT; it++) {
         const int hpix = it * 32 + (tid >> 3);
-        const int hy = hpix / Wp, hx = hpix - hy * Wp;
+        const int img = hpix / hpi, hr = hpix - img * hpi;
+        const int hy = hr / Wp, hx = hr - hy * Wp;
         const int iy = y0 + hy - 1, ix = hx - 1;
-        off[it] = (it >= nit || hpix >= hp) ? -2 : ((iy < 0 || iy >= H || ix < 0 || ix >= W) ? -1 : ((pb * H + iy) * W + ix));
+        const bool pad = iy < 0 || iy >= H || ix < 0 || ix >= W || (pb + img) >= p.B;
+        off[it] = (it >= nit || hpix >= hp) ? -2 : (pad ? -1 : (((pb + img) * H + iy) * W + ix));
     }
-    float4 xh[HALO_NIT], ca, cb;
+    float4 xh[HALO_NIT], cfr;
     const bool has_coef = p.coefA != nullptr;
+    // coefficient staging: thread t < nimg*16 carries one float4 of A (t & 8 == 0) or B of image t >> 4
+    const int cf_img = tid >> 4, cf_isb = (tid >> 3) & 1;
+    const bool cf_mine = has_coef && tid < nimg * 16 && (pb + cf_img) < p.B;
 
     auto load_halo = [&](int chunk) {
         const int c = chunk * KC + c4;
@@ -247,10 +255,11 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th) {
 #pragma unroll
         for (int it = 0; it < HALO_NIT; it++)
             if (off[it] >= 0) xh[it] = *reinterpret_cast<const float4 *>(sb + (int64_t)off[it] * ld);
-        if (has_coef) {
-            ca = *reinterpret_cast<const float4 *>(p.coefA + (int64_t)pb * Cin + c);
-            cb = *reinterpret_cast<const float4 *>(p.coefB + (int64_t)pb * Cin + c);
-        }
+        if (cf_mine)
+            cfr = *reinterpret_cast<const float4 *>((cf_isb ? p.coefB : p.coefA) + (int64_t)(pb + cf_img) * Cin + c);
+    };
+    auto store_coef = [&]() {
+        if (cf_mine) *reinterpret_cast<float4 *>(Cf + cf_img * 64 + cf_isb * 32 + c4) = cfr;
     };
     auto store_halo = [&]() {
 #pragma unroll
@@ -260,6 +269,9 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th) {
             if (off[it] >= 0) {
                 x = xh[it];
                 if (has_coef) {
+                    const int img = (it * 32 + (tid >> 3)) / hpi;
+                    const float4 ca = *reinterpret_cast<const float4 *>(Cf + img * 64 + c4);
+                    const float4 cb = *reinterpret_cast<const float4 *>(Cf + img * 64 + 32 + c4);
                     x.x = fmaf(x.x, ca.x, cb.x);
                     x.y = fmaf(x.y, ca.y, cb.y);
                     x.z = fmaf(x.z, ca.z, cb.z);
@@ -295,11 +307,13 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th) {
 
     // ---- A fragment base addresses: output pixel -> halo coordinates of tap (0, 0)
     int abase[RM];
+    const int hwt = th * W;  // output pixels per image inside the tile
 #pragma unroll
     for (int i = 0; i < RM; i++) {
         const int mloc = (wm * RM + i) * 32 + l31;
-        const int yy = mloc / W, xx = mloc - yy * W;
-        abase[i] = (yy * Wp + xx) * LDS_LD + kh * 4;
+        const int img = mloc / hwt, ml = mloc - img * hwt;
+        const int yy = ml / W, xx = ml - yy * W;
+        abase[i] = (img * hpi + yy * Wp + xx) * LDS_LD + kh * 4;
     }
     const float *bpw = Bsb + (wn * RN * 32 + l31) * LDS_LD + kh * 4;
 
@@ -314,8 +328,10 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th) {
     const int nch = Cin / KC;
     load_halo(0);
     load_w(0, 0);
-    store_halo();
+    store_coef();
     store_w(0);
+    __syncthreads();
+    store_halo();
     __syncthreads();
 
     int s = 0;
@@ -349,7 +365,8 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th) {
             }
             if (!last_tap || more) store_w(buf ^ 1);
             if (last_tap && more) {
-                __syncthreads();  // every wave has finished reading this chunk's halo
+                store_coef();     // (the previous chunk's coefficients were consumed before its first tap)
+                __syncthreads();  // every wave has finished reading this chunk's halo; coefficients visible
                 store_halo();
             }
             __syncthreads();
@@ -368,6 +385,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th) {
             for (int r = 0; r < 16; r++) {
                 const int row = (wm * RM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 const int64_t m = m0 + row;
+                if (m >= M) continue;
                 float v = acc[i][j][r] + bias;
                 if (p.res0) v += (n < p.R0) ? p.res0[m * p.R0 + n] : p.res1[m * R1 + (n - p.R0)];
                 p.out[m * p.Cout + n] = v;
@@ -434,27 +452,35 @@ bool igemm_supported(const ConvLaunch &c) {
     return true;
 }
 
-static bool halo_ok(const ConvLaunch &c, int *th) {
+static bool halo_ok(const ConvLaunch &c, int *th, int *nimg) {
     static int disabled = -1;
     if (disabled < 0) { const char *e = getenv("DLPM_NO_HALO"); disabled = (e && e[0] == '1') ? 1 : 0; }
     if (disabled || c.ks != 3 || c.stride != 1 || c.ups || c.out_nchw) return false;
     const int W = c.Wout, HW = c.Hout * c.Wout;
-    if (W < 8 || W > 64 || BM % W != 0 || HW % BM != 0) return false;
-    *th = BM / W;
-    return (*th + 2) * (W + 2) * 8 <= HALO_NIT * 256;
+    if (W < 4 || W > 64 || BM % W != 0) return false;
+    if (HW >= BM) {            // th full rows of one image
+        if (HW % BM != 0) return false;
+        *th = BM / W;
+        *nimg = 1;
+    } else {                   // several whole (small) images per tile
+        if (BM % HW != 0) return false;
+        *th = c.Hout;
+        *nimg = BM / HW;
+    }
+    return *nimg * (*th + 2) * (W + 2) * 8 <= HALO_NIT * 256;
 }
 
 template <int BN, int WAVES_M, int WAVES_N, int RM, int RN>
-static int launch_halo(const ConvLaunch &c, int th, int64_t grid, hipStream_t st) {
-    const int hp = (th + 2) * (c.Wout + 2);
-    const size_t shmem = (size_t)(((hp + 3) & ~3) + 2 * BN) * LDS_LD * sizeof(float);
+static int launch_halo(const ConvLaunch &c, int th, int nimg, int64_t grid, hipStream_t st) {
+    const int hp = nimg * (th + 2) * (c.Wout + 2);
+    const size_t shmem = (size_t)(((hp + 3) & ~3) + 2 * BN) * LDS_LD * sizeof(float) + (size_t)nimg * 64 * sizeof(float);
     static bool attr = false;
     if (!attr) {
         DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo<BN, WAVES_M, WAVES_N, RM, RN>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
         attr = true;
     }
-    k_conv3x3_halo<BN, WAVES_M, WAVES_N, RM, RN><<<(unsigned)grid, 256, shmem, st>>>(c, th);
+    k_conv3x3_halo<BN, WAVES_M, WAVES_N, RM, RN><<<(unsigned)grid, 256, shmem, st>>>(c, th, nimg);
     return DLPM_OK;
 }
 
@@ -479,12 +505,12 @@ int launch_conv_igemm(const ConvLaunch &c, hipStream_t st) {
     else
         snprintf(pname, sizeof(pname), "%s", c.ks == 3 ? "conv3x3_igemm" : "conv1x1_igemm");
     ProfScope ps(pname, 2.0 * M * c.Cout * K, bytes, st);
-    int th = 0;
-    if (halo_ok(c, &th)) {
+    int th = 0, nimg = 1;
+    if (halo_ok(c, &th, &nimg)) {
         int r;
-        if (c.Cout > 64) r = launch_halo<128, 2, 2, 2, 2>(c, th, mt * ceil_div(c.Cout, 128), st);
-        else if (c.Cout > 32) r = launch_halo<64, 2, 2, 2, 1>(c, th, mt * ceil_div(c.Cout, 64), st);
-        else r = launch_halo<32, 4, 1, 1, 1>(c, th, mt * ceil_div(c.Cout, 32), st);
+        if (c.Cout > 64) r = launch_halo<128, 2, 2, 2, 2>(c, th, nimg, mt * ceil_div(c.Cout, 128), st);
+        else if (c.Cout > 32) r = launch_halo<64, 2, 2, 2, 1>(c, th, nimg, mt * ceil_div(c.Cout, 64), st);
+        else r = launch_halo<32, 4, 1, 1, 1>(c, th, nimg, mt * ceil_div(c.Cout, 32), st);
         if (r != DLPM_OK) return r;
         DLPM_LAUNCH_CHECK();
         return DLPM_OK;

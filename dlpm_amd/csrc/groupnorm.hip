@@ -7,8 +7,9 @@
 // normalised activation is never written to HBM: this kernel only READS x (4 B/element, HBM/L2
 // bound) and writes 2*B*C floats.  x is NHWC and may be a virtual concat of two tensors (the
 // UNet skip connection, unet.py:489), whose groups can straddle the two sources.
-// Statistics are two-pass (mean, then centred sum of squares) in fp32, one workgroup per sample;
-// wavefront-level parallelism is over channels (coalesced rows) x pixel slices.
+// Statistics in fp32, one workgroup per sample, parallel over channels (coalesced rows) x pixel
+// slices: a one-pass shifted-data kernel for channel counts divisible by 4 (every shipped config),
+// a two-pass scalar kernel otherwise.
 #include "conv.h"
 
 namespace dlpm {
@@ -83,8 +84,12 @@ __global__ void __launch_bounds__(512) k_gn_coeffs(const float *__restrict__ src
     }
 }
 
-// Vectorised variant (C0 % 4 == 0 and C1 % 4 == 0): one thread owns 4 consecutive channels and a
-// pixel slice, 16-byte coalesced loads with 4 independent loads in flight per iteration.
+// Vectorised ONE-pass variant (C0 % 4 == 0 and C1 % 4 == 0): the activation is read exactly once
+// (4 B/element, the algorithmic minimum).  One thread owns 4 consecutive channels and a pixel slice
+// and accumulates sum and sum of squares of (x - K_c), K_c = the channel's first pixel -- the
+// shifted-data formulation, whose cancellation is governed by |K_c - mean_c| / std_c (O(1) when the
+// pivot is a sample of the data) instead of |mean| / std.  Per-channel (mean, M2) are then merged
+// into groups with Chan's parallel update, which is exact for unequal channel means.
 __global__ void __launch_bounds__(512) k_gn_coeffs_v4(const float *__restrict__ src0, const float *__restrict__ src1,
                                                       int C0, int C1, int HW, int G, const float *__restrict__ gamma,
                                                       const float *__restrict__ beta, const float *__restrict__ ss,
@@ -95,64 +100,64 @@ __global__ void __launch_bounds__(512) k_gn_coeffs_v4(const float *__restrict__ 
     const int nt = blockDim.x, tid = threadIdx.x;
     const int nsl = (Cq <= nt) ? nt / Cq : 1;
     const int nwork = nsl * Cq;
-    float *partial = sh;                 // [nsl * C]
-    float *chan = sh + (size_t)nsl * C;  // [C]
-    float *mean = chan + C, *rstd = mean + G;
+    float *p1 = sh;                          // [nsl * C] partial sums of (x - K)
+    float *p2 = p1 + (size_t)nsl * C;        // [nsl * C] partial sums of (x - K)^2
+    float *cmean = p2 + (size_t)nsl * C;     // [C] channel means
+    float *cm2 = cmean + C;                  // [C] channel centred sums of squares
+    float *mean = cm2 + C, *rstd = mean + G; // [G]
     const int b = blockIdx.x;
     const float *x0 = src0 + (int64_t)b * HW * C0;
     const float *x1 = src1 ? src1 + (int64_t)b * HW * C1 : nullptr;
-    const float inv_n = 1.0f / (float)((int64_t)cg * HW);
 
-    for (int pass = 0; pass < 2; pass++) {
-        for (int idx = tid; idx < nwork; idx += nt) {
-            const int c = (idx % Cq) * 4, sl = idx / Cq;
-            const float *xp = (c < C0) ? x0 + c : x1 + (c - C0);
-            const int ld = (c < C0) ? C0 : C1;
-            float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pass) mu = make_float4(mean[c / cg], mean[(c + 1) / cg], mean[(c + 2) / cg], mean[(c + 3) / cg]);
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a;
-            int p = sl;
-            for (; p + nsl < HW; p += 2 * nsl) {
-                const float4 v = *reinterpret_cast<const float4 *>(xp + (int64_t)p * ld);
-                const float4 w = *reinterpret_cast<const float4 *>(xp + (int64_t)(p + nsl) * ld);
-                if (pass) {
-                    float d;
-                    d = v.x - mu.x; a.x = fmaf(d, d, a.x); d = v.y - mu.y; a.y = fmaf(d, d, a.y);
-                    d = v.z - mu.z; a.z = fmaf(d, d, a.z); d = v.w - mu.w; a.w = fmaf(d, d, a.w);
-                    d = w.x - mu.x; a2.x = fmaf(d, d, a2.x); d = w.y - mu.y; a2.y = fmaf(d, d, a2.y);
-                    d = w.z - mu.z; a2.z = fmaf(d, d, a2.z); d = w.w - mu.w; a2.w = fmaf(d, d, a2.w);
-                } else {
-                    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-                    a2.x += w.x; a2.y += w.y; a2.z += w.z; a2.w += w.w;
-                }
-            }
-            for (; p < HW; p += nsl) {
-                const float4 v = *reinterpret_cast<const float4 *>(xp + (int64_t)p * ld);
-                if (pass) {
-                    float d;
-                    d = v.x - mu.x; a.x = fmaf(d, d, a.x); d = v.y - mu.y; a.y = fmaf(d, d, a.y);
-                    d = v.z - mu.z; a.z = fmaf(d, d, a.z); d = v.w - mu.w; a.w = fmaf(d, d, a.w);
-                } else {
-                    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-                }
-            }
-            *reinterpret_cast<float4 *>(partial + (size_t)sl * C + c) = make_float4(a.x + a2.x, a.y + a2.y, a.z + a2.z, a.w + a2.w);
+    for (int idx = tid; idx < nwork; idx += nt) {
+        const int c = (idx % Cq) * 4, sl = idx / Cq;
+        const float *xp = (c < C0) ? x0 + c : x1 + (c - C0);
+        const int ld = (c < C0) ? C0 : C1;
+        const float4 K = *reinterpret_cast<const float4 *>(xp);  // pivot: pixel 0
+        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, t1 = s1, t2 = s1;
+        int p = sl;
+        for (; p + nsl < HW; p += 2 * nsl) {
+            const float4 v = *reinterpret_cast<const float4 *>(xp + (int64_t)p * ld);
+            const float4 w = *reinterpret_cast<const float4 *>(xp + (int64_t)(p + nsl) * ld);
+            float d;
+            d = v.x - K.x; s1.x += d; s2.x = fmaf(d, d, s2.x); d = v.y - K.y; s1.y += d; s2.y = fmaf(d, d, s2.y);
+            d = v.z - K.z; s1.z += d; s2.z = fmaf(d, d, s2.z); d = v.w - K.w; s1.w += d; s2.w = fmaf(d, d, s2.w);
+            d = w.x - K.x; t1.x += d; t2.x = fmaf(d, d, t2.x); d = w.y - K.y; t1.y += d; t2.y = fmaf(d, d, t2.y);
+            d = w.z - K.z; t1.z += d; t2.z = fmaf(d, d, t2.z); d = w.w - K.w; t1.w += d; t2.w = fmaf(d, d, t2.w);
         }
-        __syncthreads();
-        for (int c = tid; c < C; c += nt) {
-            float s = 0.f;
-            for (int sl = 0; sl < nsl; sl++) s += partial[(size_t)sl * C + c];
-            chan[c] = s;
+        for (; p < HW; p += nsl) {
+            const float4 v = *reinterpret_cast<const float4 *>(xp + (int64_t)p * ld);
+            float d;
+            d = v.x - K.x; s1.x += d; s2.x = fmaf(d, d, s2.x); d = v.y - K.y; s1.y += d; s2.y = fmaf(d, d, s2.y);
+            d = v.z - K.z; s1.z += d; s2.z = fmaf(d, d, s2.z); d = v.w - K.w; s1.w += d; s2.w = fmaf(d, d, s2.w);
         }
-        __syncthreads();
-        for (int g = tid; g < G; g += nt) {
-            float s = 0.f;
-            for (int c = g * cg; c < (g + 1) * cg; c++) s += chan[c];
-            if (pass) rstd[g] = 1.0f / sqrtf(s * inv_n + eps);
-            else mean[g] = s * inv_n;
-        }
-        __syncthreads();
+        *reinterpret_cast<float4 *>(p1 + (size_t)sl * C + c) = make_float4(s1.x + t1.x, s1.y + t1.y, s1.z + t1.z, s1.w + t1.w);
+        *reinterpret_cast<float4 *>(p2 + (size_t)sl * C + c) = make_float4(s2.x + t2.x, s2.y + t2.y, s2.z + t2.z, s2.w + t2.w);
     }
+    __syncthreads();
+    const float fn = (float)HW;
+    for (int c = tid; c < C; c += nt) {
+        float a = 0.f, q = 0.f;
+        for (int sl = 0; sl < nsl; sl++) { a += p1[(size_t)sl * C + c]; q += p2[(size_t)sl * C + c]; }
+        const float K = (c < C0) ? x0[c] : x1[c - C0];
+        const float dm = a / fn;
+        cmean[c] = K + dm;
+        cm2[c] = fmaxf(q - a * dm, 0.f);   // sum (x - mean_c)^2 = sum (x-K)^2 - (sum (x-K))^2 / n
+    }
+    __syncthreads();
+    for (int g = tid; g < G; g += nt) {
+        float m = 0.f;
+        for (int c = g * cg; c < (g + 1) * cg; c++) m += cmean[c];
+        m /= (float)cg;
+        float M2 = 0.f;
+        for (int c = g * cg; c < (g + 1) * cg; c++) {
+            const float d = cmean[c] - m;
+            M2 += cm2[c] + fn * d * d;
+        }
+        mean[g] = m;
+        rstd[g] = 1.0f / sqrtf(M2 / (fn * (float)cg) + eps);
+    }
+    __syncthreads();
     for (int c = tid; c < C; c += nt) {
         const int g = c / cg;
         float a = rstd[g] * gamma[c];
@@ -181,7 +186,7 @@ int launch_gn_coeffs(const float *src0, const float *src1, int C0, int C1, int B
     ProfScope ps("groupnorm_coeffs", 0.0, 4.0 * ((double)B * HW * C + 2.0 * B * C), st);  // reads x once (algorithmic)
     if (C0 % 4 == 0 && C1 % 4 == 0 && C / 4 <= nt) {
         const int nslv = nt / (C / 4);
-        const size_t shv = (size_t)((size_t)nslv * C + C + 2 * groups) * sizeof(float);
+        const size_t shv = (size_t)((size_t)2 * nslv * C + 2 * C + 2 * groups) * sizeof(float);
         k_gn_coeffs_v4<<<(unsigned)B, nt, shv, st>>>(src0, src1, C0, C1, HW, groups, gamma, beta, ss, ss_stride, ss_offset,
                                                    coefA, coefB, 1e-5f);
         DLPM_LAUNCH_CHECK();

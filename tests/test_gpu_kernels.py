@@ -407,3 +407,19 @@ def test_postprocess_matches_generation_manager_fixture():
         o = torch.empty_like(x)
         _lib.check(L().dlpm_postprocess_f32(x.data_ptr(), o.data_ptr(), x.numel(), clamp, aff, st()))
         assert np.array_equal(o.cpu().numpy(), f[tag + '_samples'])
+
+
+def test_groupnorm_large_offset_is_stable():
+    """|mean| >> std (offset 100, std 0.05): the one-pass shifted statistics must not cancel."""
+    g = torch.Generator().manual_seed(9)
+    C, hw, B = 128, 16, 2
+    x = 100.0 + 0.05 * torch.randn(B, C, hw, hw, generator=g) + 0.3 * torch.randn(B, C, 1, 1, generator=g)
+    gam, bet = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    want = torch.nn.functional.group_norm(x.double(), 32, gam.double(), bet.double(), 1e-5).float()
+    xd, gd, bd = nhwc(x).to(DEV), gam.to(DEV), bet.to(DEV)
+    cA, cB = torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV)
+    _lib.check(L().dlpm_groupnorm_coeffs_f32(xd.data_ptr(), None, C, 0, B, hw * hw, 32, gd.data_ptr(), bd.data_ptr(),
+                                            None, 0, 0, cA.data_ptr(), cB.data_ptr(), st()))
+    y = (x.double() * cA.cpu().double()[:, :, None, None] + cB.cpu().double()[:, :, None, None]).float()
+    # x*A + B with |x| = 100, A ~ 3: the affine form itself carries ~100*3*6e-8 = 2e-5 of rounding in B
+    assert (y - want).abs().max().item() < 2e-4
