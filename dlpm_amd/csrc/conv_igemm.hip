@@ -69,6 +69,10 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvLaunch p) {
     bool a_ok = false;
     const bool has_coef = p.coefA != nullptr;
 
+    // All prefetch loads are UNCONDITIONAL (addresses clamped into range, zeros selected at store
+    // time): a load inside a divergent branch makes hipcc copy its result at the join, which forces
+    // s_waitcnt vmcnt(0) right there and serialises the prefetch with the MFMAs it should hide under.
+    const int wrow = min(n0 + rb, p.Cout - 1);
     auto load_step = [&](int s) {
         const int chunk = s / ntaps, tap = s - chunk * ntaps;
         const int c0 = chunk * KC;
@@ -76,26 +80,23 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvLaunch p) {
         const int iy = oy * p.stride + ky - pad, ix = ox * p.stride + kx - pad;
         a_ok = row_ok && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
         const int c = c0 + sega;
-        if (a_ok) {
-            const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
-            const int64_t pix = ((int64_t)pb * p.Hin + sy) * p.Win + sx;
-            const float *src = (c < p.C0) ? p.src0 + pix * p.C0 + c : p.src1 + pix * p.C1 + (c - p.C0);
+        const int cy = min(max(iy, 0), Hi - 1), cx = min(max(ix, 0), Wi - 1);
+        const int sy = p.ups ? (cy >> 1) : cy, sx = p.ups ? (cx >> 1) : cx;
+        const int64_t pix = ((int64_t)pb * p.Hin + sy) * p.Win + sx;
+        const float *src = (c < p.C0) ? p.src0 + pix * p.C0 + c : p.src1 + pix * p.C1 + (c - p.C0);
 #pragma unroll
-            for (int v = 0; v < 4; v++) xa[v] = reinterpret_cast<const float4 *>(src)[v];
-            if (has_coef) {
-                const float *pa = p.coefA + (int64_t)pb * Cin + c, *pbq = p.coefB + (int64_t)pb * Cin + c;
+        for (int v = 0; v < 4; v++) xa[v] = reinterpret_cast<const float4 *>(src)[v];
+        if (has_coef) {  // wave-uniform
+            const float *pa = p.coefA + (int64_t)pb * Cin + c, *pbq = p.coefB + (int64_t)pb * Cin + c;
 #pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    ca[v] = reinterpret_cast<const float4 *>(pa)[v];
-                    cb[v] = reinterpret_cast<const float4 *>(pbq)[v];
-                }
+            for (int v = 0; v < 4; v++) {
+                ca[v] = reinterpret_cast<const float4 *>(pa)[v];
+                cb[v] = reinterpret_cast<const float4 *>(pbq)[v];
             }
         }
-        if (wrow_ok) {
-            const float *wp = p.w + ((int64_t)tap * p.Cout + (n0 + rb)) * Cin + c0 + segb;
+        const float *wp = p.w + ((int64_t)tap * p.Cout + wrow) * Cin + c0 + segb;
 #pragma unroll
-            for (int v = 0; v < NBV; v++) wb[v] = reinterpret_cast<const float4 *>(wp)[v];
-        }
+        for (int v = 0; v < NBV; v++) wb[v] = reinterpret_cast<const float4 *>(wp)[v];
     };
 
     auto store_step = [&](int buf) {
@@ -103,23 +104,20 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvLaunch p) {
         float4 *da = reinterpret_cast<float4 *>(As + ra * LDS_LD + sega);
 #pragma unroll
         for (int v = 0; v < 4; v++) {
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a_ok) {
-                x = xa[v];
-                if (has_coef) {
-                    x.x = fmaf(x.x, ca[v].x, cb[v].x);
-                    x.y = fmaf(x.y, ca[v].y, cb[v].y);
-                    x.z = fmaf(x.z, ca[v].z, cb[v].z);
-                    x.w = fmaf(x.w, ca[v].w, cb[v].w);
-                }
-                if (p.act_silu) {
-                    x.x = silu_f(x.x);
-                    x.y = silu_f(x.y);
-                    x.z = silu_f(x.z);
-                    x.w = silu_f(x.w);
-                }
+            float4 x = xa[v];
+            if (has_coef) {
+                x.x = fmaf(x.x, ca[v].x, cb[v].x);
+                x.y = fmaf(x.y, ca[v].y, cb[v].y);
+                x.z = fmaf(x.z, ca[v].z, cb[v].z);
+                x.w = fmaf(x.w, ca[v].w, cb[v].w);
             }
-            da[v] = x;
+            if (p.act_silu) {
+                x.x = silu_f(x.x);
+                x.y = silu_f(x.y);
+                x.z = silu_f(x.z);
+                x.w = silu_f(x.w);
+            }
+            da[v] = a_ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         float4 *db = reinterpret_cast<float4 *>(Bs + rb * LDS_LD + segb);
 #pragma unroll
@@ -246,17 +244,18 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th, int 
     // coefficient staging: thread t < nimg*16 carries one float4 of A (t & 8 == 0) or B of image t >> 4
     const int cf_img = tid >> 4, cf_isb = (tid >> 3) & 1;
     const bool cf_mine = has_coef && tid < nimg * 16 && (pb + cf_img) < p.B;
+    const float *cf_base = has_coef ? ((cf_isb ? p.coefB : p.coefA) + (int64_t)min(pb + cf_img, p.B - 1) * Cin) : nullptr;
 
     auto load_halo = [&](int chunk) {
         const int c = chunk * KC + c4;
         const bool first = c < p.C0;
         const float *sb = first ? p.src0 + c : p.src1 + (c - p.C0);
         const int ld = first ? p.C0 : p.C1;
+        // unconditional loads (see k_conv_igemm): padding / out-of-halo items read pixel offc = 0
 #pragma unroll
         for (int it = 0; it < HALO_NIT; it++)
-            if (off[it] >= 0) xh[it] = *reinterpret_cast<const float4 *>(sb + (int64_t)off[it] * ld);
-        if (cf_mine)
-            cfr = *reinterpret_cast<const float4 *>((cf_isb ? p.coefB : p.coefA) + (int64_t)(pb + cf_img) * Cin + c);
+            if (it < nit) xh[it] = *reinterpret_cast<const float4 *>(sb + (int64_t)max(off[it], 0) * ld);
+        if (has_coef) cfr = *reinterpret_cast<const float4 *>(cf_base + c);
     };
     auto store_coef = [&]() {
         if (cf_mine) *reinterpret_cast<float4 *>(Cf + cf_img * 64 + cf_isb * 32 + c4) = cfr;
@@ -269,7 +268,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th, int 
             if (off[it] >= 0) {
                 x = xh[it];
                 if (has_coef) {
-                    const int img = (it * 32 + (tid >> 3)) / hpi;
+                    const int img = (nimg > 1) ? (it * 32 + (tid >> 3)) / hpi : 0;
                     const float4 ca = *reinterpret_cast<const float4 *>(Cf + img * 64 + c4);
                     const float4 cb = *reinterpret_cast<const float4 *>(Cf + img * 64 + 32 + c4);
                     x.x = fmaf(x.x, ca.x, cb.x);
@@ -292,12 +291,11 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th, int 
     const int rb = tid / TPR, segb = (tid % TPR) * NBF;
     const bool wrow_ok = (n0 + rb) < p.Cout;
     float4 wb[NBV];
+    const int wrow = min(n0 + rb, p.Cout - 1);
     auto load_w = [&](int chunk, int tap) {
-        if (wrow_ok) {
-            const float *wp = p.w + ((int64_t)tap * p.Cout + (n0 + rb)) * Cin + chunk * KC + segb;
+        const float *wp = p.w + ((int64_t)tap * p.Cout + wrow) * Cin + chunk * KC + segb;
 #pragma unroll
-            for (int v = 0; v < NBV; v++) wb[v] = reinterpret_cast<const float4 *>(wp)[v];
-        }
+        for (int v = 0; v < NBV; v++) wb[v] = reinterpret_cast<const float4 *>(wp)[v];
     };
     auto store_w = [&](int buf) {
         float4 *db = reinterpret_cast<float4 *>(Bsb + buf * BN * LDS_LD + rb * LDS_LD + segb);
@@ -340,8 +338,10 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th, int 
         for (int tap = 0; tap < 9; tap++, s++) {
             const int buf = s & 1;
             const bool last_tap = tap == 8, more = (chunk + 1 < nch);
-            if (!last_tap) load_w(chunk, tap + 1);
-            else if (more) { load_w(chunk + 1, 0); load_halo(chunk + 1); }
+            // one UNCONDITIONAL weight prefetch per tap (harmlessly redundant on the very last step):
+            // two call sites would make hipcc merge their results with copies behind a vmcnt(0)
+            load_w(last_tap ? min(chunk + 1, nch - 1) : chunk, last_tap ? 0 : tap + 1);
+            if (last_tap && more) load_halo(chunk + 1);
 
             const int ky = tap / 3, kx = tap - ky * 3;
             const int toff = (ky * Wp + kx) * LDS_LD;
