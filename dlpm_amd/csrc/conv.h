@@ -18,7 +18,8 @@ struct ConvLaunch {
     int R0 = 0;
     float *out = nullptr;
     int Cout = 0;
-    int in_nchw = 0, out_nchw = 0;  // direct kernel only
+    int in_nchw = 0, out_nchw = 0;  // boundary layouts
+    int abl = 0;                    // timing-only ablation bits (DLPM_ABL env; results are wrong when set)
 };
 
 // true when the MFMA implicit-GEMM kernel covers this shape
