@@ -169,14 +169,17 @@ def main():
         _lib.check(L.dlpm_prof_enable(0))
         prof = parse_prof(buf.value.decode())
         breakdown = {k: round(v['ms'] / nprof, 4) for k, v in prof.items()}
-        c = prof.get('conv3x3_igemm')
+        c = prof.get('conv3x3_halo') or prof.get('conv3x3_igemm')
         if c:
             ach = c['flops'] / (c['ms'] * 1e-3) / 1e12
-            roofline = dict(kernel='k_conv_igemm (3x3, fp32 MFMA 32x32x2)', bound='mfma', achieved=round(ach, 3),
-                            peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s', frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                            traffic=None, launches_per_step=c['launches'] // nprof,
-                            avg_launch_ms=round(c['ms'] / c['launches'], 5),
-                            flops_per_launch_avg=c['flops'] / c['launches'])
+            roofline = dict(kernel='k_conv3x3_halo<128,2,2,2,2> (3x3 stride-1 conv, fp32 MFMA 32x32x2, fused GN+SiLU/bias/residual)',
+                            bound='mfma', achieved=round(ach, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
+                            frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                            launches_per_step=c['launches'] // nprof, avg_launch_ms=round(c['ms'] / c['launches'], 5),
+                            flops_per_launch_avg=c['flops'] / c['launches'],
+                            share_of_step_ms=round(c['ms'] / nprof, 3),
+                            all_mfma_conv_classes_tflops=round(sum(v['flops'] for k, v in prof.items() if k.startswith('conv') and 'stem' not in k and 'direct' not in k)
+                                                               / (sum(v['ms'] for k, v in prof.items() if k.startswith('conv') and 'stem' not in k and 'direct' not in k) * 1e-3) / 1e12, 3))
         u = prof.get('update')
         if u:
             gbs = u['bytes'] / (u['ms'] * 1e-3) / 1e9

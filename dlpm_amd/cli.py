@@ -1,0 +1,87 @@
+"""`eval.py --generate`-compatible command line for the sampling path (no dataset / neptune needed).
+
+Covers the reference flags that reach the sampler (script_utils.py:11-12,35-39,56-67,82-83,155-221):
+  --config --generate --reverse_steps --deterministic --clip --alpha --set_seed/--random_seed
+plus --checkpoint (a reference .pt file: TrainingManager.py:267-285), --ema_eval, --out.
+Samples are produced in chunks of eval.batch_size like EvaluationManager (:181-193).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+import dlpm_amd
+from dlpm_amd.config import sample_shape
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument('--config', required=True, help='config name (dlpm_amd/configs) or path to a reference-schema YAML')
+    ap.add_argument('--generate', type=int, default=None, help='number of samples (eval.data_to_generate)')
+    ap.add_argument('--reverse_steps', type=int, default=None)
+    ap.add_argument('--alpha', type=float, default=None)
+    ap.add_argument('--deterministic', action='store_true', help='DLIM sampling')
+    ap.add_argument('--clip', action='store_true', help='clip_denoised')
+    ap.add_argument('--set_seed', type=int, default=None)
+    ap.add_argument('--random_seed', action='store_true')
+    ap.add_argument('--batch_size', type=int, default=None, help='eval.batch_size override')
+    ap.add_argument('--checkpoint', default=None, help='reference checkpoint (.pt) with model_parameters / ema_models')
+    ap.add_argument('--ema_eval', action='store_true')
+    ap.add_argument('--synthetic_weights', type=int, default=None, metavar='SEED',
+                    help='random init with the zero-initialised tensors re-drawn (benchmarks; NOT the reference init)')
+    ap.add_argument('--rng', default='philox', choices=['philox', 'reference'])
+    ap.add_argument('--out', default=None, help='.npy file for the generated samples')
+    a = ap.parse_args(argv)
+
+    p = dlpm_amd.load_config(a.config)
+    p['device'] = 'cuda'
+    m = p['method']
+    if a.alpha is not None:
+        p[m]['alpha'] = a.alpha
+    if a.generate is not None:
+        assert a.generate <= p['eval']['real_data'], 'cannot generate more data than the number of real data'
+        p['eval']['data_to_generate'] = a.generate
+    if a.reverse_steps is not None:
+        p['eval'][m]['reverse_steps'] = a.reverse_steps
+    if a.deterministic:
+        p['eval'][m]['deterministic'] = True
+    if a.clip:
+        p['eval'][m]['clip_denoised'] = True
+    if a.batch_size is not None:
+        p['eval']['batch_size'] = a.batch_size
+    seed = None if a.random_seed else a.set_seed
+    if seed is not None:
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+
+    model = dlpm_amd.init_model_by_parameter(p)
+    if a.checkpoint:
+        ck = torch.load(a.checkpoint, map_location='cpu')
+        if a.ema_eval and ck.get('ema_models'):
+            sd = model.state_dict()
+            sd.update(ck['ema_models'][0].get('shadow', ck['ema_models'][0]))
+            model.load_state_dict(sd)
+        else:
+            model.load_state_dict(ck['model_parameters'])
+    elif a.synthetic_weights is not None:
+        dlpm_amd.rerandomize_(model, a.synthetic_weights)
+    method = dlpm_amd.init_method_by_parameter(p, rng=a.rng, seed=seed or 0)
+    is_image = dlpm_amd.is_image_dataset(p['data']['dataset'])
+    gm = dlpm_amd.GenerationManager(method, dlpm_amd.ShapeProbe(sample_shape(p)), is_image, **p['eval'][m])
+    remaining, chunks = p['eval']['data_to_generate'], []
+    while remaining > 0:                                    # EvaluationManager.py:181-193
+        n = min(p['eval']['batch_size'], remaining)
+        chunks.append(gm.generate({'default': model}, n).clone())
+        remaining -= n
+        print('generated %d, %d to go' % (n, remaining), file=sys.stderr)
+    samples = torch.cat(chunks)
+    if a.out:
+        np.save(a.out, samples.numpy())
+    print('samples %s  mean %.4f  min %.4f  max %.4f' % (tuple(samples.shape), samples.mean(), samples.min(), samples.max()))
+    return samples
+
+
+if __name__ == '__main__':
+    main()

@@ -553,13 +553,13 @@ int launch_conv_igemm(const ConvLaunch &c, hipStream_t st) {
     // algorithmic bytes: input once + weights once + output once (+ residual)
     const double bytes = 4.0 * ((double)c.B * c.Hin * c.Win * (c.C0 + c.C1) + K * c.Cout + (double)M * c.Cout * (c.res0 ? 2 : 1));
     char pname[96];
+    int th = 0, nimg = 1;
     if (prof_enabled() && prof_detail())
         snprintf(pname, sizeof(pname), "conv%dx%d_igemm:H%d:Cin%d+%d:Cout%d:s%d:u%d:coef%d", c.ks, c.ks, c.Hout, c.C0, c.C1, c.Cout,
                  c.stride, c.ups, c.coefA ? 1 : 0);
     else
-        snprintf(pname, sizeof(pname), "%s", c.ks == 3 ? "conv3x3_igemm" : "conv1x1_igemm");
+        snprintf(pname, sizeof(pname), "%s", c.ks == 3 ? (halo_ok(c, &th, &nimg) ? "conv3x3_halo" : "conv3x3_igemm") : "conv1x1_igemm");
     ProfScope ps(pname, 2.0 * M * c.Cout * K, bytes, st);
-    int th = 0, nimg = 1;
     static int abl = -1;
     if (abl < 0) { const char *e = getenv("DLPM_ABL"); abl = e ? atoi(e) : 0; }
     if (abl) const_cast<ConvLaunch &>(c).abl = abl;

@@ -120,8 +120,13 @@ __device__ inline float clip_eps(float x, float e, const StepScalars &c) {
     return __fdiv_rn(x - __fmul_rn(xs, c.bg), c.bs);
 }
 
+// One reverse step, fused.  VEC: D % 4 == 0 -> each thread owns UNROLL float4 quads spaced a whole
+// grid apart, issues all of their loads (x, eps, coefficients, optional z) before any arithmetic,
+// then computes (Philox normals in registers) and stores: enough bytes in flight per CU to stream
+// at HBM rate even though the whole tensor is only tens of MB.
 template <bool VEC>
 __global__ void __launch_bounds__(256) k_update(dlpm_update_args p) {
+    constexpr int UNROLL = 4;
     const int t = *p.t_dev;
     StepScalars c{p.g_dev[t], p.bg_dev[t], p.bs_dev[t], p.bs_dev[t > 0 ? t - 1 : 0]};
     const bool dlim = p.flags & DLPM_UPD_DLIM, clip = p.flags & DLPM_UPD_CLIP;
@@ -134,35 +139,62 @@ __global__ void __launch_bounds__(256) k_update(dlpm_update_args p) {
         dl_sig = p.dlim_eta * c.bs_prev;
         dl_mean = powf(powf(c.bs_prev, p.alpha) - powf(dl_sig, p.alpha), 1.0f / p.alpha);
     }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = i / nq, q = i - b * nq;
-        float ce, cn;
-        if (!dlim) {
-            ce = p.c_eps_dev[(int64_t)t * p.B + b];
-            cn = p.c_noise_dev[(int64_t)t * p.B + b];
-        } else {
-            ce = c.bs;
-            cn = (p.dlim_eta != 0.0f && t != 1) ? dl_sig * sqrtf(p.A_dev[(int64_t)t * p.B + b]) : 0.0f;
-        }
-        if (VEC) {
-            const int64_t base = b * D + q * 4;
-            float4 x = *reinterpret_cast<const float4 *>(p.x_dev + base);
-            float4 e = *reinterpret_cast<const float4 *>(p.eps_dev + base);
-            float4 z;
-            if (p.z_dev) z = *reinterpret_cast<const float4 *>(p.z_dev + base);
-            else if (cn != 0.0f) z = philox_normal4(p.seed, (uint64_t)(p.sample_offset + b), (uint32_t)q, kPurposeStepZ, (uint32_t)t);
-            else z = make_float4(0.f, 0.f, 0.f, 0.f);
-            float xv[4] = {x.x, x.y, x.z, x.w}, ev[4] = {e.x, e.y, e.z, e.w}, zv[4] = {z.x, z.y, z.z, z.w}, o[4];
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (VEC) {
+        for (int64_t base_i = tid0; base_i < total; base_i += nthreads * UNROLL) {
+            float4 x[UNROLL], e[UNROLL], z[UNROLL];
+            float ce[UNROLL], cn[UNROLL];
+            int64_t b[UNROLL], q[UNROLL];
+            bool ok[UNROLL];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                float ee = clip ? clip_eps(xv[j], ev[j], c) : ev[j];
-                float m = __fdiv_rn(xv[j] - __fmul_rn(ce, ee), c.g);
-                if (dlim) m = __fadd_rn(m, __fmul_rn(dl_mean, ee));
-                o[j] = __fadd_rn(m, __fmul_rn(cn, zv[j]));
+            for (int u = 0; u < UNROLL; u++) {
+                const int64_t i = base_i + u * nthreads;
+                ok[u] = i < total;
+                const int64_t ii = ok[u] ? i : tid0;          // clamp: loads stay unconditional
+                b[u] = ii / nq;
+                q[u] = ii - b[u] * nq;
+                const int64_t off = b[u] * D + q[u] * 4;
+                x[u] = *reinterpret_cast<const float4 *>(p.x_dev + off);
+                e[u] = *reinterpret_cast<const float4 *>(p.eps_dev + off);
+                if (p.z_dev) z[u] = *reinterpret_cast<const float4 *>(p.z_dev + off);
+                if (!dlim) {
+                    ce[u] = p.c_eps_dev[(int64_t)t * p.B + b[u]];
+                    cn[u] = p.c_noise_dev[(int64_t)t * p.B + b[u]];
+                } else {
+                    ce[u] = c.bs;
+                    cn[u] = (p.dlim_eta != 0.0f && t != 1) ? dl_sig * sqrtf(p.A_dev[(int64_t)t * p.B + b[u]]) : 0.0f;
+                }
             }
-            *reinterpret_cast<float4 *>(p.x_dev + base) = make_float4(o[0], o[1], o[2], o[3]);
-        } else {
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                if (!p.z_dev)
+                    z[u] = (cn[u] != 0.0f) ? philox_normal4(p.seed, (uint64_t)(p.sample_offset + b[u]), (uint32_t)q[u],
+                                                            kPurposeStepZ, (uint32_t)t)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                float xv[4] = {x[u].x, x[u].y, x[u].z, x[u].w}, ev[4] = {e[u].x, e[u].y, e[u].z, e[u].w};
+                float zv[4] = {z[u].x, z[u].y, z[u].z, z[u].w}, o[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float ee = clip ? clip_eps(xv[j], ev[j], c) : ev[j];
+                    float m = __fdiv_rn(xv[j] - __fmul_rn(ce[u], ee), c.g);
+                    if (dlim) m = __fadd_rn(m, __fmul_rn(dl_mean, ee));
+                    o[j] = __fadd_rn(m, __fmul_rn(cn[u], zv[j]));
+                }
+                if (ok[u]) *reinterpret_cast<float4 *>(p.x_dev + b[u] * D + q[u] * 4) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    } else {
+        for (int64_t i = tid0; i < total; i += nthreads) {
+            const int64_t b = i / nq, q = i - b * nq;
+            float ce, cn;
+            if (!dlim) {
+                ce = p.c_eps_dev[(int64_t)t * p.B + b];
+                cn = p.c_noise_dev[(int64_t)t * p.B + b];
+            } else {
+                ce = c.bs;
+                cn = (p.dlim_eta != 0.0f && t != 1) ? dl_sig * sqrtf(p.A_dev[(int64_t)t * p.B + b]) : 0.0f;
+            }
             const int64_t idx = b * D + q;
             float xv = p.x_dev[idx], ev = p.eps_dev[idx], zv;
             if (p.z_dev) zv = p.z_dev[idx];
@@ -267,7 +299,8 @@ extern "C" int dlpm_update_f32(const dlpm_update_args *a, dlpm_stream_t stream) 
                                           reinterpret_cast<uintptr_t>(a->z_dev)) % 16 == 0);
     int64_t items = a->B * (vec ? a->D / 4 : a->D);
     // memory-bound: cap the grid at 8 blocks per CU and grid-stride the rest
-    unsigned grid = (unsigned)std::min<int64_t>(ceil_div(items, 256), 256 * 8);
+    // 4 quads per thread (see k_update); at most 8 blocks per CU, the rest is grid-strided
+    unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(items, 256 * (vec ? 4 : 1)), 256 * 8));
     // algorithmic bytes: read x, read eps, write x (+ read z when injected)
     ProfScope ps("update", 0.0, 4.0 * (double)a->B * a->D * (a->z_dev ? 4 : 3), as_stream(stream));
     if (vec) k_update<true><<<grid, 256, 0, as_stream(stream)>>>(*a);
