@@ -212,6 +212,53 @@ __global__ void __launch_bounds__(256) k_update(dlpm_update_args p) {
     }
 }
 
+// Fast path of the fused update (stochastic DLPM step, no clipping, D % 4 == 0): one workgroup per
+// sample, so the two per-sample coefficients are wave-uniform scalars, the Philox counter is just
+// (sample, quad), and there is no per-element index division.  Three quads per thread are loaded
+// before any arithmetic.  The division by gamma_t is a reciprocal multiply plus one Newton residual
+// step (correctly rounded except for ties; the reference divides).
+__device__ __forceinline__ float div_by(float a, float g, float rg) {
+    const float q = a * rg;
+    return fmaf(fmaf(-q, g, a), rg, q);
+}
+
+__global__ void __launch_bounds__(256) k_update_rows(dlpm_update_args p) {
+    const int t = *p.t_dev;
+    const float g = p.g_dev[t], rg = 1.0f / g;
+    const int64_t b = blockIdx.x;
+    const float ce = p.c_eps_dev[(int64_t)t * p.B + b], cn = p.c_noise_dev[(int64_t)t * p.B + b];
+    const int nq = (int)(p.D >> 2);
+    float *xr = p.x_dev + b * p.D;
+    const float *er = p.eps_dev + b * p.D;
+    const float *zr = p.z_dev ? p.z_dev + b * p.D : nullptr;
+    const uint64_t gidx = (uint64_t)(p.sample_offset + b);
+    for (int q0 = threadIdx.x; q0 < nq; q0 += 3 * 256) {
+        float4 x[3], e[3], z[3];
+        int q[3];
+        bool ok[3];
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            q[u] = q0 + u * 256;
+            ok[u] = q[u] < nq;
+            const int qq = ok[u] ? q[u] : q0;
+            x[u] = reinterpret_cast<const float4 *>(xr)[qq];
+            e[u] = reinterpret_cast<const float4 *>(er)[qq];
+            if (zr) z[u] = reinterpret_cast<const float4 *>(zr)[qq];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            if (!zr) z[u] = (cn != 0.0f) ? philox_normal4(p.seed, gidx, (uint32_t)q[u], kPurposeStepZ, (uint32_t)t)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 o;
+            o.x = fmaf(cn, z[u].x, div_by(x[u].x - ce * e[u].x, g, rg));
+            o.y = fmaf(cn, z[u].y, div_by(x[u].y - ce * e[u].y, g, rg));
+            o.z = fmaf(cn, z[u].z, div_by(x[u].z - ce * e[u].z, g, rg));
+            o.w = fmaf(cn, z[u].w, div_by(x[u].w - ce * e[u].w, g, rg));
+            if (ok[u]) reinterpret_cast<float4 *>(xr)[q[u]] = o;
+        }
+    }
+}
+
 __global__ void k_advance(int32_t *t) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *t = *t - 1;
 }
@@ -303,7 +350,9 @@ extern "C" int dlpm_update_f32(const dlpm_update_args *a, dlpm_stream_t stream) 
     unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(items, 256 * (vec ? 4 : 1)), 256 * 8));
     // algorithmic bytes: read x, read eps, write x (+ read z when injected)
     ProfScope ps("update", 0.0, 4.0 * (double)a->B * a->D * (a->z_dev ? 4 : 3), as_stream(stream));
-    if (vec) k_update<true><<<grid, 256, 0, as_stream(stream)>>>(*a);
+    if (vec && !(a->flags & (DLPM_UPD_DLIM | DLPM_UPD_CLIP)) && a->B < (1 << 30))
+        k_update_rows<<<(unsigned)a->B, 256, 0, as_stream(stream)>>>(*a);
+    else if (vec) k_update<true><<<grid, 256, 0, as_stream(stream)>>>(*a);
     else k_update<false><<<grid, 256, 0, as_stream(stream)>>>(*a);
     DLPM_LAUNCH_CHECK();
     if (a->flags & DLPM_UPD_ADVANCE) {

@@ -12,9 +12,9 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint64_t key) {
     uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-        c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
+        // one 32x32->64 multiply each (v_mad_u64_u32): integer multiplies are quarter rate on CDNA
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x, p1 = (uint64_t)0xCD9E8D57u * c.z;
+        c = make_uint4((uint32_t)(p1 >> 32) ^ c.y ^ k0, (uint32_t)p1, (uint32_t)(p0 >> 32) ^ c.w ^ k1, (uint32_t)p0);
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
@@ -28,11 +28,12 @@ __device__ __forceinline__ float4 philox_normal4(uint64_t seed, uint64_t gidx, u
     const float k = 1.0f / 16777216.0f;
     float u0 = ((float)(r.x >> 8) + 0.5f) * k, u1 = ((float)(r.y >> 8) + 0.5f) * k;
     float u2 = ((float)(r.z >> 8) + 0.5f) * k, u3 = ((float)(r.w >> 8) + 0.5f) * k;
-    float r0 = sqrtf(-2.0f * __logf(u0)), r1 = sqrtf(-2.0f * __logf(u2));
-    float s0, c0, s1, c1;
-    __sincosf(6.28318530717958647692f * u1, &s0, &c0);
-    __sincosf(6.28318530717958647692f * u3, &s1, &c1);
-    return make_float4(r0 * c0, r0 * s0, r1 * c1, r1 * s1);
+    // Box-Muller on the hardware transcendentals: v_log_f32 is log2, v_sin/v_cos take REVOLUTIONS
+    // (sin(2 pi x)), so no range reduction and no 2*pi multiply are needed.
+    const float k2 = -1.3862943611198906f;  // -2 ln 2
+    float r0 = __builtin_amdgcn_sqrtf(k2 * __builtin_amdgcn_logf(u0)), r1 = __builtin_amdgcn_sqrtf(k2 * __builtin_amdgcn_logf(u2));
+    return make_float4(r0 * __builtin_amdgcn_cosf(u1), r0 * __builtin_amdgcn_sinf(u1), r1 * __builtin_amdgcn_cosf(u3),
+                       r1 * __builtin_amdgcn_sinf(u3));
 }
 
 }  // namespace dlpm
