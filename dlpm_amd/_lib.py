@@ -22,7 +22,7 @@ class MT19937(C.Structure):
 class UpdateArgs(C.Structure):
     _fields_ = [('x_dev', vp), ('eps_dev', vp), ('z_dev', vp), ('t_dev', vp), ('g_dev', vp), ('bg_dev', vp),
                 ('bs_dev', vp), ('c_eps_dev', vp), ('c_noise_dev', vp), ('A_dev', vp), ('B', i64), ('D', i64),
-                ('T', i32), ('flags', i32), ('dlim_eta', f32), ('alpha', f32), ('seed', u64), ('sample_offset', i64)]
+                ('T', i32), ('flags', i32), ('dlim_eta', f32), ('alpha', f32), ('seed', u64), ('sample_offset', i64), ('key_dev', vp)]
 
 
 class UNetConfig(C.Structure):

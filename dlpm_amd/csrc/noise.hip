@@ -127,6 +127,7 @@ __device__ inline float clip_eps(float x, float e, const StepScalars &c) {
 template <bool VEC>
 __global__ void __launch_bounds__(256) k_update(dlpm_update_args p) {
     constexpr int UNROLL = 4;
+    if (p.key_dev) { p.seed = p.key_dev[0]; p.sample_offset = (int64_t)p.key_dev[1]; }
     const int t = *p.t_dev;
     StepScalars c{p.g_dev[t], p.bg_dev[t], p.bs_dev[t], p.bs_dev[t > 0 ? t - 1 : 0]};
     const bool dlim = p.flags & DLPM_UPD_DLIM, clip = p.flags & DLPM_UPD_CLIP;
@@ -231,7 +232,8 @@ __global__ void __launch_bounds__(256) k_update_rows(dlpm_update_args p) {
     float *xr = p.x_dev + b * p.D;
     const float *er = p.eps_dev + b * p.D;
     const float *zr = p.z_dev ? p.z_dev + b * p.D : nullptr;
-    const uint64_t gidx = (uint64_t)(p.sample_offset + b);
+    const uint64_t seed = p.key_dev ? p.key_dev[0] : p.seed;
+    const uint64_t gidx = (uint64_t)((p.key_dev ? (int64_t)p.key_dev[1] : p.sample_offset) + b);
     for (int q0 = threadIdx.x; q0 < nq; q0 += 3 * 256) {
         float4 x[3], e[3], z[3];
         int q[3];
@@ -247,7 +249,7 @@ __global__ void __launch_bounds__(256) k_update_rows(dlpm_update_args p) {
         }
 #pragma unroll
         for (int u = 0; u < 3; u++) {
-            if (!zr) z[u] = (cn != 0.0f) ? philox_normal4(p.seed, gidx, (uint32_t)q[u], kPurposeStepZ, (uint32_t)t)
+            if (!zr) z[u] = (cn != 0.0f) ? philox_normal4(seed, gidx, (uint32_t)q[u], kPurposeStepZ, (uint32_t)t)
                                          : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 o;
             o.x = fmaf(cn, z[u].x, div_by(x[u].x - ce * e[u].x, g, rg));

@@ -21,6 +21,8 @@ struct dlpm_sampler {
     float *A = nullptr, *c_eps = nullptr, *c_noise = nullptr;         // [T,B]
     float *x = nullptr, *eps = nullptr, *tvec = nullptr;
     int32_t *t_dev = nullptr;
+    uint64_t *key_dev = nullptr;   // {seed, sample_offset}: read by the update kernel, so reseeding keeps the graph
+    int graph_steps = 0;           // steps inside the captured graph
     void *ws = nullptr;
     int64_t ws_bytes = 0;
     int32_t t_host = 0;
@@ -61,7 +63,7 @@ int one_step(dlpm_sampler *s, const float *z, bool advance, hipStream_t st) {
     a.B = s->cfg.B; a.D = s->D; a.T = s->cfg.T;
     a.flags = (s->cfg.flags & (DLPM_UPD_DLIM | DLPM_UPD_CLIP)) | (advance ? DLPM_UPD_ADVANCE : 0);
     a.dlim_eta = s->cfg.dlim_eta; a.alpha = (float)s->cfg.alpha;
-    a.seed = s->cfg.seed; a.sample_offset = s->cfg.sample_offset;
+    a.seed = s->cfg.seed; a.sample_offset = s->cfg.sample_offset; a.key_dev = s->key_dev;
     return dlpm_update_f32(&a, st);
 }
 
@@ -117,6 +119,11 @@ extern "C" int dlpm_sampler_create(const dlpm_sampler_config *cfg, dlpm_sampler 
     if ((e = hipMalloc(&s->eps, (size_t)B * s->D * sizeof(float))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&s->tvec, (size_t)B * sizeof(float))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&s->t_dev, sizeof(int32_t))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&s->key_dev, 2 * sizeof(uint64_t))) != hipSuccess) return fail(e);
+    {
+        uint64_t key[2] = {cfg->seed, (uint64_t)cfg->sample_offset};
+        if ((e = hipMemcpy(s->key_dev, key, sizeof(key), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    }
     if (cfg->unet) {
         s->ws_bytes = dlpm_unet_workspace_bytes(cfg->unet, B);
         if (s->ws_bytes < 0) {
@@ -134,11 +141,11 @@ extern "C" int dlpm_sampler_reseed(dlpm_sampler *s, uint64_t seed, int64_t sampl
     if (seed == s->cfg.seed && sample_offset == s->cfg.sample_offset) return DLPM_OK;
     s->cfg.seed = seed;
     s->cfg.sample_offset = sample_offset;
-    // the Philox key is a kernel argument baked into the captured update node: recapture lazily
-    if (s->exec) (void)hipGraphExecDestroy(s->exec);
-    if (s->graph) (void)hipGraphDestroy(s->graph);
-    s->exec = nullptr;
-    s->graph = nullptr;
+    // the key is read from device memory by the captured update node: no recapture needed.  The copy
+    // is synchronous: it must not race with a replay still in flight on the private stream.
+    DLPM_HIP(hipDeviceSynchronize());
+    uint64_t key[2] = {seed, (uint64_t)sample_offset};
+    DLPM_HIP(hipMemcpy(s->key_dev, key, sizeof(key), hipMemcpyHostToDevice));
     return DLPM_OK;
 }
 
@@ -169,28 +176,40 @@ extern "C" int dlpm_sampler_step_injected(dlpm_sampler *s, const float *z_dev, d
 
 static int steps_on(dlpm_sampler *s, int32_t nsteps, hipStream_t st, bool graph) {
     if (graph && !s->exec) {
-        // the first step runs eagerly (sets function attributes, pages code in), the second is captured
+        // the first step runs eagerly (sets function attributes, pages code in), then `use_graph`
+        // consecutive steps are captured into one graph
         TRY(one_step(s, nullptr, true, st));
         s->t_host -= 1;
         nsteps -= 1;
-        if (nsteps == 0) return DLPM_OK;
-        DLPM_HIP(hipStreamSynchronize(st));
-        DLPM_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        int r = one_step(s, nullptr, true, st);
-        hipError_t e = hipStreamEndCapture(st, &s->graph);
-        if (r != DLPM_OK) {
-            if (s->graph) (void)hipGraphDestroy(s->graph);
-            s->graph = nullptr;
-            return r;
+        const int gs = s->cfg.use_graph;
+        if (nsteps >= gs) {
+            DLPM_HIP(hipStreamSynchronize(st));
+            DLPM_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            int r = DLPM_OK;
+            for (int i = 0; i < gs && r == DLPM_OK; i++) r = one_step(s, nullptr, true, st);
+            hipError_t e = hipStreamEndCapture(st, &s->graph);
+            if (r != DLPM_OK) {
+                if (s->graph) (void)hipGraphDestroy(s->graph);
+                s->graph = nullptr;
+                return r;
+            }
+            DLPM_HIP(e);
+            DLPM_HIP(hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0));
+            s->graph_steps = gs;
+            // capture only records: nothing ran, so t is unchanged and the replays below do the work
         }
-        DLPM_HIP(e);
-        DLPM_HIP(hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0));
     }
-    for (int i = 0; i < nsteps; i++) {
-        if (graph) DLPM_HIP(hipGraphLaunch(s->exec, st));
-        else TRY(one_step(s, nullptr, true, st));
+    while (nsteps > 0) {
+        if (graph && s->exec && nsteps >= s->graph_steps) {
+            DLPM_HIP(hipGraphLaunch(s->exec, st));
+            nsteps -= s->graph_steps;
+            s->t_host -= s->graph_steps;
+        } else {
+            TRY(one_step(s, nullptr, true, st));
+            nsteps -= 1;
+            s->t_host -= 1;
+        }
     }
-    s->t_host -= nsteps;
     return DLPM_OK;
 }
 
@@ -240,7 +259,7 @@ extern "C" void dlpm_sampler_destroy(dlpm_sampler *s) {
     if (s->ev_in) (void)hipEventDestroy(s->ev_in);
     if (s->ev_out) (void)hipEventDestroy(s->ev_out);
     if (s->own) (void)hipStreamDestroy(s->own);
-    void *bufs[] = {s->g, s->bg, s->s, s->bs, s->A, s->c_eps, s->c_noise, s->x, s->eps, s->tvec, s->t_dev, s->ws};
+    void *bufs[] = {s->g, s->bg, s->s, s->bs, s->A, s->c_eps, s->c_noise, s->x, s->eps, s->tvec, s->t_dev, s->key_dev, s->ws};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete s;

@@ -137,7 +137,13 @@ class GenerativeLevyProcess:
         cfg.clamp_a = -1.0 if clamp_a is None else float(clamp_a)
         cfg.clamp_eps = -1.0 if clamp_eps is None else float(clamp_eps)
         cfg.flags, cfg.dlim_eta, cfg.seed = flags, float(eta), seed
-        cfg.sample_offset, cfg.use_graph = self.sample_offset, int(self.use_graph and self.rng == 'philox')
+        gs = 0
+        if self.use_graph and self.rng == 'philox':
+            # steps per captured graph: 1 for the UNets (~150 launches, ms-long steps), 33 for the
+            # launch-bound MLP (4 launches per step) unless the caller asked for a specific count
+            gs = self.use_graph if isinstance(self.use_graph, int) and not isinstance(self.use_graph, bool) else (
+                1 if handles['unet'] else 33)
+        cfg.sample_offset, cfg.use_graph = self.sample_offset, gs
         sched = self.dlpm.host_schedule
         cfg.g, cfg.bg, cfg.s, cfg.bs = (v.data_ptr() for v in sched)
         h = C.c_void_p()

@@ -128,6 +128,8 @@ typedef struct dlpm_update_args {
     float alpha;
     uint64_t seed;            /* Philox key                                                      */
     int64_t sample_offset;    /* global index of sample 0 of this shard                          */
+    const uint64_t *key_dev;  /* optional device pair {seed, sample_offset} overriding the two fields
+                                 above: lets a captured graph be replayed under a new key          */
 } dlpm_update_args;
 
 /* One reverse step on the whole batch:
@@ -255,14 +257,16 @@ typedef struct dlpm_sampler_config {
     float dlim_eta;
     uint64_t seed;
     int64_t sample_offset;      /* global index of this shard's first sample */
-    int32_t use_graph;          /* 1: capture one step into a hipGraph and replay it */
+    int32_t use_graph;          /* > 0: capture this many consecutive reverse steps into one hipGraph and
+                                   replay it (1 suits the UNets; launch-bound nets want tens)          */
     const float *g, *bg, *s, *bs; /* host schedule [T] each, or all NULL = dlpm_schedule_f32(T, alpha) */
 } dlpm_sampler_config;
 
 typedef struct dlpm_sampler dlpm_sampler;
 
 int dlpm_sampler_create(const dlpm_sampler_config *cfg, dlpm_sampler **out);
-/* New Philox key / shard offset for the next begin() (drops the captured graph, keeps the buffers). */
+/* New Philox key / shard offset for the next begin(); the captured graph stays valid (the key lives
+ * in device memory). */
 int dlpm_sampler_reseed(dlpm_sampler *s, uint64_t seed, int64_t sample_offset);
 /* Draw A (Philox), build the tables, draw x_T; sets t = T-1.  p_sample_loop_progressive prologue:
  * GenerativeLevyProcess.py:306-315. */
