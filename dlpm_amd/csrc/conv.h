@@ -20,6 +20,10 @@ struct ConvLaunch {
     int Cout = 0;
     int in_nchw = 0, out_nchw = 0;  // boundary layouts
     int abl = 0;                    // timing-only ablation bits (DLPM_ABL env; results are wrong when set)
+    // Optional fused GroupNorm statistics of the OUTPUT: per (image, 128-pixel tile, channel) the
+    // pair (mean, centred sum of squares) over the tile's pixels, written by the MFMA kernels'
+    // epilogue when the tile lies inside one image (Hout*Wout % 128 == 0).  [B][HW/128][Cout] float2.
+    float2 *stats_out = nullptr;
 };
 
 // true when the MFMA implicit-GEMM kernel covers this shape
@@ -41,6 +45,11 @@ int relayout_weight(const float *oihw_dev, float *dst_dev, int Cout, int Cin, in
 int launch_gn_coeffs(const float *src0, const float *src1, int C0, int C1, int B, int HW, int groups,
                      const float *gamma, const float *beta, const float *ss, int64_t ss_stride, int64_t ss_offset,
                      float *coefA, float *coefB, hipStream_t st);
+// GroupNorm coefficients from per-tile channel statistics (see ConvLaunch::stats_out) instead of the
+// activations: st0/st1 = statistics of the two concat sources, nt = tiles per image.
+int launch_gn_coeffs_from_stats(const float2 *st0, const float2 *st1, int C0, int C1, int B, int nt, int HW, int groups,
+                                const float *gamma, const float *beta, const float *ss, int64_t ss_stride,
+                                int64_t ss_offset, float *coefA, float *coefB, hipStream_t st);
 int launch_attention(const float *qkv, float *out, int B, int T, int C, int heads, hipStream_t st);
 int launch_timestep_embedding(const float *t, float *emb, int64_t B, int dim, hipStream_t st);
 

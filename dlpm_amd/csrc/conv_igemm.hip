@@ -38,8 +38,13 @@ constexpr int LDS_LD = 36;  // padded row length (floats)
 template <int BN, int WAVES_M, int WAVES_N, int RM, int RN>
 __device__ __forceinline__ void epilogue_rows(const ConvLaunch &p, floatx16 (&acc)[RM][RN], float *lds, int64_t m0, int n0,
                                               int64_t M, int tid, int wm, int wn, int l31, int kh) {
-    constexpr int LD = BN + 4, PR = RM * 32, C4 = BN / 4;
+    constexpr int LD = BN + 4, PR = RM * 32, C4 = BN / 4, RG = 256 / C4;  // RG row groups share a column quad
     const int R1 = p.Cout - p.R0;
+    // fused GroupNorm statistics of the output (tile inside one image only): every thread keeps the
+    // same 4 channels across the whole epilogue, so it carries shifted sums for them in registers
+    const bool do_stats = p.stats_out != nullptr;
+    float4 K = make_float4(0.f, 0.f, 0.f, 0.f), s1 = K, s2 = K;
+    int cnt = 0;
     for (int ph = 0; ph < WAVES_M; ph++) {
         if (wm == ph) {
 #pragma unroll
@@ -66,11 +71,45 @@ __device__ __forceinline__ void epilogue_rows(const ConvLaunch &p, floatx16 (&ac
                                                 : *reinterpret_cast<const float4 *>(p.res1 + m * R1 + (n - p.R0));
                     v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
                 }
+                if (do_stats) {
+                    if (cnt == 0) K = v;  // pivot = this thread's first value per channel
+                    float d;
+                    d = v.x - K.x; s1.x += d; s2.x = fmaf(d, d, s2.x);
+                    d = v.y - K.y; s1.y += d; s2.y = fmaf(d, d, s2.y);
+                    d = v.z - K.z; s1.z += d; s2.z = fmaf(d, d, s2.z);
+                    d = v.w - K.w; s1.w += d; s2.w = fmaf(d, d, s2.w);
+                    cnt++;
+                }
                 if ((p.abl & 1) && v.x == v.x) continue;  // timing ablation only
                 *reinterpret_cast<float4 *>(p.out + m * p.Cout + n) = v;
             }
         }
         __syncthreads();
+    }
+    if (do_stats) {
+        // per-thread (mean, M2) over its cnt rows -> LDS [RG][BN] -> threads < BN merge the RG
+        // partials of one channel with Chan's update and write the tile's pair
+        float2 *part = reinterpret_cast<float2 *>(lds);  // the row image is dead now
+        const int c4 = tid % C4, rg = tid / C4;
+        const float fc = (float)(cnt > 0 ? cnt : 1);
+        const float mx = s1.x / fc, my = s1.y / fc, mz = s1.z / fc, mw = s1.w / fc;
+        part[rg * BN + c4 * 4 + 0] = make_float2(K.x + mx, fmaxf(s2.x - s1.x * mx, 0.f));
+        part[rg * BN + c4 * 4 + 1] = make_float2(K.y + my, fmaxf(s2.y - s1.y * my, 0.f));
+        part[rg * BN + c4 * 4 + 2] = make_float2(K.z + mz, fmaxf(s2.z - s1.z * mz, 0.f));
+        part[rg * BN + c4 * 4 + 3] = make_float2(K.w + mw, fmaxf(s2.w - s1.w * mw, 0.f));
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.Cout) {
+            const float npart = (float)(BM / RG);  // rows behind each partial (tiles are full here)
+            float mean = part[tid].x, M2 = part[tid].y, na = npart;
+            for (int g = 1; g < RG; g++) {
+                const float2 q = part[g * BN + tid];
+                const float d = q.x - mean, N = na + npart;
+                mean += d * (npart / N);
+                M2 += q.y + d * d * (na * npart / N);
+                na = N;
+            }
+            p.stats_out[(m0 / BM) * p.Cout + n0 + tid] = make_float2(mean, M2);
+        }
     }
 }
 

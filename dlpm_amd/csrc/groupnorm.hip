@@ -173,7 +173,75 @@ __global__ void __launch_bounds__(512) k_gn_coeffs_v4(const float *__restrict__ 
     }
 }
 
+// Coefficients from the per-tile channel statistics the MFMA conv epilogues emit (ConvLaunch::
+// stats_out): the activation itself is never re-read, so GroupNorm costs O(B*C) instead of a full
+// 4 B/element pass.  Tiles, then channels of a group, are merged with Chan's parallel update.
+__global__ void __launch_bounds__(256) k_gn_coeffs_stats(const float2 *__restrict__ st0, const float2 *__restrict__ st1, int C0,
+                                                         int C1, int nt, int HW, int G, const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, const float *__restrict__ ss,
+                                                         int64_t ss_stride, int64_t ss_offset, float *__restrict__ coefA,
+                                                         float *__restrict__ coefB, float eps) {
+    extern __shared__ float sh[];
+    const int C = C0 + C1, cg = C / G;
+    float *cmean = sh, *cm2 = sh + C, *mean = cm2 + C, *rstd = mean + G;
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const float npt = (float)(HW / nt);  // pixels per tile
+    for (int c = tid; c < C; c += nthr) {
+        const float2 *sp = (c < C0) ? st0 + (int64_t)b * nt * C0 + c : st1 + (int64_t)b * nt * C1 + (c - C0);
+        const int ld = (c < C0) ? C0 : C1;
+        float m = sp[0].x, M2 = sp[0].y, na = npt;
+        for (int k = 1; k < nt; k++) {
+            const float2 q = sp[(int64_t)k * ld];
+            const float d = q.x - m, N = na + npt;
+            m += d * (npt / N);
+            M2 += q.y + d * d * (na * npt / N);
+            na = N;
+        }
+        cmean[c] = m;
+        cm2[c] = M2;
+    }
+    __syncthreads();
+    const float fn = (float)HW;
+    for (int g = tid; g < G; g += nthr) {
+        float m = 0.f;
+        for (int c = g * cg; c < (g + 1) * cg; c++) m += cmean[c];
+        m /= (float)cg;
+        float M2 = 0.f;
+        for (int c = g * cg; c < (g + 1) * cg; c++) {
+            const float d = cmean[c] - m;
+            M2 += cm2[c] + fn * d * d;
+        }
+        mean[g] = m;
+        rstd[g] = 1.0f / sqrtf(M2 / (fn * (float)cg) + eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += nthr) {
+        const int g = c / cg;
+        float a = rstd[g] * gamma[c];
+        float bb = beta[c] - mean[g] * a;
+        if (ss) {
+            const float sc = 1.0f + ss[(int64_t)b * ss_stride + ss_offset + c];
+            const float sft = ss[(int64_t)b * ss_stride + ss_offset + C + c];
+            a = a * sc;
+            bb = fmaf(bb, sc, sft);
+        }
+        coefA[(int64_t)b * C + c] = a;
+        coefB[(int64_t)b * C + c] = bb;
+    }
+}
+
 }  // namespace
+
+int launch_gn_coeffs_from_stats(const float2 *st0, const float2 *st1, int C0, int C1, int B, int nt, int HW, int groups,
+                                const float *gamma, const float *beta, const float *ss, int64_t ss_stride,
+                                int64_t ss_offset, float *coefA, float *coefB, hipStream_t st) {
+    const int C = C0 + C1;
+    ProfScope ps("groupnorm_from_stats", 0.0, 8.0 * (double)B * nt * C + 8.0 * B * C, st);
+    k_gn_coeffs_stats<<<(unsigned)B, 256, (size_t)(2 * C + 2 * groups) * sizeof(float), st>>>(
+        st0, st1, C0, C1, nt, HW, groups, gamma, beta, ss, ss_stride, ss_offset, coefA, coefB, 1e-5f);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
 
 int launch_gn_coeffs(const float *src0, const float *src1, int C0, int C1, int B, int HW, int groups, const float *gamma,
                      const float *beta, const float *ss, int64_t ss_stride, int64_t ss_offset, float *coefA,

@@ -14,6 +14,7 @@
 //   bias, residual add            -> conv epilogue
 //   22 per-ResBlock Linear(4mc -> 2C) -> one GEMM against the row-concatenated weights
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -55,6 +56,7 @@ struct Layer {
 struct Tensor4 {
     float *p = nullptr;
     int C = 0, H = 0, W = 0;
+    float2 *stats = nullptr;  // per (image, 128-pixel tile, channel) (mean, M2) emitted by the producing conv, or null
 };
 
 struct Bump {
@@ -69,6 +71,29 @@ struct Bump {
         return r;
     }
 };
+
+// GroupNorm statistics can ride on the producing conv's epilogue when its 128-pixel tiles stay inside
+// one image and the conv runs on the MFMA kernels with the row epilogue
+bool can_emit_stats(const ConvW &c, int H, int W) {
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("DLPM_NO_GN_FUSION"); off = (e && e[0] == '1') ? 1 : 0; }
+    return !off && c.use_igemm && (H * W) % 128 == 0 && (c.cout & 3) == 0;
+}
+
+float2 *alloc_stats(Bump &ws, int B, int H, int W, int C) {
+    return reinterpret_cast<float2 *>(ws.alloc((int64_t)2 * B * (H * W / 128) * C));
+}
+
+// GroupNorm(+scale/shift) coefficients of the virtual concat [x0 | x1]
+int gn_any(Tensor4 x0, Tensor4 x1, int B, int groups, const float *gamma, const float *beta, const float *ss,
+           int64_t ss_stride, int64_t ss_offset, float *cA, float *cB, hipStream_t st) {
+    const int HW = x0.H * x0.W;
+    if (x0.stats && (x1.C == 0 || x1.stats))
+        return launch_gn_coeffs_from_stats(x0.stats, x1.stats, x0.C, x1.C, B, HW / 128, HW, groups, gamma, beta, ss, ss_stride,
+                                           ss_offset, cA, cB, st);
+    return launch_gn_coeffs(x0.p, x1.p, x0.C, x1.C, B, HW, groups, gamma, beta, ss, ss_stride, ss_offset, cA, cB, st);
+}
+
 
 }  // namespace
 
@@ -247,24 +272,27 @@ int run_res(Ctx &cx, const Layer &L, Tensor4 x0, Tensor4 x1, Tensor4 *out) {
     const int B = cx.B, H = x0.H, W = x0.W, HW = H * W;
     const int C0 = x0.C, C1 = x1.C, Cin = C0 + C1, Co = L.cout;
     float *cA1 = cx.ws.alloc((int64_t)B * Cin), *cB1 = cx.ws.alloc((int64_t)B * Cin);
-    float *h1 = cx.ws.alloc((int64_t)B * HW * Co);
+    Tensor4 h1;
+    h1.C = Co; h1.H = H; h1.W = W;
+    h1.p = cx.ws.alloc((int64_t)B * HW * Co);
+    if (can_emit_stats(L.c1, H, W)) h1.stats = alloc_stats(cx.ws, B, H, W, Co);
     float *cA2 = cx.ws.alloc((int64_t)B * Co), *cB2 = cx.ws.alloc((int64_t)B * Co);
     float *sk = L.has_skip ? cx.ws.alloc((int64_t)B * HW * Co) : nullptr;
     float *o = cx.ws.alloc((int64_t)B * HW * Co);
     out->p = o; out->C = Co; out->H = H; out->W = W;
+    out->stats = can_emit_stats(L.c2, H, W) ? alloc_stats(cx.ws, B, H, W, Co) : nullptr;
     if (cx.dry()) return DLPM_OK;
     const int G1 = Cin < 32 ? Cin : 32, G2 = Co < 32 ? Co : 32;
-    TRY(launch_gn_coeffs(x0.p, x1.p, C0, C1, B, HW, G1, u->params[L.p_gn1_w].dev, u->params[L.p_gn1_b].dev, nullptr, 0, 0,
-                         cA1, cB1, cx.st));
+    TRY(gn_any(x0, x1, B, G1, u->params[L.p_gn1_w].dev, u->params[L.p_gn1_b].dev, nullptr, 0, 0, cA1, cB1, cx.st));
     ConvLaunch a;
     a.src0 = x0.p; a.src1 = x1.p; a.C0 = C0; a.C1 = C1; a.B = B; a.Hin = a.Hout = H; a.Win = a.Wout = W;
-    a.bias = u->params[L.c1.p_b].dev; a.coefA = cA1; a.coefB = cB1; a.act_silu = 1; a.out = h1;
+    a.bias = u->params[L.c1.p_b].dev; a.coefA = cA1; a.coefB = cB1; a.act_silu = 1; a.out = h1.p; a.stats_out = h1.stats;
     TRY(run_conv(L.c1, a, cx.st));
-    TRY(launch_gn_coeffs(h1, nullptr, Co, 0, B, HW, G2, u->params[L.p_gn2_w].dev, u->params[L.p_gn2_b].dev, cx.embout,
-                         u->emb_total, L.emb_off, cA2, cB2, cx.st));
+    TRY(gn_any(h1, Tensor4(), B, G2, u->params[L.p_gn2_w].dev, u->params[L.p_gn2_b].dev, cx.embout, u->emb_total, L.emb_off,
+               cA2, cB2, cx.st));
     ConvLaunch b;
-    b.src0 = h1; b.C0 = Co; b.B = B; b.Hin = b.Hout = H; b.Win = b.Wout = W;
-    b.bias = u->params[L.c2.p_b].dev; b.coefA = cA2; b.coefB = cB2; b.act_silu = 1; b.out = o;
+    b.src0 = h1.p; b.C0 = Co; b.B = B; b.Hin = b.Hout = H; b.Win = b.Wout = W;
+    b.bias = u->params[L.c2.p_b].dev; b.coefA = cA2; b.coefB = cB2; b.act_silu = 1; b.out = o; b.stats_out = out->stats;
     if (L.has_skip) {
         ConvLaunch s;
         s.src0 = x0.p; s.src1 = x1.p; s.C0 = C0; s.C1 = C1; s.B = B; s.Hin = s.Hout = H; s.Win = s.Wout = W;
@@ -284,11 +312,13 @@ int run_attn(Ctx &cx, const Layer &L, Tensor4 x, Tensor4 *out) {
     float *qkv = cx.ws.alloc((int64_t)B * T * 3 * C);
     float *av = cx.ws.alloc((int64_t)B * T * C);
     float *o = cx.ws.alloc((int64_t)B * T * C);
+    const Tensor4 xin = x;
     *out = x;
     out->p = o;
+    out->stats = can_emit_stats(L.c2, x.H, x.W) ? alloc_stats(cx.ws, B, x.H, x.W, C) : nullptr;
     if (cx.dry()) return DLPM_OK;
-    TRY(launch_gn_coeffs(x.p, nullptr, C, 0, B, T, C < 32 ? C : 32, u->params[L.p_gn1_w].dev, u->params[L.p_gn1_b].dev,
-                         nullptr, 0, 0, cA, cB, cx.st));
+    TRY(gn_any(xin, Tensor4(), B, C < 32 ? C : 32, u->params[L.p_gn1_w].dev, u->params[L.p_gn1_b].dev, nullptr, 0, 0, cA, cB,
+               cx.st));
     ConvLaunch q;
     q.src0 = x.p; q.C0 = C; q.B = B; q.Hin = q.Hout = x.H; q.Win = q.Wout = x.W;
     q.bias = u->params[L.c1.p_b].dev; q.coefA = cA; q.coefB = cB; q.out = qkv;
@@ -296,7 +326,7 @@ int run_attn(Ctx &cx, const Layer &L, Tensor4 x, Tensor4 *out) {
     TRY(launch_attention(qkv, av, B, T, C, u->cfg.num_heads, cx.st));
     ConvLaunch p;
     p.src0 = av; p.C0 = C; p.B = B; p.Hin = p.Hout = x.H; p.Win = p.Wout = x.W;
-    p.bias = u->params[L.c2.p_b].dev; p.res0 = x.p; p.R0 = C; p.out = o;
+    p.bias = u->params[L.c2.p_b].dev; p.res0 = x.p; p.R0 = C; p.out = o; p.stats_out = out->stats;
     return run_conv(L.c2, p, cx.st);
 }
 
@@ -333,11 +363,12 @@ int run_seq(Ctx &cx, const std::vector<Layer> &seq, Tensor4 x0, Tensor4 x1, cons
                 o.H = up ? h.H * 2 : (h.H - 1) / 2 + 1;
                 o.W = up ? h.W * 2 : (h.W - 1) / 2 + 1;
                 o.p = cx.ws.alloc((int64_t)B * o.H * o.W * o.C);
+                if (can_emit_stats(L.c1, o.H, o.W)) o.stats = alloc_stats(cx.ws, B, o.H, o.W, o.C);
                 if (!cx.dry()) {
                     ConvLaunch a;
                     a.src0 = h.p; a.C0 = h.C; a.B = B; a.Hin = h.H; a.Win = h.W; a.Hout = o.H; a.Wout = o.W;
                     a.stride = up ? 1 : 2; a.ups = up ? 1 : 0;
-                    a.bias = u->params[L.c1.p_b].dev; a.out = o.p;
+                    a.bias = u->params[L.c1.p_b].dev; a.out = o.p; a.stats_out = o.stats;
                     TRY(run_conv(L.c1, a, cx.st));
                 }
                 break;
@@ -387,8 +418,8 @@ int walk(dlpm_unet *u, Ctx &cx, const float *x, const float *t, float *eps) {
     }
     float *cA = cx.ws.alloc((int64_t)B * h.C), *cB = cx.ws.alloc((int64_t)B * h.C);
     if (!cx.dry()) {
-        TRY(launch_gn_coeffs(h.p, nullptr, h.C, 0, B, h.H * h.W, h.C < 32 ? h.C : 32, u->params[u->p_head_gn_w].dev,
-                             u->params[u->p_head_gn_b].dev, nullptr, 0, 0, cA, cB, cx.st));
+        TRY(gn_any(h, Tensor4(), B, h.C < 32 ? h.C : 32, u->params[u->p_head_gn_w].dev, u->params[u->p_head_gn_b].dev, nullptr,
+                   0, 0, cA, cB, cx.st));
         ConvLaunch a;
         a.src0 = h.p; a.C0 = h.C; a.B = B; a.Hin = a.Hout = h.H; a.Win = a.Wout = h.W;
         a.bias = u->params[u->head.p_b].dev; a.coefA = cA; a.coefB = cB; a.act_silu = 1; a.out = eps; a.out_nchw = 1;
