@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th, int 
             const bool last_tap = tap == 8, more = (chunk + 1 < nch);
             // one UNCONDITIONAL weight prefetch per tap (harmlessly redundant on the very last step):
             // two call sites would make hipcc merge their results with copies behind a vmcnt(0)
-            load_w(last_tap ? min(chunk + 1, nch - 1) : chunk, last_tap ? 0 : tap + 1);
+            if (!(p.abl & 32)) load_w(last_tap ? min(chunk + 1, nch - 1) : chunk, last_tap ? 0 : tap + 1);
             if (last_tap && more) load_halo(chunk + 1);
 
             const int ky = tap / 3, kx = tap - ky * 3;
@@ -452,13 +452,13 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th, int 
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                     }
             }
-            if (!last_tap || more) store_w(buf ^ 1);
+            if ((!last_tap || more) && !(p.abl & 8)) store_w(buf ^ 1);
             if (last_tap && more) {
                 store_coef();     // (the previous chunk's coefficients were consumed before its first tap)
                 __syncthreads();  // every wave has finished reading this chunk's halo; coefficients visible
                 store_halo();
             }
-            __syncthreads();
+            if (!(p.abl & 16)) __syncthreads();
         }
     }
 
