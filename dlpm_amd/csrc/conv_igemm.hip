@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th, int 
     __syncthreads();
 
     int s = 0;
-    for (int chunk = 0; chunk < nch; chunk++) {
+    for (int chunk = 0; chunk < ((p.abl & 64) ? 0 : nch); chunk++) {
 #pragma unroll 1
         for (int tap = 0; tap < 9; tap++, s++) {
             const int buf = s & 1;
@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th, int 
         }
     }
 
-    if ((p.Cout & 3) == 0 && (p.R0 & 3) == 0) {
+    if (!p.out_nchw && (p.Cout & 3) == 0 && (p.R0 & 3) == 0) {
         epilogue_rows<BN, WAVES_M, WAVES_N, RM, RN>(p, acc, hsm, m0, n0, M, tid, wm, wn, l31, kh);
         return;
     }
@@ -481,7 +481,12 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th, int 
                 if (m >= M) continue;
                 float v = acc[i][j][r] + bias;
                 if (p.res0) v += (n < p.R0) ? p.res0[m * p.R0 + n] : p.res1[m * R1 + (n - p.R0)];
-                p.out[m * p.Cout + n] = v;
+                if (p.out_nchw) {
+                    const int64_t bb = m / HWo;
+                    p.out[(bb * p.Cout + n) * HWo + (m - bb * HWo)] = v;
+                } else {
+                    p.out[m * p.Cout + n] = v;
+                }
             }
         }
     }
@@ -548,7 +553,7 @@ bool igemm_supported(const ConvLaunch &c) {
 static bool halo_ok(const ConvLaunch &c, int *th, int *nimg) {
     static int disabled = -1;
     if (disabled < 0) { const char *e = getenv("DLPM_NO_HALO"); disabled = (e && e[0] == '1') ? 1 : 0; }
-    if (disabled || c.ks != 3 || c.stride != 1 || c.ups || c.out_nchw) return false;
+    if (disabled || c.ks != 3 || c.stride != 1 || c.ups) return false;
     const int W = c.Wout, HW = c.Hout * c.Wout;
     if (W < 4 || W > 64 || BM % W != 0) return false;
     if (HW >= BM) {            // th full rows of one image
