@@ -31,6 +31,7 @@ WORKLOADS = {
     # name: (config, per-GPU batch, T, alpha)
     'cifar10_unet_b1024_T1000': ('cifar10', 1024, 1000, 1.7),
     'mnist_unet_b256_T1000': ('mnist', 256, 1000, 1.7),
+    'celeba64_unet_b256_T1000': ('celeba64', 256, 1000, 1.8),   # per-GPU shard of BASELINE configs[4]
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 PEAK_HBM_GBS = 8000.0

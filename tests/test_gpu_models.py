@@ -109,3 +109,18 @@ def test_error_paths():
         net(torch.zeros(1, 3, 15, 15, device=DEV), torch.zeros(1, device=DEV))
     with pytest.raises(NotImplementedError):
         dlpm_amd.UNetModel(3, 32, 3, 1, [2], channel_mult=[1, 2], num_heads=4, use_scale_shift_norm=False)
+
+
+def test_unet_64x64_against_oracle():
+    """BASELINE configs[4] shape (64x64, attention at 16x16 = 256 tokens and 8x8), narrow width to keep
+    the CPU oracle fast: mc=32, same block structure as the CIFAR net."""
+    torch.manual_seed(11)
+    net = dlpm_amd.UNetModel(3, 32, 3, 2, [4, 8, 16], channel_mult=[1, 2, 2, 2], num_heads=4, use_scale_shift_norm=True)
+    dlpm_amd.rerandomize_(net, 12)
+    g = torch.Generator().manual_seed(13)
+    x, t = torch.randn(2, 3, 64, 64, generator=g), torch.rand(2, generator=g)
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        want = nets.unet_forward(sd, x, t, 4)
+    got = net(x.to(DEV), t.to(DEV)).cpu()
+    assert (got - want).abs().max().item() < 1e-4

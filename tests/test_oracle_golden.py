@@ -195,3 +195,23 @@ def test_layers():
 
 
 # F6 UNets + F8 need the build's seed-identical weight container: tests/test_host_mirror.py
+
+
+def test_unet_trajectory_same_seeds():
+    """The tiny UNet inside a full T=100 sample() on identical seeds (oracle vs the reference run)."""
+    from test_host_mirror import build_unet
+    from dlpm_amd.weights import state_digest
+    f = golden('f5_traj_unet_tiny')
+    net, _ = build_unet('tiny')
+    assert state_digest(net) == bytes(f['digest']).hex()
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    T, alpha, ca, ce = f['meta']
+    with torch.no_grad():
+        x, hist = sampler.sample(lambda x, t: nets.unet_forward(sd, x, t, 4), [int(v) for v in f['shape']], int(T),
+                                 float(alpha), sampler.Streams(0, 0), clamp_a=float(ca), clamp_eps=float(ce),
+                                 get_sample_history=True)
+    want = f['history_every10']
+    got = hist[::10].numpy()
+    scale = np.abs(want).max(axis=(1, 2, 3, 4), keepdims=True) + 1e-6
+    assert np.max(np.abs(got - want) / scale) < 2e-5
+    assert np.abs(x.numpy() - f['final']).max() < 1e-4 * max(1.0, np.abs(f['final']).max())

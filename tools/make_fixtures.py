@@ -282,6 +282,22 @@ def f5_trajectories():
     run_traj('f5_traj_mlp_toy_b32', mlp, [32, 1, 2], 25, 1.7, extra=None)
 
 
+def f5_unet_trajectory():
+    # the real UNet in the loop on identical seeds: tiny architecture (weights from seeds, see f6), full
+    # sample() of the reference; only every 10th state is kept to bound the file size
+    torch.manual_seed(1234)
+    net = make_unet(3, 32, [1, 2], [2], 4, 1).eval()
+    rerandomize(net, 4321)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    T, alpha, shape = 100, 1.7, [2, 3, 16, 16]
+    meth = GenerativeLevyProcess(alpha=alpha, device='cpu', reverse_steps=T, rescale_timesteps=True)
+    x, hist = meth.sample({'default': net}, shape, T, clamp_a=10, clamp_eps=50, get_sample_history=True)
+    save('f5_traj_unet_tiny', final=x, history_every10=hist[::10], A=meth.dlpm.A[:, :, 0, 0, 0],
+         meta=np.array([T, alpha, 10, 50]), shape=np.array(shape),
+         digest=np.frombuffer(bytes.fromhex(weight_digest(net)), dtype=np.uint8))
+
+
 def f6_models():
     # ---- MLP forward
     p = yaml.safe_load(open(os.path.join(REF, 'dlpm/configs/2d_data.yml')))
@@ -441,8 +457,8 @@ def f8_generation_manager():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8']
-    table = dict(f1=f1_schedule, f2=f2_noise, f3=f3_tables, f4=f4_single_step, f5=f5_trajectories,
+    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f5u', 'f6', 'f7', 'f8']
+    table = dict(f1=f1_schedule, f2=f2_noise, f3=f3_tables, f4=f4_single_step, f5=f5_trajectories, f5u=f5_unet_trajectory,
                  f6=f6_models, f7=f7_layers, f8=f8_generation_manager)
     with torch.no_grad():
         for w in which:
