@@ -33,6 +33,14 @@ WORKLOADS = {
     'mnist_unet_b256_T1000': ('mnist', 256, 1000, 1.7),
     'celeba64_unet_b256_T1000': ('celeba64', 256, 1000, 1.8),   # per-GPU shard of BASELINE configs[4]
 }
+METRIC = {
+    'cifar10': 'samples/sec at T=1000 (CIFAR-10 32x32, alpha=1.7)',
+    'mnist': 'samples/sec at T=1000 (MNIST 32x32, alpha=1.7) [parity config, not the headline]',
+    'celeba64': 'samples/sec at T=1000 (CelebA 64x64, alpha=1.8) [builder-defined net, not the headline]',
+}
+# HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc runs,
+# FETCH_SIZE doubled per the gfx950 guide): profiles/r01/pmc_hbm_traffic_*.txt
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {'k_conv3x3_halo<128,2,2,2,2>': (0.6579 + 0.2044) * 1e9}
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 PEAK_HBM_GBS = 8000.0
 
@@ -175,7 +183,9 @@ def main():
             ach = c['flops'] / (c['ms'] * 1e-3) / 1e12
             roofline = dict(kernel='k_conv3x3_halo<128,2,2,2,2> (3x3 stride-1 conv, fp32 MFMA 32x32x2, fused GN+SiLU/bias/residual)',
                             bound='mfma', achieved=round(ach, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                            frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                            frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                            traffic=(PMC_TRAFFIC_BYTES_PER_LAUNCH['k_conv3x3_halo<128,2,2,2,2>'] if cfg_name == 'cifar10' and B == 1024 else None),
+                            traffic_note='HBM bytes per launch (mean over the 44 launches of a step) from committed rocprofv3 PMC passes, profiles/r01/pmc_hbm_traffic_v3.txt; algorithmic bytes per launch = %.4g' % (c['bytes'] / c['launches']),
                             launches_per_step=c['launches'] // nprof, avg_launch_ms=round(c['ms'] / c['launches'], 5),
                             flops_per_launch_avg=c['flops'] / c['launches'],
                             share_of_step_ms=round(c['ms'] / nprof, 3),
@@ -195,7 +205,7 @@ def main():
     if rank == 0:
         step_tflops = flops_per_sample * B * world / (ms_per_step * 1e-3) / 1e12
         out = {
-            'metric': 'samples/sec at T=1000 (CIFAR-10 32x32, alpha=1.7)', 'value': round(value, 4),
+            'metric': METRIC[cfg_name], 'value': round(value, 4),
             'unit': 'samples/s', 'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(ms_per_step, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': args.workload, 'state_shape_per_gpu': shape, 'global_batch': B * world,
