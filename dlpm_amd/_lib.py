@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libdlpm_amd.so')
 
 vp, i32, i64, u32, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
 
-UPD_DLIM, UPD_CLIP, UPD_ADVANCE = 1, 2, 4
+UPD_DLIM, UPD_CLIP, UPD_ADVANCE, SMP_NO_FUSED_MLP = 1, 2, 4, 8
 
 
 class MT19937(C.Structure):
@@ -76,6 +76,7 @@ SIGNATURES = {
     'dlpm_mlp_set_param': (C.c_int, [vp, C.c_char_p, vp, i64]),
     'dlpm_mlp_finalize': (C.c_int, [vp]),
     'dlpm_mlp_forward': (C.c_int, [vp, vp, vp, vp, i64, vp]),
+    'dlpm_mlp_sample_steps_f32': (C.c_int, [vp, vp, vp, vp, vp, i32, i64, i32, i32, u64, i64, vp, vp]),
     'dlpm_mlp_destroy': (None, [vp]),
     'dlpm_conv2d_f32': (C.c_int, [C.POINTER(ConvArgs), vp, vp]),
     'dlpm_groupnorm_coeffs_f32': (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i64, i64, vp, vp, vp]),

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "common.h"
+#include "philox.h"
 
 using namespace dlpm;
 
@@ -152,6 +153,127 @@ __global__ void __launch_bounds__(64) k_mlp_forward(const float *__restrict__ P,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The whole reverse loop for the toy net in ONE launch (BASELINE configs[0] is launch-bound: 4
+// kernels of a few microseconds per step otherwise).  Samples are independent, so one wavefront
+// owns one sample for all its steps: lanes = hidden units, state x (F <= 4 features) replicated in
+// registers, Linear layers as 16 iterations of {one float4 weight load per lane, one 16-byte LDS
+// broadcast of 4 activations, 4 FMAs}.  Everything that depends only on the step index -- the time
+// embedding and every block's t_proj output -- comes from a [T][blocks][64] table built once.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_mlp_tp_table(const float *__restrict__ P, MlpOffsets o, float *__restrict__ tp, int T,
+                                                     int TE, int nblk) {
+    __shared__ float e0[NU], e1[NU];
+    const int lane = threadIdx.x, ti = blockIdx.x;
+    const float tv = __fmul_rn((float)ti, 1.0f / (float)T);  // t.float() * (1/T), GenerativeLevyProcess.py:92-96
+    if (lane < TE) e0[lane] = silu(fmaf(P[o.te_w + lane], tv, P[o.te_b + lane]));
+    __syncthreads();
+    if (lane < TE) {
+        float a = P[o.tm_b + lane];
+        for (int k = 0; k < TE; k++) a = fmaf(P[o.tm_w + k * TE + lane], e0[k], a);
+        e1[lane] = silu(a);
+    }
+    __syncthreads();
+    for (int bi = 0; bi < nblk; bi++) {
+        const float *Q = P + o.blk0 + (int64_t)bi * o.blk_stride;
+        float a = Q[o.b_tb + lane];
+        for (int k = 0; k < TE; k++) a = fmaf(Q[o.b_tw + k * NU + lane], e1[k], a);
+        tp[((int64_t)ti * nblk + bi) * NU + lane] = silu(a);
+    }
+}
+
+// acc += sum_k W[lane][k] act[k] with W stored as float4 per (k/4, lane)
+__device__ __forceinline__ float matvec_q4(const float4 *__restrict__ Wq, const float *act, int lane, float acc) {
+#pragma unroll 4
+    for (int kq = 0; kq < NU / 4; kq++) {
+        const float4 w = Wq[kq * NU + lane];
+        const float4 a = *reinterpret_cast<const float4 *>(act + 4 * kq);
+        acc = fmaf(w.x, a.x, acc);
+        acc = fmaf(w.y, a.y, acc);
+        acc = fmaf(w.z, a.z, acc);
+        acc = fmaf(w.w, a.w, acc);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ float layer_norm1(float v, float gam, float bet) {
+    const float mean = wave_sum(v) * (1.0f / NU);
+    const float d = v - mean;
+    const float var = wave_sum(d * d) * (1.0f / NU);
+    return d * (1.0f / sqrtf(var + 1e-5f)) * gam + bet;
+}
+
+struct MlpLoopArgs {
+    const float *P;        // packed parameters ([k][unit] layout)
+    const float4 *Q4;      // the 64x64 matrices of every block as float4 per (k/4, unit): [blk][2][16][64]
+    const float *tp;       // [T][nblk][64]
+    float *x;              // [B][F] state, updated in place
+    const float *c_eps, *c_noise, *g;   // [T,B], [T,B], [T]
+    int64_t B;
+    int F, T, nblk, t_start, nsteps;
+    const uint64_t *key_dev;
+    uint64_t seed;
+    int64_t sample_offset;
+};
+
+__global__ void __launch_bounds__(256) k_mlp_sample(MlpLoopArgs a, MlpOffsets o) {
+    __shared__ __attribute__((aligned(16))) float acts[4][NU];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * 4 + wv;
+    const bool live = b < a.B;
+    const int64_t bb = live ? b : a.B - 1;            // dead waves shadow the last sample (barriers stay uniform)
+    float *act = acts[wv];
+    const float *P = a.P;
+    const uint64_t seed = a.key_dev ? a.key_dev[0] : a.seed;
+    const uint64_t gidx = (uint64_t)((a.key_dev ? (int64_t)a.key_dev[1] : a.sample_offset) + bb);
+    float x[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < a.F; f++) x[f] = a.x[bb * a.F + f];
+    const float in_b = P[o.in_b + lane], in_g = P[o.in_g + lane], in_be = P[o.in_be + lane];
+    float in_w[4] = {0.f, 0.f, 0.f, 0.f}, out_w[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < a.F; f++) {
+        in_w[f] = P[o.in_w + f * NU + lane];
+        out_w[f] = P[o.out_w + f * NU + lane];
+    }
+    for (int step = 0; step < a.nsteps; step++) {
+        const int t = a.t_start - step;
+        // ---- model forward at step t
+        float h = in_b;
+        for (int f = 0; f < a.F; f++) h = fmaf(in_w[f], x[f], h);
+        h = silu(layer_norm1(h, in_g, in_be));
+        for (int bi = 0; bi < a.nblk; bi++) {
+            const float *Q = P + o.blk0 + (int64_t)bi * o.blk_stride;
+            const float4 *W1 = a.Q4 + ((int64_t)bi * 2 + 0) * (NU / 4) * NU, *W2 = W1 + (NU / 4) * NU;
+            act[lane] = h;
+            __syncthreads();
+            float y = matvec_q4(W1, act, lane, Q[o.b_b1 + lane]);
+            y = silu(layer_norm1(y, Q[o.b_g1 + lane], Q[o.b_be1 + lane])) + a.tp[((int64_t)t * a.nblk + bi) * NU + lane];
+            __syncthreads();
+            act[lane] = y;
+            __syncthreads();
+            float z = matvec_q4(W2, act, lane, Q[o.b_b2 + lane]);
+            z = layer_norm1(z, Q[o.b_g2 + lane], Q[o.b_be2 + lane]);
+            h = silu(z + h);
+            __syncthreads();
+        }
+        // ---- eps, then the DLPM update (dlpm.py:272-278, GenerativeLevyProcess.py:236-238)
+        const float g = a.g[t];
+        const float ce = a.c_eps[(int64_t)t * a.B + bb], cn = a.c_noise[(int64_t)t * a.B + bb];
+        float zz[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cn != 0.0f) {
+            const float4 z4 = philox_normal4(seed, gidx, 0u, 4u /* kPurposeStepZ */, (uint32_t)t);
+            zz[0] = z4.x; zz[1] = z4.y; zz[2] = z4.z; zz[3] = z4.w;
+        }
+        for (int f = 0; f < a.F; f++) {
+            const float eps = wave_sum(out_w[f] * h) + P[o.out_b + f];
+            const float m = __fdiv_rn(x[f] - __fmul_rn(ce, eps), g);
+            x[f] = __fadd_rn(m, __fmul_rn(cn, zz[f]));
+        }
+    }
+    if (live && lane == 0)
+        for (int f = 0; f < a.F; f++) a.x[b * a.F + f] = x[f];
+}
+
 }  // namespace
 
 struct dlpm_mlp {
@@ -160,6 +282,9 @@ struct dlpm_mlp {
     std::map<std::string, bool> seen;
     MlpOffsets off;
     float *dev = nullptr;
+    float4 *q4 = nullptr;      // float4-interleaved copies of the 64x64 matrices (k_mlp_sample)
+    float *tp = nullptr;       // [T][nblocks+1][64] step-only terms
+    int tp_T = 0;
     bool finalized = false;
 };
 
@@ -279,7 +404,55 @@ extern "C" int dlpm_mlp_finalize(dlpm_mlp *m) {
     }
     if (!m->dev) DLPM_HIP(hipMalloc(&m->dev, m->host.size() * sizeof(float)));
     DLPM_HIP(hipMemcpy(m->dev, m->host.data(), m->host.size() * sizeof(float), hipMemcpyHostToDevice));
+    {   // [blk][2][k/4][unit] float4 = (W[unit][4kq .. 4kq+3]); host holds W transposed: host[off + k*64 + unit]
+        const int nb = m->nblocks + 1;
+        std::vector<float> q((size_t)nb * 2 * NU * NU);
+        for (int bi = 0; bi < nb; bi++)
+            for (int which = 0; which < 2; which++) {
+                const int src = m->off.blk0 + bi * m->off.blk_stride + (which ? m->off.b_w2 : m->off.b_w1);
+                float *dst = q.data() + ((size_t)bi * 2 + which) * NU * NU;
+                for (int kq = 0; kq < NU / 4; kq++)
+                    for (int u = 0; u < NU; u++)
+                        for (int j = 0; j < 4; j++) dst[((size_t)kq * NU + u) * 4 + j] = m->host[src + (4 * kq + j) * NU + u];
+            }
+        if (!m->q4) DLPM_HIP(hipMalloc(&m->q4, q.size() * sizeof(float)));
+        DLPM_HIP(hipMemcpy(m->q4, q.data(), q.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    m->tp_T = 0;
     m->finalized = true;
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_mlp_sample_steps_f32(dlpm_mlp *m, float *x_dev, const float *c_eps_dev, const float *c_noise_dev,
+                                         const float *g_dev, int32_t T, int64_t B, int32_t t_start, int32_t nsteps,
+                                         uint64_t seed, int64_t sample_offset, const uint64_t *key_dev, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(m && x_dev && c_eps_dev && c_noise_dev && g_dev, "dlpm_mlp_sample_steps_f32: null argument");
+    DLPM_CHECK_ARG(T >= 2 && B > 0 && nsteps >= 0 && t_start < T && t_start - nsteps >= 0, "dlpm_mlp_sample_steps_f32: bad step range");
+    if (!m->finalized) {
+        set_error("dlpm_mlp_sample_steps_f32: call dlpm_mlp_finalize first");
+        return DLPM_ERR_STATE;
+    }
+    if (m->F > 4) {
+        set_error("dlpm_mlp_sample_steps_f32: the fused loop keeps the state in registers: nfeatures <= 4 (got %d)", m->F);
+        return DLPM_ERR_UNSUPPORTED;
+    }
+    if (nsteps == 0) return DLPM_OK;
+    hipStream_t st = as_stream(stream);
+    const int nb = m->nblocks + 1;
+    if (m->tp_T != T) {
+        if (m->tp) DLPM_HIP(hipFree(m->tp));
+        m->tp = nullptr;
+        DLPM_HIP(hipMalloc(&m->tp, (size_t)T * nb * NU * sizeof(float)));
+        k_mlp_tp_table<<<(unsigned)T, 64, 0, st>>>(m->dev, m->off, m->tp, T, m->TE, nb);
+        DLPM_LAUNCH_CHECK();
+        m->tp_T = T;
+    }
+    MlpLoopArgs a;
+    a.P = m->dev; a.Q4 = m->q4; a.tp = m->tp; a.x = x_dev; a.c_eps = c_eps_dev; a.c_noise = c_noise_dev; a.g = g_dev;
+    a.B = B; a.F = m->F; a.T = T; a.nblk = nb; a.t_start = t_start; a.nsteps = nsteps;
+    a.key_dev = key_dev; a.seed = seed; a.sample_offset = sample_offset;
+    k_mlp_sample<<<(unsigned)ceil_div(B, 4), 256, 0, st>>>(a, m->off);
+    DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }
 
@@ -299,5 +472,7 @@ extern "C" int dlpm_mlp_forward(dlpm_mlp *m, const float *x_dev, const float *t_
 extern "C" void dlpm_mlp_destroy(dlpm_mlp *m) {
     if (!m) return;
     if (m->dev) (void)hipFree(m->dev);
+    if (m->q4) (void)hipFree(m->q4);
+    if (m->tp) (void)hipFree(m->tp);
     delete m;
 }

@@ -218,6 +218,18 @@ extern "C" int dlpm_sampler_steps(dlpm_sampler *s, int32_t nsteps, dlpm_stream_t
     hipStream_t st = as_stream(stream);
     if (nsteps > s->t_host) nsteps = s->t_host;
     if (nsteps == 0) return DLPM_OK;
+    // toy net, plain stochastic DLPM steps: the whole run of steps is one launch (state in registers)
+    // (one wave per sample: best while the batch is latency-bound; beyond ~16k samples the 4-samples-per-wave
+    //  forward kernel + update kernel reuse the weights better)
+    if (s->cfg.mlp && !(s->cfg.flags & (DLPM_UPD_DLIM | DLPM_UPD_CLIP | DLPM_SMP_NO_FUSED_MLP)) && s->D <= 4 && s->cfg.B <= 16384 &&
+        !prof_enabled()) {
+        TRY(dlpm_mlp_sample_steps_f32(s->cfg.mlp, s->x, s->c_eps, s->c_noise, s->g, s->cfg.T, s->cfg.B, s->t_host, nsteps,
+                                      s->cfg.seed, s->cfg.sample_offset, s->key_dev, st));
+        s->t_host -= nsteps;
+        k_set_t<<<1, 64, 0, st>>>(s->t_dev, s->t_host);
+        DLPM_LAUNCH_CHECK();
+        return DLPM_OK;
+    }
     const bool graph = s->cfg.use_graph && !prof_enabled();
     if (!graph) return steps_on(s, nsteps, st, false);
     if (!s->own) {

@@ -76,7 +76,7 @@ class GenerativeLevyProcess:
     def __init__(self, alpha, device, reverse_steps, model_mean_type=ModelMeanType.EPSILON,
                  model_var_type=ModelVarType.FIXED, time_spacing='linear', rescale_timesteps=False, isotropic=True,
                  LIM=False, scale='scale_preserving', input_scaling=False,
-                 rng='philox', seed=0, sample_offset=0, use_graph=True, reference_streams=None):
+                 rng='philox', seed=0, sample_offset=0, use_graph=True, reference_streams=None, fused_mlp=True):
         assert (model_mean_type == ModelMeanType.EPSILON) and (model_var_type == ModelVarType.FIXED), \
             'Only epsilon prediction and fixed variance are supported for the moment'
         if LIM:
@@ -91,6 +91,7 @@ class GenerativeLevyProcess:
         self.LIM, self.input_scaling = LIM, input_scaling
         self.rng, self.seed, self.sample_offset, self.use_graph = rng, seed, sample_offset, use_graph
         self.reference_streams = reference_streams
+        self.fused_mlp = fused_mlp
         self.dlpm = DLPM(alpha, device, diffusion_steps=reverse_steps, time_spacing=time_spacing, isotropic=isotropic,
                          scale=scale)
         self._samplers = {}
@@ -122,7 +123,7 @@ class GenerativeLevyProcess:
             dims = (1, 1, shape[2])
             handles = dict(unet=None, mlp=model.native_handle())
         key = (id(model), handles['unet'].value if handles['unet'] else handles['mlp'].value, tuple(shape),
-               self.reverse_steps, self.alpha, flags, eta, clamp_a, clamp_eps, self.sample_offset, self.use_graph)
+               self.reverse_steps, self.alpha, flags, eta, clamp_a, clamp_eps, self.sample_offset, self.use_graph, self.fused_mlp)
         ent = self._samplers.get(key)
         if ent is not None:
             _lib.check(_lib.lib().dlpm_sampler_reseed(ent['h'], seed, self.sample_offset))
@@ -136,7 +137,8 @@ class GenerativeLevyProcess:
         cfg.alpha = float(self.alpha)
         cfg.clamp_a = -1.0 if clamp_a is None else float(clamp_a)
         cfg.clamp_eps = -1.0 if clamp_eps is None else float(clamp_eps)
-        cfg.flags, cfg.dlim_eta, cfg.seed = flags, float(eta), seed
+        cfg.flags = flags | (0 if self.fused_mlp else _lib.SMP_NO_FUSED_MLP)
+        cfg.dlim_eta, cfg.seed = float(eta), seed
         gs = 0
         if self.use_graph and self.rng == 'philox':
             # steps per captured graph: 1 for the UNets (~150 launches, ms-long steps), 33 for the

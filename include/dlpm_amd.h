@@ -110,7 +110,8 @@ int dlpm_coeff_tables_f32(const float *A_dev, const float *g_dev, const float *s
 enum dlpm_update_flags {
     DLPM_UPD_DLIM = 1,        /* deterministic / DLIM step instead of the stochastic DLPM step */
     DLPM_UPD_CLIP = 2,        /* clip_denoised: eps <- predict_eps(clamp(predict_xstart)) first  */
-    DLPM_UPD_ADVANCE = 4      /* after the update, thread 0 decrements *t_dev (graph replay)     */
+    DLPM_UPD_ADVANCE = 4,     /* after the update, thread 0 decrements *t_dev (graph replay)     */
+    DLPM_SMP_NO_FUSED_MLP = 8 /* sampler only: do not use the one-launch toy-net loop            */
 };
 
 typedef struct dlpm_update_args {
@@ -188,6 +189,14 @@ int dlpm_mlp_finalize(dlpm_mlp *net);
 /* eps_dev[B,1,F] = MLP(x_dev[B,1,F], t_dev[B]) -- MLPModel.forward, Model.py:148-211. */
 int dlpm_mlp_forward(dlpm_mlp *net, const float *x_dev, const float *t_dev, float *eps_dev, int64_t B,
                      dlpm_stream_t stream);
+/* `nsteps` whole reverse steps t = t_start, t_start-1, ... for the toy net in ONE launch: model forward
+ * + DLPM update (Philox noise) with the state held in registers (nfeatures <= 4).  x_dev[B,1,F] is
+ * updated in place; tables as produced by dlpm_coeff_tables_f32.  key_dev (nullable) overrides
+ * {seed, sample_offset} from device memory.  Replaces the loop body of p_sample_loop_progressive
+ * (GenerativeLevyProcess.py:317-330) for BASELINE configs[0], which is otherwise launch-bound. */
+int dlpm_mlp_sample_steps_f32(dlpm_mlp *net, float *x_dev, const float *c_eps_dev, const float *c_noise_dev,
+                              const float *g_dev, int32_t T, int64_t B, int32_t t_start, int32_t nsteps,
+                              uint64_t seed, int64_t sample_offset, const uint64_t *key_dev, dlpm_stream_t stream);
 void dlpm_mlp_destroy(dlpm_mlp *net);
 
 /* ------------------------------------------------------------------------------------------
@@ -253,7 +262,7 @@ typedef struct dlpm_sampler_config {
     int32_t T;                  /* reverse steps */
     double alpha;
     double clamp_a, clamp_eps;  /* < 0: none */
-    int32_t flags;              /* DLPM_UPD_DLIM | DLPM_UPD_CLIP */
+    int32_t flags;              /* DLPM_UPD_DLIM | DLPM_UPD_CLIP | DLPM_SMP_NO_FUSED_MLP */
     float dlim_eta;
     uint64_t seed;
     int64_t sample_offset;      /* global index of this shard's first sample */
