@@ -35,7 +35,7 @@ class ConvArgs(C.Structure):
     _fields_ = [('src0', vp), ('src1', vp), ('C0', i32), ('C1', i32), ('B', i32), ('Hin', i32), ('Win', i32),
                 ('Hout', i32), ('Wout', i32), ('ksize', i32), ('stride', i32), ('upsample', i32), ('weight', vp),
                 ('bias', vp), ('coefA', vp), ('coefB', vp), ('act_silu', i32), ('res0', vp), ('res1', vp), ('R0', i32),
-                ('out', vp), ('Cout', i32), ('in_nchw', i32), ('out_nchw', i32), ('force_direct', i32)]
+                ('out', vp), ('Cout', i32), ('in_nchw', i32), ('out_nchw', i32), ('force_direct', i32), ('scratch_floats', i64)]
 
 
 class SamplerConfig(C.Structure):

@@ -11,6 +11,8 @@ struct ConvLaunch {
     int B = 0, Hin = 0, Win = 0, Hout = 0, Wout = 0;
     int ks = 1, stride = 1, ups = 0;
     const float *w = nullptr;      // igemm: [ks*ks][Cout][Cin]   direct: [ks*ks][Cin][Cout]
+    const float *w_frag = nullptr; // optional, 3x3 only: MFMA B-fragment order [Cout/32][Cin/32][9][4][64 lanes][4]
+                                   // (see k_conv3x3_halo_ws): each wave streams it straight into registers
     const float *bias = nullptr;   // [Cout] or null
     const float *coefA = nullptr, *coefB = nullptr;  // [B, Cin] fused GroupNorm affine, or null
     int act_silu = 0;
@@ -41,6 +43,9 @@ inline int launch_conv_fallback(const ConvLaunch &L, hipStream_t st) {
 
 // weight re-layout kernels: OIHW -> [tap][Cout][Cin] (igemm) or [tap][Cin][Cout] (direct)
 int relayout_weight(const float *oihw_dev, float *dst_dev, int Cout, int Cin, int ks, bool for_igemm, hipStream_t st);
+// OIHW 3x3 -> fragment order for k_conv3x3_halo_ws; dst holds frag_weight_floats(Cout, Cin) floats
+int64_t frag_weight_floats(int Cout, int Cin);
+int relayout_weight_frag(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st);
 
 int launch_gn_coeffs(const float *src0, const float *src1, int C0, int C1, int B, int HW, int groups,
                      const float *gamma, const float *beta, const float *ss, int64_t ss_stride, int64_t ss_offset,

@@ -492,6 +492,230 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_conv3x3_halo_ws: the halo kernel with the WEIGHTS STREAMED STRAIGHT INTO REGISTERS.
+// The weight tile is identical for every workgroup and every wave needs only its own 64 output
+// channels of it, so instead of staging it through LDS (global load -> VGPR -> ds_write -> barrier
+// -> ds_read, once per tap) the weights are stored pre-arranged in MFMA B-fragment order
+//   Wf[n-block of 32][chunk][tap][k-group][lane][4]
+// -- the 36 fragment groups of a chunk, and the chunks after one another, form one linear stream of
+// 1-KB pieces per n-block -- and each wave reads its stream with fully coalesced 1-KB loads,
+// prefetching two groups (2 x 1024 MFMA cycles) ahead in a 3-slot register ring.  LDS then holds only
+// the activation halo, and the per-tap workgroup barrier disappears: waves synchronise twice per
+// 32-channel chunk instead of nine times.  Measured motivation (DLPM_ABL ablations, MFMA
+// micro-benchmark tools/mb/mfma_loop.hip): the LDS weight staging + per-tap barrier cost ~8 % of the
+// kernel.
+// ---------------------------------------------------------------------------------------------
+template <int BN, int WAVES_M, int WAVES_N, int RM, int RN>
+__global__ void __launch_bounds__(256, 2) k_conv3x3_halo_ws(ConvLaunch p, int th, int nimg) {
+    static_assert(WAVES_M * WAVES_N == 4 && WAVES_M * RM * 32 == BM && WAVES_N * RN * 32 == BN, "tile shape");
+    constexpr int NG = 36;  // fragment groups per chunk: 9 taps x 4 k-groups
+    extern __shared__ __attribute__((aligned(16))) float hsm[];
+    const int W = p.Wout, H = p.Hout, Wp = W + 2;
+    const int hpi = (th + 2) * Wp;
+    const int hp = nimg * hpi;
+    float *Ah = hsm;
+    float *Cf = hsm + ((hp + 3) & ~3) * LDS_LD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int Cin = p.C0 + p.C1;
+    const int HWo = H * W;
+    const int ntile_n = (p.Cout + BN - 1) / BN;
+    const int64_t M = (int64_t)p.B * HWo;
+    const int64_t m0 = (int64_t)(blockIdx.x / ntile_n) * BM;
+    const int n0 = (blockIdx.x % ntile_n) * BN;
+    const int pb = (int)(m0 / HWo);
+    const int y0 = (nimg > 1) ? 0 : (int)((m0 - (int64_t)pb * HWo) / W);
+    const int nch = Cin / KC;
+
+    // ---- halo staging (as k_conv3x3_halo)
+    const int c4 = (tid & 7) * 4;
+    const int nit = (hp * 8 + 255) / 256;
+    int off[HALO_NIT];
+#pragma unroll
+    for (int it = 0; it < HALO_NIT; it++) {
+        const int hpix = it * 32 + (tid >> 3);
+        const int img = hpix / hpi, hr = hpix - img * hpi;
+        const int hy = hr / Wp, hx = hr - hy * Wp;
+        const int iy = y0 + hy - 1, ix = hx - 1;
+        const bool pad = iy < 0 || iy >= H || ix < 0 || ix >= W || (pb + img) >= p.B;
+        off[it] = (it >= nit || hpix >= hp) ? -2 : (pad ? -1 : (((pb + img) * H + iy) * W + ix));
+    }
+    float4 xh[HALO_NIT], cfr;
+    const bool has_coef = p.coefA != nullptr;
+    const int cf_img = tid >> 4, cf_isb = (tid >> 3) & 1;
+    const bool cf_mine = has_coef && tid < nimg * 16 && (pb + cf_img) < p.B;
+    const float *cf_base = has_coef ? ((cf_isb ? p.coefB : p.coefA) + (int64_t)min(pb + cf_img, p.B - 1) * Cin) : nullptr;
+    auto load_halo = [&](int chunk) {
+        const int c = chunk * KC + c4;
+        const bool first = c < p.C0;
+        const float *sb = first ? p.src0 + c : p.src1 + (c - p.C0);
+        const int ld = first ? p.C0 : p.C1;
+#pragma unroll
+        for (int it = 0; it < HALO_NIT; it++)
+            if (it < nit) xh[it] = *reinterpret_cast<const float4 *>(sb + (int64_t)max(off[it], 0) * ld);
+        if (has_coef) cfr = *reinterpret_cast<const float4 *>(cf_base + c);
+    };
+    auto store_coef = [&]() {
+        if (cf_mine) *reinterpret_cast<float4 *>(Cf + cf_img * 64 + cf_isb * 32 + c4) = cfr;
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int it = 0; it < HALO_NIT; it++) {
+            if (off[it] == -2) continue;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (off[it] >= 0) {
+                x = xh[it];
+                if (has_coef) {
+                    const int img = (nimg > 1) ? (it * 32 + (tid >> 3)) / hpi : 0;
+                    const float4 ca = *reinterpret_cast<const float4 *>(Cf + img * 64 + c4);
+                    const float4 cb = *reinterpret_cast<const float4 *>(Cf + img * 64 + 32 + c4);
+                    x.x = fmaf(x.x, ca.x, cb.x);
+                    x.y = fmaf(x.y, ca.y, cb.y);
+                    x.z = fmaf(x.z, ca.z, cb.z);
+                    x.w = fmaf(x.w, ca.w, cb.w);
+                }
+                if (p.act_silu) {
+                    x.x = silu_f(x.x);
+                    x.y = silu_f(x.y);
+                    x.z = silu_f(x.z);
+                    x.w = silu_f(x.w);
+                }
+            }
+            *reinterpret_cast<float4 *>(Ah + (it * 32 + (tid >> 3)) * LDS_LD + c4) = x;
+        }
+    };
+
+    // ---- weight stream of this wave: RN linear streams of float4-per-lane fragments
+    // (one base pointer + integer offsets: an array of advancing pointers degrades to flat_load, whose
+    //  out-of-order completion forces vmcnt(0)/lgkmcnt(0) waits and kills the prefetch ring)
+    const float4 *__restrict__ wbase = reinterpret_cast<const float4 *>(p.w_frag) + lane;
+    int64_t woff[RN];
+#pragma unroll
+    for (int j = 0; j < RN; j++) woff[j] = (int64_t)((n0 >> 5) + wn * RN + j) * nch * NG * 64;
+    float4 bq[3][RN];  // ring: group g lives in slot g % 3
+
+    int abase[RM];
+    const int hwt = th * W;
+#pragma unroll
+    for (int i = 0; i < RM; i++) {
+        const int mloc = (wm * RM + i) * 32 + l31;
+        const int img = mloc / hwt, ml = mloc - img * hwt;
+        const int yy = ml / W, xx = ml - yy * W;
+        abase[i] = (img * hpi + yy * Wp + xx) * LDS_LD + kh * 4;
+    }
+
+    floatx16 acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; i++)
+#pragma unroll
+        for (int j = 0; j < RN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    load_halo(0);
+#pragma unroll
+    for (int j = 0; j < RN; j++) {
+        bq[0][j] = wbase[woff[j]];
+        bq[1][j] = wbase[woff[j] + 64];
+    }
+    store_coef();
+    __syncthreads();
+    store_halo();
+    __syncthreads();
+
+    for (int chunk = 0; chunk < nch; chunk++) {
+        const bool more = chunk + 1 < nch;
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            const int tap = g >> 2, kk = g & 3;
+            // prefetch fragment group g + 2 of the linear stream (runs on into the next chunk; the
+            // array is padded by two groups so the very last prefetches stay in bounds)
+#pragma unroll
+            for (int j = 0; j < RN; j++) bq[(g + 2) % 3][j] = wbase[woff[j] + (g + 2) * 64];
+            if (g == 24 && more) load_halo(chunk + 1);  // tap 6: two taps of MFMAs cover its latency
+            // pin the prefetch HERE: left alone, the scheduler sinks each load to just before its first
+            // use (two groups later) to save registers and then waits for it with vmcnt(0)
+            __builtin_amdgcn_sched_barrier(0);
+
+            const int toff = ((tap / 3) * Wp + (tap % 3)) * LDS_LD + kk * 8;
+            float4 af[RM];
+#pragma unroll
+            for (int i = 0; i < RM; i++) af[i] = *reinterpret_cast<const float4 *>(Ah + abase[i] + toff);
+#pragma unroll
+            for (int i = 0; i < RM; i++)
+#pragma unroll
+                for (int j = 0; j < RN; j++) {
+                    const float4 b = bq[g % 3][j];
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, b.x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, b.y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, b.z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, b.w, acc[i][j], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < RN; j++) woff[j] += NG * 64;
+        if (more) {
+            store_coef();
+            __syncthreads();  // every wave has finished reading this chunk's halo; coefficients visible
+            store_halo();
+            __syncthreads();
+        }
+    }
+    __syncthreads();  // the epilogue reuses the halo LDS
+
+    if (!p.out_nchw && (p.Cout & 3) == 0 && (p.R0 & 3) == 0) {
+        epilogue_rows<BN, WAVES_M, WAVES_N, RM, RN>(p, acc, hsm, m0, n0, M, tid, wm, wn, l31, kh);
+        return;
+    }
+    const int R1 = p.Cout - p.R0;
+#pragma unroll
+    for (int j = 0; j < RN; j++) {
+        const int n = n0 + (wn * RN + j) * 32 + l31;
+        if (n >= p.Cout) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < RM; i++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (wm * RM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int64_t m = m0 + row;
+                if (m >= M) continue;
+                float v = acc[i][j][r] + bias;
+                if (p.res0) v += (n < p.R0) ? p.res0[m * p.R0 + n] : p.res1[m * R1 + (n - p.R0)];
+                if (p.out_nchw) {
+                    const int64_t bb = m / HWo;
+                    p.out[(bb * p.Cout + n) * HWo + (m - bb * HWo)] = v;
+                } else {
+                    p.out[m * p.Cout + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// OIHW (3x3) -> Wf[nb][chunk][tap][kk][lane][4]:  lane = kh*32 + l31 holds
+// W[cout = nb*32 + l31][cin = chunk*32 + kk*8 + kh*4 + e][tap], zero beyond Cout.
+__global__ void k_relayout_weight_frag(const float *oihw, float *dst, int Cout, int Cin) {
+    const int nbk = (Cout + 31) / 32, nch = Cin / 32;
+    const int64_t n = (int64_t)nbk * nch * 36 * 64 * 4;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int e = (int)(i & 3);
+    const int lane = (int)((i >> 2) & 63);
+    int64_t r = i >> 8;
+    const int kk = (int)(r & 3);
+    r >>= 2;
+    const int tap = (int)(r % 9);
+    r /= 9;
+    const int chunk = (int)(r % nch);
+    const int nb = (int)(r / nch);
+    const int co = nb * 32 + (lane & 31), ci = chunk * 32 + kk * 8 + (lane >> 5) * 4 + e;
+    dst[i] = (co < Cout) ? oihw[((int64_t)co * Cin + ci) * 9 + tap] : 0.f;
+}
+
 // stem: Cin = image channels read from the caller's NCHW state, 3x3 stride 1, writes NHWC.
 // One thread = one pixel x 4 output channels; the 9*Cin taps are broadcast across the 32 threads
 // of a pixel, weight rows are coalesced float4 loads.
@@ -569,6 +793,24 @@ static bool halo_ok(const ConvLaunch &c, int *th, int *nimg) {
 }
 
 template <int BN, int WAVES_M, int WAVES_N, int RM, int RN>
+static int launch_halo_ws(const ConvLaunch &c, int th, int nimg, int64_t grid, hipStream_t st) {
+    const int hp = nimg * (th + 2) * (c.Wout + 2);
+    size_t shmem = (size_t)((hp + 3) & ~3) * LDS_LD * sizeof(float) + (size_t)nimg * 64 * sizeof(float);
+    const size_t epi = (size_t)(RM * 32) * (BN + 4) * sizeof(float);   // epilogue_rows' row image
+    const size_t stats = (size_t)(256 / (BN / 4)) * BN * 2 * sizeof(float);
+    if (shmem < epi) shmem = epi;
+    if (shmem < stats) shmem = stats;
+    static bool attr = false;
+    if (!attr) {
+        DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo_ws<BN, WAVES_M, WAVES_N, RM, RN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr = true;
+    }
+    k_conv3x3_halo_ws<BN, WAVES_M, WAVES_N, RM, RN><<<(unsigned)grid, 256, shmem, st>>>(c, th, nimg);
+    return DLPM_OK;
+}
+
+template <int BN, int WAVES_M, int WAVES_N, int RM, int RN>
 static int launch_halo(const ConvLaunch &c, int th, int nimg, int64_t grid, hipStream_t st) {
     const int hp = nimg * (th + 2) * (c.Wout + 2);
     const size_t shmem = (size_t)(((hp + 3) & ~3) + 2 * BN) * LDS_LD * sizeof(float) + (size_t)nimg * 64 * sizeof(float);
@@ -609,6 +851,16 @@ int launch_conv_igemm(const ConvLaunch &c, hipStream_t st) {
     if (abl) const_cast<ConvLaunch &>(c).abl = abl;
     if (halo_ok(c, &th, &nimg)) {
         int r;
+        static int no_ws = -1;
+        if (no_ws < 0) { const char *e = getenv("DLPM_NO_WS"); no_ws = (e && e[0] == '1') ? 1 : 0; }
+        if (c.w_frag && !no_ws && !c.abl && (c.C0 + c.C1) % KC == 0) {
+            if (c.Cout > 64) r = launch_halo_ws<128, 2, 2, 2, 2>(c, th, nimg, mt * ceil_div(c.Cout, 128), st);
+            else if (c.Cout > 32) r = launch_halo_ws<64, 2, 2, 2, 1>(c, th, nimg, mt * ceil_div(c.Cout, 64), st);
+            else r = launch_halo_ws<32, 4, 1, 1, 1>(c, th, nimg, mt * ceil_div(c.Cout, 32), st);
+            if (r != DLPM_OK) return r;
+            DLPM_LAUNCH_CHECK();
+            return DLPM_OK;
+        }
         if (c.Cout > 64) r = launch_halo<128, 2, 2, 2, 2>(c, th, nimg, mt * ceil_div(c.Cout, 128), st);
         else if (c.Cout > 32) r = launch_halo<64, 2, 2, 2, 1>(c, th, nimg, mt * ceil_div(c.Cout, 64), st);
         else r = launch_halo<32, 4, 1, 1, 1>(c, th, nimg, mt * ceil_div(c.Cout, 32), st);
@@ -626,6 +878,19 @@ int launch_conv_igemm(const ConvLaunch &c, hipStream_t st) {
         const int64_t grid = mt * ceil_div(c.Cout, 32);
         k_conv_igemm<32, 4, 1, 1, 1><<<(unsigned)grid, 256, 0, st>>>(c);
     }
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+int64_t frag_weight_floats(int Cout, int Cin) {
+    // + 2 groups of padding at the end: the 2-ahead prefetch of the last groups reads past the data
+    return ((int64_t)((Cout + 31) / 32) * (Cin / 32) * 36 + 2) * 256;
+}
+
+int relayout_weight_frag(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st) {
+    const int64_t n = (int64_t)((Cout + 31) / 32) * (Cin / 32) * 36 * 256;
+    DLPM_HIP(hipMemsetAsync(dst_dev + n, 0, 2 * 256 * sizeof(float), st));
+    k_relayout_weight_frag<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }

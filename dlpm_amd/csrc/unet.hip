@@ -39,6 +39,7 @@ struct ConvW {            // one convolution's weights
     int cout = 0, cin = 0, ks = 1;
     bool use_igemm = false;
     float *w_dev = nullptr;  // re-laid-out copy (or the original for 1x1 igemm)
+    float *w_frag = nullptr; // 3x3 only: MFMA fragment order for the weight-streaming halo kernel
     bool owns = false;
 };
 
@@ -242,11 +243,17 @@ int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 no
     }
     DLPM_HIP(hipMalloc(&c.w_dev, (size_t)c.cout * c.cin * c.ks * c.ks * sizeof(float)));
     c.owns = true;
+    if (c.use_igemm && c.ks == 3 && c.cin % 32 == 0) {
+        DLPM_HIP(hipMalloc(&c.w_frag, (size_t)frag_weight_floats(c.cout, c.cin) * sizeof(float)));
+        int r = relayout_weight_frag(src, c.w_frag, c.cout, c.cin, nullptr);
+        if (r != DLPM_OK) return r;
+    }
     return relayout_weight(src, c.w_dev, c.cout, c.cin, c.ks, c.use_igemm, nullptr);
 }
 
 int run_conv(const ConvW &c, ConvLaunch L, hipStream_t st) {
     L.w = c.w_dev;
+    L.w_frag = c.w_frag;
     L.ks = c.ks;
     L.Cout = c.cout;
     return c.use_igemm ? launch_conv_igemm(L, st) : launch_conv_fallback(L, st);
@@ -504,6 +511,8 @@ extern "C" int dlpm_unet_set_param(dlpm_unet *net, const char *key, const float 
 
 static void free_conv(ConvW &c) {
     if (c.owns && c.w_dev) (void)hipFree(c.w_dev);
+    if (c.w_frag) (void)hipFree(c.w_frag);
+    c.w_frag = nullptr;
     c.w_dev = nullptr;
     c.owns = false;
 }
@@ -685,6 +694,12 @@ extern "C" int dlpm_conv2d_f32(const dlpm_conv_args *a, float *scratch_dev, dlpm
     hipStream_t st = as_stream(stream);
     TRY(relayout_weight(a->weight, scratch_dev, a->Cout, a->C0 + a->C1, a->ksize, ig, st));
     L.w = scratch_dev;
+    if (ig && a->ksize == 3 && (a->C0 + a->C1) % 32 == 0 &&
+        a->scratch_floats >= (int64_t)a->Cout * (a->C0 + a->C1) * 9 + frag_weight_floats(a->Cout, a->C0 + a->C1)) {
+        float *wf = scratch_dev + (int64_t)a->Cout * (a->C0 + a->C1) * 9;
+        TRY(relayout_weight_frag(a->weight, wf, a->Cout, a->C0 + a->C1, st));
+        L.w_frag = wf;
+    }
     if (ig) return launch_conv_igemm(L, st);
     return a->force_direct ? launch_conv_direct(L, st) : launch_conv_fallback(L, st);
 }

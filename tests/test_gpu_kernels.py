@@ -65,7 +65,8 @@ def run_conv(x0, w, bias=None, x1=None, stride=1, ups=0, coef=None, silu=False, 
     out = torch.empty((B, Cout, Hout, Wout) if out_nchw else (B, Hout, Wout, Cout), device=DEV)
     a.out, a.Cout = out.data_ptr(), Cout
     a.in_nchw, a.out_nchw, a.force_direct = int(in_nchw), int(out_nchw), int(force_direct)
-    scratch = torch.empty(2 * w.numel() + 64, device=DEV)
+    scratch = torch.empty(3 * w.numel() + 16 * 1024 * (1 + Cout // 32), device=DEV)
+    a.scratch_floats = scratch.numel()
     _lib.check(L().dlpm_conv2d_f32(C.byref(a), scratch.data_ptr(), st()))
     torch.cuda.synchronize()
     return (out if out_nchw else nchw(out)).cpu()
