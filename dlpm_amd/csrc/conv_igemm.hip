@@ -500,13 +500,13 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th, int 
 //   Wf[n-block of 32][chunk][tap][k-group][lane][4]
 // -- the 36 fragment groups of a chunk, and the chunks after one another, form one linear stream of
 // 1-KB pieces per n-block -- and each wave reads its stream with fully coalesced 1-KB loads,
-// prefetching two groups (2 x 1024 MFMA cycles) ahead in a 3-slot register ring.  LDS then holds only
+// prefetching one group (1024 MFMA cycles) ahead in a small register ring.  LDS then holds only
 // the activation halo, and the per-tap workgroup barrier disappears: waves synchronise twice per
 // 32-channel chunk instead of nine times.  Measured motivation (DLPM_ABL ablations, MFMA
 // micro-benchmark tools/mb/mfma_loop.hip): the LDS weight staging + per-tap barrier cost ~8 % of the
 // kernel.
 // ---------------------------------------------------------------------------------------------
-template <int BN, int WAVES_M, int WAVES_N, int RM, int RN>
+template <int BN, int WAVES_M, int WAVES_N, int RM, int RN, int RING>
 __global__ void __launch_bounds__(256, 2) k_conv3x3_halo_ws(ConvLaunch p, int th, int nimg) {
     static_assert(WAVES_M * WAVES_N == 4 && WAVES_M * RM * 32 == BM && WAVES_N * RN * 32 == BN, "tile shape");
     constexpr int NG = 36;  // fragment groups per chunk: 9 taps x 4 k-groups
@@ -595,7 +595,8 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_halo_ws(ConvLaunch p, int th
     int64_t woff[RN];
 #pragma unroll
     for (int j = 0; j < RN; j++) woff[j] = (int64_t)((n0 >> 5) + wn * RN + j) * nch * NG * 64;
-    float4 bq[3][RN];  // ring: group g lives in slot g % 3
+    constexpr int AHEAD = RING - 1;
+    float4 bq[RING][RN];  // ring: group g lives in slot g % RING
 
     int abase[RM];
     const int hwt = th * W;
@@ -618,8 +619,8 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_halo_ws(ConvLaunch p, int th
     load_halo(0);
 #pragma unroll
     for (int j = 0; j < RN; j++) {
-        bq[0][j] = wbase[woff[j]];
-        bq[1][j] = wbase[woff[j] + 64];
+#pragma unroll
+        for (int a = 0; a < AHEAD; a++) bq[a][j] = wbase[woff[j] + a * 64];
     }
     store_coef();
     __syncthreads();
@@ -634,7 +635,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_halo_ws(ConvLaunch p, int th
             // prefetch fragment group g + 2 of the linear stream (runs on into the next chunk; the
             // array is padded by two groups so the very last prefetches stay in bounds)
 #pragma unroll
-            for (int j = 0; j < RN; j++) bq[(g + 2) % 3][j] = wbase[woff[j] + (g + 2) * 64];
+            for (int j = 0; j < RN; j++) bq[(g + AHEAD) % RING][j] = wbase[woff[j] + (g + AHEAD) * 64];
             if (g == 24 && more) load_halo(chunk + 1);  // tap 6: two taps of MFMAs cover its latency
             // pin the prefetch HERE: left alone, the scheduler sinks each load to just before its first
             // use (two groups later) to save registers and then waits for it with vmcnt(0)
@@ -648,7 +649,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_halo_ws(ConvLaunch p, int th
             for (int i = 0; i < RM; i++)
 #pragma unroll
                 for (int j = 0; j < RN; j++) {
-                    const float4 b = bq[g % 3][j];
+                    const float4 b = bq[g % RING][j];
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, b.x, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, b.y, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, b.z, acc[i][j], 0, 0, 0);
@@ -792,8 +793,8 @@ static bool halo_ok(const ConvLaunch &c, int *th, int *nimg) {
     return *nimg * (*th + 2) * (W + 2) * 8 <= HALO_NIT * 256;
 }
 
-template <int BN, int WAVES_M, int WAVES_N, int RM, int RN>
-static int launch_halo_ws(const ConvLaunch &c, int th, int nimg, int64_t grid, hipStream_t st) {
+template <int BN, int WAVES_M, int WAVES_N, int RM, int RN, int RING>
+static int launch_halo_ws_r(const ConvLaunch &c, int th, int nimg, int64_t grid, hipStream_t st) {
     const int hp = nimg * (th + 2) * (c.Wout + 2);
     size_t shmem = (size_t)((hp + 3) & ~3) * LDS_LD * sizeof(float) + (size_t)nimg * 64 * sizeof(float);
     const size_t epi = (size_t)(RM * 32) * (BN + 4) * sizeof(float);   // epilogue_rows' row image
@@ -802,12 +803,22 @@ static int launch_halo_ws(const ConvLaunch &c, int th, int nimg, int64_t grid, h
     if (shmem < stats) shmem = stats;
     static bool attr = false;
     if (!attr) {
-        DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo_ws<BN, WAVES_M, WAVES_N, RM, RN>),
+        DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo_ws<BN, WAVES_M, WAVES_N, RM, RN, RING>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         attr = true;
     }
-    k_conv3x3_halo_ws<BN, WAVES_M, WAVES_N, RM, RN><<<(unsigned)grid, 256, shmem, st>>>(c, th, nimg);
+    k_conv3x3_halo_ws<BN, WAVES_M, WAVES_N, RM, RN, RING><<<(unsigned)grid, 256, shmem, st>>>(c, th, nimg);
     return DLPM_OK;
+}
+
+template <int BN, int WAVES_M, int WAVES_N, int RM, int RN>
+static int launch_halo_ws(const ConvLaunch &c, int th, int nimg, int64_t grid, hipStream_t st) {
+    static int ring = -1;
+    if (ring < 0) { const char *e = getenv("DLPM_WS_RING"); ring = e ? atoi(e) : 2; }
+    // one group (16 MFMAs = 1024 cycles) of prefetch distance measured faster than two: the kernel sits at the
+    // 256-register cap and the third ring slot costs spills (98.6 vs 100.5 ms/step on the CIFAR net)
+    if (ring == 3) return launch_halo_ws_r<BN, WAVES_M, WAVES_N, RM, RN, 3>(c, th, nimg, grid, st);
+    return launch_halo_ws_r<BN, WAVES_M, WAVES_N, RM, RN, 2>(c, th, nimg, grid, st);
 }
 
 template <int BN, int WAVES_M, int WAVES_N, int RM, int RN>
