@@ -635,7 +635,12 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_halo_ws(ConvLaunch p, int th
             // prefetch fragment group g + 2 of the linear stream (runs on into the next chunk; the
             // array is padded by two groups so the very last prefetches stay in bounds)
 #pragma unroll
-            for (int j = 0; j < RN; j++) bq[(g + AHEAD) % RING][j] = wbase[woff[j] + (g + AHEAD) * 64];
+            for (int j = 0; j < RN; j++) {
+                // (advancing offset + one small immediate: with static offsets up to 36 KB the compiler keeps a
+                //  dozen 64-bit base registers alive, and this kernel is at the register cap)
+                bq[(g + AHEAD) % RING][j] = wbase[woff[j] + AHEAD * 64];
+                woff[j] += 64;
+            }
             if (g == 24 && more) load_halo(chunk + 1);  // tap 6: two taps of MFMAs cover its latency
             // pin the prefetch HERE: left alone, the scheduler sinks each load to just before its first
             // use (two groups later) to save registers and then waits for it with vmcnt(0)
@@ -656,8 +661,6 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_halo_ws(ConvLaunch p, int th
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, b.w, acc[i][j], 0, 0, 0);
                 }
         }
-#pragma unroll
-        for (int j = 0; j < RN; j++) woff[j] += NG * 64;
         if (more) {
             store_coef();
             __syncthreads();  // every wave has finished reading this chunk's halo; coefficients visible
