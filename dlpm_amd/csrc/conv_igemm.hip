@@ -506,13 +506,18 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th, int 
 // micro-benchmark tools/mb/mfma_loop.hip): the LDS weight staging + per-tap barrier cost ~8 % of the
 // kernel.
 // ---------------------------------------------------------------------------------------------
-template <int BN, int WAVES_M, int WAVES_N, int RM, int RN, int RING>
+template <int BN, int WAVES_M, int WAVES_N, int RM, int RN, int RING, bool UPS>
 __global__ void __launch_bounds__(256, 2) k_conv3x3_halo_ws(ConvLaunch p, int th, int nimg) {
+    // UPS: the conv runs on the nearest-x2 upsampled input (Upsample, unet.py:73-75).  The halo tile then holds
+    // the SOURCE-resolution patch ((th/2+2) x (W/2+2) pixels) and each lane's tap address is
+    // row_offset[ky] + col_offset[kx], which depend on the parity of its output pixel.
     static_assert(WAVES_M * WAVES_N == 4 && WAVES_M * RM * 32 == BM && WAVES_N * RN * 32 == BN, "tile shape");
     constexpr int NG = 36;  // fragment groups per chunk: 9 taps x 4 k-groups
     extern __shared__ __attribute__((aligned(16))) float hsm[];
-    const int W = p.Wout, H = p.Hout, Wp = W + 2;
-    const int hpi = (th + 2) * Wp;
+    const int W = p.Wout, H = p.Hout;
+    const int Ws = UPS ? (W >> 1) : W, Hs = UPS ? (H >> 1) : H;   // source (staged) resolution
+    const int Wp = Ws + 2;
+    const int hpi = ((UPS ? (th >> 1) : th) + 2) * Wp;
     const int hp = nimg * hpi;
     float *Ah = hsm;
     float *Cf = hsm + ((hp + 3) & ~3) * LDS_LD;
@@ -539,9 +544,9 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_halo_ws(ConvLaunch p, int th
         const int hpix = it * 32 + (tid >> 3);
         const int img = hpix / hpi, hr = hpix - img * hpi;
         const int hy = hr / Wp, hx = hr - hy * Wp;
-        const int iy = y0 + hy - 1, ix = hx - 1;
-        const bool pad = iy < 0 || iy >= H || ix < 0 || ix >= W || (pb + img) >= p.B;
-        off[it] = (it >= nit || hpix >= hp) ? -2 : (pad ? -1 : (((pb + img) * H + iy) * W + ix));
+        const int iy = (UPS ? (y0 >> 1) : y0) + hy - 1, ix = hx - 1;
+        const bool pad = iy < 0 || iy >= Hs || ix < 0 || ix >= Ws || (pb + img) >= p.B;
+        off[it] = (it >= nit || hpix >= hp) ? -2 : (pad ? -1 : (((pb + img) * Hs + iy) * Ws + ix));
     }
     float4 xh[HALO_NIT], cfr;
     const bool has_coef = p.coefA != nullptr;
@@ -598,7 +603,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_halo_ws(ConvLaunch p, int th
     constexpr int AHEAD = RING - 1;
     float4 bq[RING][RN];  // ring: group g lives in slot g % RING
 
-    int abase[RM];
+    int abase[RM], rowoff[RM][3], coloff[RM][3];
     const int hwt = th * W;
 #pragma unroll
     for (int i = 0; i < RM; i++) {
@@ -606,6 +611,13 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_halo_ws(ConvLaunch p, int th
         const int img = mloc / hwt, ml = mloc - img * hwt;
         const int yy = ml / W, xx = ml - yy * W;
         abase[i] = (img * hpi + yy * Wp + xx) * LDS_LD + kh * 4;
+        if (UPS) {
+#pragma unroll
+            for (int d = 0; d < 3; d++) {   // source halo coordinates of tap row/column d (arithmetic shift: -1 -> -1)
+                rowoff[i][d] = (img * hpi + (((yy + d - 1) >> 1) + 1) * Wp) * LDS_LD + kh * 4;
+                coloff[i][d] = (((xx + d - 1) >> 1) + 1) * LDS_LD;
+            }
+        }
     }
 
     floatx16 acc[RM][RN];
@@ -649,7 +661,8 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_halo_ws(ConvLaunch p, int th
             const int toff = ((tap / 3) * Wp + (tap % 3)) * LDS_LD + kk * 8;
             float4 af[RM];
 #pragma unroll
-            for (int i = 0; i < RM; i++) af[i] = *reinterpret_cast<const float4 *>(Ah + abase[i] + toff);
+            for (int i = 0; i < RM; i++)
+                af[i] = *reinterpret_cast<const float4 *>(Ah + (UPS ? rowoff[i][tap / 3] + coloff[i][tap % 3] + kk * 8 : abase[i] + toff));
 #pragma unroll
             for (int i = 0; i < RM; i++)
 #pragma unroll
@@ -778,10 +791,17 @@ bool igemm_supported(const ConvLaunch &c) {
     return true;
 }
 
+static bool ws_disabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DLPM_NO_WS"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 static bool halo_ok(const ConvLaunch &c, int *th, int *nimg) {
     static int disabled = -1;
     if (disabled < 0) { const char *e = getenv("DLPM_NO_HALO"); disabled = (e && e[0] == '1') ? 1 : 0; }
-    if (disabled || c.ks != 3 || c.stride != 1 || c.ups) return false;
+    if (disabled || c.ks != 3 || c.stride != 1) return false;
+    if (c.ups && (!c.w_frag || ws_disabled() || (c.Wout & 1) || (c.Hout & 1))) return false;   // upsample: weight-streaming kernel only
     const int W = c.Wout, HW = c.Hout * c.Wout;
     if (W < 4 || W > 64 || BM % W != 0) return false;
     if (HW >= BM) {            // th full rows of one image
@@ -793,12 +813,13 @@ static bool halo_ok(const ConvLaunch &c, int *th, int *nimg) {
         *th = c.Hout;
         *nimg = BM / HW;
     }
+    if (c.ups && ((*th & 1) || (c.C0 + c.C1) % KC != 0 || c.abl)) return false;
     return *nimg * (*th + 2) * (W + 2) * 8 <= HALO_NIT * 256;
 }
 
-template <int BN, int WAVES_M, int WAVES_N, int RM, int RN, int RING>
+template <int BN, int WAVES_M, int WAVES_N, int RM, int RN, int RING, bool UPS>
 static int launch_halo_ws_r(const ConvLaunch &c, int th, int nimg, int64_t grid, hipStream_t st) {
-    const int hp = nimg * (th + 2) * (c.Wout + 2);
+    const int hp = nimg * ((UPS ? th / 2 : th) + 2) * ((UPS ? c.Wout / 2 : c.Wout) + 2);
     size_t shmem = (size_t)((hp + 3) & ~3) * LDS_LD * sizeof(float) + (size_t)nimg * 64 * sizeof(float);
     const size_t epi = (size_t)(RM * 32) * (BN + 4) * sizeof(float);   // epilogue_rows' row image
     const size_t stats = (size_t)(256 / (BN / 4)) * BN * 2 * sizeof(float);
@@ -806,22 +827,19 @@ static int launch_halo_ws_r(const ConvLaunch &c, int th, int nimg, int64_t grid,
     if (shmem < stats) shmem = stats;
     static bool attr = false;
     if (!attr) {
-        DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo_ws<BN, WAVES_M, WAVES_N, RM, RN, RING>),
+        DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo_ws<BN, WAVES_M, WAVES_N, RM, RN, RING, UPS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         attr = true;
     }
-    k_conv3x3_halo_ws<BN, WAVES_M, WAVES_N, RM, RN, RING><<<(unsigned)grid, 256, shmem, st>>>(c, th, nimg);
+    k_conv3x3_halo_ws<BN, WAVES_M, WAVES_N, RM, RN, RING, UPS><<<(unsigned)grid, 256, shmem, st>>>(c, th, nimg);
     return DLPM_OK;
 }
 
 template <int BN, int WAVES_M, int WAVES_N, int RM, int RN>
 static int launch_halo_ws(const ConvLaunch &c, int th, int nimg, int64_t grid, hipStream_t st) {
-    static int ring = -1;
-    if (ring < 0) { const char *e = getenv("DLPM_WS_RING"); ring = e ? atoi(e) : 2; }
-    // one group (16 MFMAs = 1024 cycles) of prefetch distance measured faster than two: the kernel sits at the
-    // 256-register cap and the third ring slot costs spills (98.6 vs 100.5 ms/step on the CIFAR net)
-    if (ring == 3) return launch_halo_ws_r<BN, WAVES_M, WAVES_N, RM, RN, 3>(c, th, nimg, grid, st);
-    return launch_halo_ws_r<BN, WAVES_M, WAVES_N, RM, RN, 2>(c, th, nimg, grid, st);
+    // ring depth 2 = one fragment group (16 MFMAs = 1024 cycles) of prefetch distance; 3 measured equal
+    if (c.ups) return launch_halo_ws_r<BN, WAVES_M, WAVES_N, RM, RN, 2, true>(c, th, nimg, grid, st);
+    return launch_halo_ws_r<BN, WAVES_M, WAVES_N, RM, RN, 2, false>(c, th, nimg, grid, st);
 }
 
 template <int BN, int WAVES_M, int WAVES_N, int RM, int RN>
@@ -865,9 +883,7 @@ int launch_conv_igemm(const ConvLaunch &c, hipStream_t st) {
     if (abl) const_cast<ConvLaunch &>(c).abl = abl;
     if (halo_ok(c, &th, &nimg)) {
         int r;
-        static int no_ws = -1;
-        if (no_ws < 0) { const char *e = getenv("DLPM_NO_WS"); no_ws = (e && e[0] == '1') ? 1 : 0; }
-        if (c.w_frag && !no_ws && !c.abl && (c.C0 + c.C1) % KC == 0) {
+        if (c.w_frag && !ws_disabled() && !c.abl && (c.C0 + c.C1) % KC == 0) {
             if (c.Cout > 64) r = launch_halo_ws<128, 2, 2, 2, 2>(c, th, nimg, mt * ceil_div(c.Cout, 128), st);
             else if (c.Cout > 32) r = launch_halo_ws<64, 2, 2, 2, 1>(c, th, nimg, mt * ceil_div(c.Cout, 64), st);
             else r = launch_halo_ws<32, 4, 1, 1, 1>(c, th, nimg, mt * ceil_div(c.Cout, 32), st);

@@ -107,6 +107,9 @@ CONV_CASES = [
     ('igemm_halo_16x16', 3, 64, 0, 16, 64, 3, 1, 0, True, True, False),
     ('igemm_halo_16x16_noact_cout32', 2, 32, 0, 16, 32, 3, 1, 0, False, False, True),
     ('igemm_halo_64x64', 1, 32, 0, 64, 32, 3, 1, 0, True, True, False),
+    ('igemm_halo_upsample_16to32', 2, 64, 0, 16, 128, 3, 1, 1, False, False, False),
+    ('igemm_halo_upsample_4to8_multiimage', 3, 32, 0, 4, 64, 3, 1, 1, False, False, True),
+    ('igemm_halo_upsample_8to16_coef', 2, 32, 0, 8, 32, 3, 1, 1, True, True, False),
     ('direct_odd_channels', 2, 24, 0, 8, 40, 3, 1, 0, True, True, True),
     ('direct_concat_1x1', 2, 8, 16, 4, 8, 1, 1, 0, False, False, False),
     ('direct_stride2', 2, 8, 0, 8, 8, 3, 2, 0, False, False, False),
