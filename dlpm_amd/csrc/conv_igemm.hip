@@ -734,10 +734,12 @@ __global__ void k_relayout_weight_frag(const float *oihw, float *dst, int Cout, 
 }
 
 // stem: Cin = image channels read from the caller's NCHW state, 3x3 stride 1, writes NHWC.
-// One thread = one pixel x 4 output channels; the 9*Cin taps are broadcast across the 32 threads
-// of a pixel, weight rows are coalesced float4 loads.
+// One thread = one pixel x 4 output channels.  CIN is a template parameter so that the 9*CIN taps unroll
+// into predicated (branch-free) loads issued together; the weight rows are coalesced float4 loads that
+// the 32 threads of a pixel share, the inputs are broadcast across them.
+template <int CIN>
 __global__ void __launch_bounds__(256) k_conv_stem(ConvLaunch p) {
-    const int Cin = p.C0, Cq = p.Cout / 4;
+    const int Cq = p.Cout / 4;
     const int HWo = p.Hout * p.Wout;
     const int64_t total = (int64_t)p.B * HWo * Cq;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -747,22 +749,28 @@ __global__ void __launch_bounds__(256) k_conv_stem(ConvLaunch p) {
     const int b = (int)(m / HWo);
     const int rem = (int)(m - (int64_t)b * HWo);
     const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-    float4 acc = reinterpret_cast<const float4 *>(p.bias)[nq];
-    for (int ky = 0; ky < 3; ky++) {
-        const int iy = oy + ky - 1;
-        if (iy < 0 || iy >= p.Hin) continue;
+    float v[9 * CIN];
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
         for (int kx = 0; kx < 3; kx++) {
-            const int ix = ox + kx - 1;
-            if (ix < 0 || ix >= p.Win) continue;
-            for (int c = 0; c < Cin; c++) {
-                const float v = p.src0[(((int64_t)b * Cin + c) * p.Hin + iy) * p.Win + ix];
-                const float4 w = reinterpret_cast<const float4 *>(p.w + ((int64_t)(ky * 3 + kx) * Cin + c) * p.Cout)[nq];
-                acc.x = fmaf(v, w.x, acc.x);
-                acc.y = fmaf(v, w.y, acc.y);
-                acc.z = fmaf(v, w.z, acc.z);
-                acc.w = fmaf(v, w.w, acc.w);
+            const int iy = oy + ky - 1, ix = ox + kx - 1;
+            const bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+            const int cy = min(max(iy, 0), p.Hin - 1), cx = min(max(ix, 0), p.Win - 1);
+#pragma unroll
+            for (int c = 0; c < CIN; c++) {
+                const float x = p.src0[(((int64_t)b * CIN + c) * p.Hin + cy) * p.Win + cx];
+                v[(ky * 3 + kx) * CIN + c] = ok ? x : 0.f;
             }
         }
+    float4 acc = reinterpret_cast<const float4 *>(p.bias)[nq];
+#pragma unroll
+    for (int k = 0; k < 9 * CIN; k++) {
+        const float4 w = reinterpret_cast<const float4 *>(p.w + (int64_t)k * p.Cout)[nq];
+        acc.x = fmaf(v[k], w.x, acc.x);
+        acc.y = fmaf(v[k], w.y, acc.y);
+        acc.z = fmaf(v[k], w.z, acc.z);
+        acc.w = fmaf(v[k], w.w, acc.w);
     }
     reinterpret_cast<float4 *>(p.out + m * p.Cout)[nq] = acc;
 }
@@ -859,7 +867,9 @@ static int launch_halo(const ConvLaunch &c, int th, int nimg, int64_t grid, hipS
 int launch_conv_stem(const ConvLaunch &c, hipStream_t st) {
     const int64_t total = (int64_t)c.B * c.Hout * c.Wout * (c.Cout / 4);
     ProfScope ps("conv_stem", 2.0 * total * 4 * c.C0 * 9, 4.0 * ((double)c.B * c.Hin * c.Win * c.C0 + total * 4.0), st);
-    k_conv_stem<<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(c);
+    if (c.C0 == 3) k_conv_stem<3><<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(c);
+    else if (c.C0 == 1) k_conv_stem<1><<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(c);
+    else return launch_conv_direct(c, st);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }
