@@ -40,7 +40,7 @@ METRIC = {
 }
 # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc runs,
 # FETCH_SIZE doubled per the gfx950 guide): profiles/r01/pmc_hbm_traffic_*.txt
-PMC_TRAFFIC_BYTES_PER_LAUNCH = {'k_conv3x3_halo_ws<128,2,2,2,2,2>': (0.6718 + 0.2065) * 1e9}
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {'k_conv3x3_halo_ws<128,2,2,2,2,2>': (0.6663 + 0.2194) * 1e9}  # fetch + write, mean over all three instantiations
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 PEAK_HBM_GBS = 8000.0
 
@@ -185,7 +185,7 @@ def main():
                             bound='mfma', achieved=round(ach, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
                             frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                             traffic=(PMC_TRAFFIC_BYTES_PER_LAUNCH['k_conv3x3_halo_ws<128,2,2,2,2,2>'] if cfg_name == 'cifar10' and B == 1024 else None),
-                            traffic_note='HBM bytes per launch (mean over the 44 launches of a step) from committed rocprofv3 PMC passes, profiles/r01/pmc_hbm_traffic_v8.txt; algorithmic bytes per launch = %.4g' % (c['bytes'] / c['launches']),
+                            traffic_note='HBM bytes per launch (mean over the 48 launches of a step) from committed rocprofv3 PMC passes, profiles/r01/pmc_hbm_traffic_v9.txt; algorithmic bytes per launch = %.4g' % (c['bytes'] / c['launches']),
                             launches_per_step=c['launches'] // nprof, avg_launch_ms=round(c['ms'] / c['launches'], 5),
                             flops_per_launch_avg=c['flops'] / c['launches'],
                             share_of_step_ms=round(c['ms'] / nprof, 3),
@@ -194,7 +194,7 @@ def main():
         u = prof.get('update')
         if u:
             gbs = u['bytes'] / (u['ms'] * 1e-3) / 1e9
-            upd = dict(kernel='k_update (fused x_{t-1} update, Philox noise)', bound='hbm', achieved=round(gbs, 1),
+            upd = dict(kernel='k_update_rows (fused x_{t-1} update, Philox noise)', bound='hbm', achieved=round(gbs, 1),
                        peak=PEAK_HBM_GBS, unit='GB/s', frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None,
                        bytes_per_launch=u['bytes'] / u['launches'], avg_launch_ms=round(u['ms'] / u['launches'], 5))
 
