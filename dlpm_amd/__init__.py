@@ -15,3 +15,4 @@ from .mlp import MLPModel  # noqa: F401
 from .generation import GenerationManager, ShapeProbe  # noqa: F401
 from .weights import rerandomize_  # noqa: F401
 from .config import load_config, is_image_dataset, init_model_by_parameter  # noqa: F401
+from . import checkpoint  # noqa: F401

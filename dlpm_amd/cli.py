@@ -2,7 +2,9 @@
 
 Covers the reference flags that reach the sampler (script_utils.py:11-12,35-39,56-67,82-83,155-221):
   --config --generate --reverse_steps --deterministic --clip --alpha --set_seed/--random_seed
-plus --checkpoint (a reference .pt file: TrainingManager.py:267-285), --ema_eval, --out.
+plus the checkpoint to evaluate, resolved like eval.py does (eval.py:21, bem/utils_exp.py:96-139):
+  --name N [--models_dir models] [--epoch E]  ->  models/N/<dataset>/model_<exphash>[_<E>].pt
+or given directly with --checkpoint FILE; --ema_eval [--ema_index I] evaluates an EMA shadow.
 Samples are produced in chunks of eval.batch_size like EvaluationManager (:181-193).
 """
 import argparse
@@ -28,7 +30,11 @@ def main(argv=None):
     ap.add_argument('--random_seed', action='store_true')
     ap.add_argument('--batch_size', type=int, default=None, help='eval.batch_size override')
     ap.add_argument('--checkpoint', default=None, help='reference checkpoint (.pt) with model_parameters / ema_models')
+    ap.add_argument('--name', default=None, help='experiment name: checkpoints are looked up under <models_dir>/<name>/')
+    ap.add_argument('--models_dir', default='models')
+    ap.add_argument('--epoch', type=int, default=None, help='checkpointed epoch to load (default: the latest)')
     ap.add_argument('--ema_eval', action='store_true')
+    ap.add_argument('--ema_index', type=int, default=0, help='which EMA shadow (order of training.<method>.ema_rates)')
     ap.add_argument('--synthetic_weights', type=int, default=None, metavar='SEED',
                     help='random init with the zero-initialised tensors re-drawn (benchmarks; NOT the reference init)')
     ap.add_argument('--rng', default='philox', choices=['philox', 'reference'])
@@ -57,14 +63,13 @@ def main(argv=None):
         np.random.seed(seed)
 
     model = dlpm_amd.init_model_by_parameter(p)
-    if a.checkpoint:
-        ck = torch.load(a.checkpoint, map_location='cpu')
-        if a.ema_eval and ck.get('ema_models'):
-            sd = model.state_dict()
-            sd.update(ck['ema_models'][0].get('shadow', ck['ema_models'][0]))
-            model.load_state_dict(sd)
-        else:
-            model.load_state_dict(ck['model_parameters'])
+    path = a.checkpoint
+    if path is None and a.name is not None:
+        path = dlpm_amd.checkpoint.find_checkpoint(p, os.path.join(a.models_dir, a.name), epoch=a.epoch)
+    if path:
+        epoch, steps = dlpm_amd.checkpoint.load_into(model, path, ema=a.ema_index if a.ema_eval else None)
+        print('loaded %s (epoch %s, %s steps%s)' % (path, epoch, steps, ', ema #%d' % a.ema_index if a.ema_eval else ''),
+              file=sys.stderr)
     elif a.synthetic_weights is not None:
         dlpm_amd.rerandomize_(model, a.synthetic_weights)
     method = dlpm_amd.init_method_by_parameter(p, rng=a.rng, seed=seed or 0)

@@ -17,6 +17,8 @@ Fixture families:
   F6 unet / mlp forward  UNetModel.forward, MLPModel.forward      dlpm/models/unet.py:463-492, Model.py:148-211
   F7 layers              GroupNorm32, QKVAttention, embedding...  dlpm/models/unet.py, nn.py
   F8 generation manager  clamp + inverse affine                   bem/GenerationManager.py:29-63
+  F9 checkpoints         TrainingManager.save/load, EMAHelper,    bem/TrainingManager.py:240-285, bem/utils_ema.py,
+                         FileHandler path hashing                 bem/utils_exp.py:52-151, dlpm/dlpm_experiment.py:11-19
 """
 import os
 import sys
@@ -25,9 +27,12 @@ import hashlib
 sys.dont_write_bytecode = True
 from unittest.mock import MagicMock
 
+import transformers  # noqa: F401  (must be imported before torchvision is stubbed: it probes for the package)
+from transformers import get_scheduler  # noqa: F401
+
 for _m in ['torchvision', 'torchvision.transforms', 'torchvision.transforms.functional',
-           'torchvision.datasets', 'torchvision.datasets.utils', 'torchvision.utils',
-           'imageio', 'torchquad']:
+           'torchvision.datasets', 'torchvision.datasets.utils', 'torchvision.utils', 'torchvision.models',
+           'imageio', 'torchquad', 'pyemd', 'prdc', 'prd', 'prd.prd_score', 'lmdb', 'thop', 'neptune']:
     sys.modules[_m] = MagicMock()
 REF = os.environ.get('DLPM_REFERENCE', '/root/reference')
 sys.path.insert(0, REF)
@@ -456,10 +461,109 @@ def f8_generation_manager():
     save('f8_generation_manager', **arrs)
 
 
+def f9_checkpoints():
+    """(a) known-answer experiment/eval hashes of the shipped configs and the file `eval.py` would pick in a
+    few directory layouts; (b) a checkpoint written by the reference's own TrainingManager.save for the toy
+    MLP with two EMA shadows, plus the reference net's outputs under the raw and each EMA weight set;
+    (c) a check that a file written by dlpm_amd.checkpoint.save_checkpoint is accepted by the reference's
+    TrainingManager.load (asserted here, nothing stored)."""
+    import json
+    import tempfile
+    import types
+    from pathlib import Path
+    import bem.utils_exp as ue
+    import dlpm.dlpm_experiment as de
+    from bem.TrainingManager import TrainingManager
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+
+    # ---- (a) hashes + path resolution
+    fh = ue.FileHandler(exp_hash=de.exp_hash)
+    info = {'hashes': {}, 'layouts': []}
+    for n in ['cifar10', 'mnist', '2d_data', 'cifar10_lt']:
+        p = ue.FileHandler.get_param_from_config(os.path.join(REF, 'dlpm', 'configs'), n + '.yml')
+        info['hashes'][n] = [fh.get_exp_hash(p), fh.get_eval_hash(p)]
+        p2 = yaml.safe_load(yaml.safe_dump(p))
+        p2['dlpm']['alpha'] = 1.7                              # what --alpha 1.7 does before hashing
+        info['hashes'][n + '@alpha1.7'] = [fh.get_exp_hash(p2), fh.get_eval_hash(p2)]
+    p = ue.FileHandler.get_param_from_config(os.path.join(REF, 'dlpm', 'configs'), 'mnist.yml')
+    h = fh.get_exp_hash(p)
+    for files, epoch in [(['model_%s_300.pt', 'model_%s_900.pt', 'model_%s_600.pt'], None),
+                         (['model_%s.pt'], None),
+                         (['model_%s.pt', 'model_%s_40.pt'], None),
+                         (['model_%s_300.pt', 'model_%s_900.pt'], 300),
+                         (['model_%s_300.pt', 'parameters_%s.pt', 'eval_%s.pt', 'model_0123456789abcdef_1200.pt'], None)]:
+        with tempfile.TemporaryDirectory() as d:
+            os.makedirs(os.path.join(d, 'mnist'))
+            for f in files:
+                Path(os.path.join(d, 'mnist', f % h if '%s' in f else f)).touch()
+            model_path, param_path, eval_path = fh.get_paths_from_param(p, d, curr_epoch=epoch)
+            ev_model, ev_param, ev_eval = fh.get_paths_from_param(p, d, curr_epoch=epoch, new_eval_subdir=True)
+            info['layouts'].append(dict(config='mnist', files=[f % h if '%s' in f else f for f in files], epoch=epoch,
+                                        model=os.path.relpath(model_path, d), eval_dir=os.path.relpath(os.path.dirname(ev_eval), d)))
+    with open(os.path.join(OUT, 'f9_paths.json'), 'w') as f:
+        json.dump(info, f, indent=1, sort_keys=True)
+    print('wrote f9_paths.json')
+
+    # ---- (b) the reference's writer on the toy MLP
+    p = yaml.safe_load(open(os.path.join(REF, 'dlpm', 'configs', '2d_data.yml')))
+    p['device'] = 'cpu'
+    torch.manual_seed(7)
+    with torch.enable_grad():
+        net = ref_mlp.MLPModel(p)
+        opt = torch.optim.AdamW(net.parameters(), lr=5e-3)
+        ev = types.SimpleNamespace(logger=None)
+        method = types.SimpleNamespace(device='cpu')
+        tm = TrainingManager({'default': net}, None, method, {'default': opt}, {'default': None}, ev, ema_rates=[0.9, 0.5])
+        g = torch.Generator().manual_seed(11)
+        for it in range(3):                                    # three "training" steps: real gradients, real EMA updates
+            x = torch.randn(16, 1, 2, generator=g)
+            t = torch.rand(16, generator=g)
+            loss = (net(x, t) - x).pow(2).mean()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            for e in tm.ema_objects:
+                e['default'].update(net)
+        tm.epochs, tm.total_steps = 3, 3
+    path = os.path.join(OUT, 'f9_checkpoint_mlp.pt')
+    tm.save(path)
+    net.eval()
+    x = torch.randn(8, 1, 2, generator=g) * 3
+    t = torch.rand(8, generator=g)
+    arrs = dict(x=x, t=t, y_raw=net(x, t))
+    for i, e in enumerate(tm.ema_objects):
+        m = e['default'].get_ema_model().eval()
+        arrs['y_ema%d' % i] = m(x, t)
+        arrs['mu%d' % i] = np.float64(e['default'].mu)
+    assert not torch.equal(arrs['y_raw'], arrs['y_ema0']) and not torch.equal(arrs['y_ema0'], arrs['y_ema1'])
+    save('f9_checkpoint_mlp_io', **arrs)
+    print('wrote f9_checkpoint_mlp.pt %8.1f kB' % (os.path.getsize(path) / 1e3))
+
+    # ---- (c) our writer -> the reference's loader
+    from dlpm_amd import checkpoint as ck
+    import dlpm_amd
+    mine = dlpm_amd.MLPModel(p)
+    mine.load_state_dict(net.state_dict())
+    shadows = [dict(e['default'].shadow) for e in tm.ema_objects]
+    with tempfile.TemporaryDirectory() as d:
+        f = ck.save_checkpoint(os.path.join(d, 'model_x.pt'), {'default': mine}, epoch=5, steps=50,
+                               ema_shadows={'default': shadows})
+        torch.manual_seed(8)
+        net2 = ref_mlp.MLPModel(p)
+        tm2 = TrainingManager({'default': net2}, None, method, {'default': None}, {'default': None}, ev, ema_rates=[0.9, 0.5])
+        tm2.load(f)
+        assert tm2.epochs == 5 and tm2.total_steps == 50
+        for (k, a), (_, b) in zip(net.state_dict().items(), net2.state_dict().items()):
+            assert torch.equal(a, b), k
+        for e, s in zip(tm2.ema_objects, shadows):
+            assert all(torch.equal(e['default'].shadow[k], s[k]) for k in s)
+    print('reference TrainingManager.load accepted a dlpm_amd.checkpoint.save_checkpoint file')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f5u', 'f6', 'f7', 'f8']
+    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f5u', 'f6', 'f7', 'f8', 'f9']
     table = dict(f1=f1_schedule, f2=f2_noise, f3=f3_tables, f4=f4_single_step, f5=f5_trajectories, f5u=f5_unet_trajectory,
-                 f6=f6_models, f7=f7_layers, f8=f8_generation_manager)
+                 f6=f6_models, f7=f7_layers, f8=f8_generation_manager, f9=f9_checkpoints)
     with torch.no_grad():
         for w in which:
             table[w]()
