@@ -13,6 +13,7 @@ from .process import DLPM  # noqa: F401
 from .unet import UNetModel, unet_from_config  # noqa: F401
 from .mlp import MLPModel  # noqa: F401
 from .generation import GenerationManager, ShapeProbe  # noqa: F401
+from .evaluation import EvaluationManager, ImageDump  # noqa: F401
 from .weights import rerandomize_  # noqa: F401
 from .config import load_config, is_image_dataset, init_model_by_parameter  # noqa: F401
 from . import checkpoint  # noqa: F401

@@ -60,6 +60,10 @@ SIGNATURES = {
     'dlpm_update_f32': (C.c_int, [C.POINTER(UpdateArgs), vp]),
     'dlpm_fill_scaled_t_f32': (C.c_int, [vp, vp, i32, i64, vp]),
     'dlpm_postprocess_f32': (C.c_int, [vp, vp, i64, f32, C.c_int, vp]),
+    'dlpm_images_to_rgb8': (C.c_int, [vp, vp, i64, i32, i32, i32, vp]),
+    'dlpm_png_bound': (i64, [i32, i32]),
+    'dlpm_png_encode_rgb8': (C.c_int, [vp, i32, i32, i32, vp, i64, C.POINTER(i64)]),
+    'dlpm_png_write_rgb8': (C.c_int, [vp, i64, i32, i32, C.c_char_p, i64, i32, i32]),
     'dlpm_unet_create': (C.c_int, [C.POINTER(UNetConfig), C.POINTER(vp)]),
     'dlpm_unet_set_param': (C.c_int, [vp, C.c_char_p, vp, i64]),
     'dlpm_unet_num_params': (C.c_int, [vp]),

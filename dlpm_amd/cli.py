@@ -39,6 +39,11 @@ def main(argv=None):
                     help='random init with the zero-initialised tensors re-drawn (benchmarks; NOT the reference init)')
     ap.add_argument('--rng', default='philox', choices=['philox', 'reference'])
     ap.add_argument('--out', default=None, help='.npy file for the generated samples')
+    ap.add_argument('--gen_data_path', default=None,
+                    help='directory for <i>.png files (EvaluationManager image dump); images only')
+    ap.add_argument('--device_batch', type=int, default=None,
+                    help='with --gen_data_path and --rng philox: sample in chunks of at least this many images '
+                         '(pixels do not depend on the chunking)')
     a = ap.parse_args(argv)
 
     p = dlpm_amd.load_config(a.config)
@@ -75,6 +80,14 @@ def main(argv=None):
     method = dlpm_amd.init_method_by_parameter(p, rng=a.rng, seed=seed or 0)
     is_image = dlpm_amd.is_image_dataset(p['data']['dataset'])
     gm = dlpm_amd.GenerationManager(method, dlpm_amd.ShapeProbe(sample_shape(p)), is_image, **p['eval'][m])
+    if a.gen_data_path:
+        assert is_image, '--gen_data_path dumps images; 2-D data has no image form'
+        ev = dlpm_amd.EvaluationManager(method, gm, None, is_image=True, gen_data_path=a.gen_data_path,
+                                        device_batch=a.device_batch)
+        r = ev.evaluate_model({'default': model}, data_to_generate=p['eval']['data_to_generate'],
+                              batch_size=p['eval']['batch_size'])
+        print('wrote %d png files to %s' % (r['generated'], r['gen_data_path']))
+        return r
     remaining, chunks = p['eval']['data_to_generate'], []
     while remaining > 0:                                    # EvaluationManager.py:181-193
         n = min(p['eval']['batch_size'], remaining)

@@ -32,18 +32,19 @@ class GenerationManager:
         self.samples = []
         self.history = []
 
-    def _post(self, x):
-        """clamp + (x+1)/2 in one HIP kernel, then the D2H copy."""
+    def _post(self, x, to_host=True):
+        """clamp + (x+1)/2 in one HIP kernel, then the D2H copy (skipped when the caller keeps the samples on
+        the GPU, e.g. dlpm_amd.EvaluationManager's image dump)."""
         clamp = 1.0 if self.is_image else 6.0
         if x.is_cuda:
             x = x.contiguous().float()
             out = torch.empty_like(x)
             _lib.check(_lib.lib().dlpm_postprocess_f32(x.data_ptr(), out.data_ptr(), x.numel(), clamp,
                                                       1 if self.is_image else 0, _lib.stream_ptr()))
-            return out.cpu()
+            return out.cpu() if to_host else out
         raise _lib.DlpmError('GenerationManager expects samples on the GPU; there is no CPU fallback')
 
-    def generate(self, models, nsamples, get_sample_history=False, print_progression=False, **kwargs):
+    def generate(self, models, nsamples, get_sample_history=False, print_progression=False, to_host=True, **kwargs):
         assert nsamples > 0, 'nsamples must be greater than 0, got {}'.format(nsamples)
         tmp_kwargs = copy.deepcopy(self.kwargs)
         tmp_kwargs.update(kwargs)
@@ -55,9 +56,9 @@ class GenerationManager:
         nfeat = data.shape[-1]
         if get_sample_history:
             _, hist = x
-            self.samples = self._post(hist[-1, ..., :nfeat])
-            self.history = self._post(hist[..., :nfeat])
+            self.samples = self._post(hist[-1, ..., :nfeat], to_host)
+            self.history = self._post(hist[..., :nfeat], to_host)
         else:
-            self.samples = self._post(x[..., :nfeat])
+            self.samples = self._post(x[..., :nfeat], to_host)
             self.history = []
         return self.samples

@@ -16,6 +16,7 @@ Two RNG modes:
                    randn) regenerated on the host by libdlpm_amd and uploaded, for parity with the
                    reference CPU path on identical seeds.
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -96,6 +97,7 @@ class GenerativeLevyProcess:
                          scale=scale)
         self._samplers = {}
         self.calls = 0          # number of sample() calls so far: folded into the Philox key
+        self._dataset = None    # see dataset_stream()
 
     # -------------------------------------------------------------------------------- helpers
     def _scale_timesteps(self, t):
@@ -106,12 +108,33 @@ class GenerativeLevyProcess:
     def get_timesteps(self, N, **kwargs):
         return self.dlpm.get_timesteps(N)
 
+    def _philox_key(self):
+        """(seed, first global sample index) of the next sample() call."""
+        calls, first = (self._dataset['calls'], self._dataset['next']) if self._dataset else (self.calls, 0)
+        return (self.seed + 0x9E3779B97F4A7C15 * calls) & 0xFFFFFFFFFFFFFFFF, self.sample_offset + first
+
+    @contextlib.contextmanager
+    def dataset_stream(self, first_index=0):
+        """Inside this context every sample() call continues ONE Philox stream indexed by the running sample
+        count, so the i-th generated sample does not depend on how the G samples are cut into chunks
+        (EvaluationManager's eval.batch_size loop) or split over ranks.  Outside it each call draws a fresh
+        stream, as successive reference calls do.  No effect with rng='reference' (the MT19937 streams
+        simply continue, which is the reference's behaviour)."""
+        assert self._dataset is None, 'dataset_stream() does not nest'
+        self._dataset = dict(calls=self.calls, next=first_index)
+        try:
+            yield self
+        finally:
+            self._dataset = None
+            self.calls += 1
+
     def _streams(self):
         if self.reference_streams is None:
             self.reference_streams = ReferenceStreams(self.seed, self.seed)
         return self.reference_streams
 
-    def _native_sampler(self, model, shape, flags, eta, clamp_a, clamp_eps, seed):
+    def _native_sampler(self, model, shape, flags, eta, clamp_a, clamp_eps, seed, offset=None):
+        offset = self.sample_offset if offset is None else offset
         from .unet import UNetModel
         B = shape[0]
         if isinstance(model, UNetModel):
@@ -123,10 +146,10 @@ class GenerativeLevyProcess:
             dims = (1, 1, shape[2])
             handles = dict(unet=None, mlp=model.native_handle())
         key = (id(model), handles['unet'].value if handles['unet'] else handles['mlp'].value, tuple(shape),
-               self.reverse_steps, self.alpha, flags, eta, clamp_a, clamp_eps, self.sample_offset, self.use_graph, self.fused_mlp)
+               self.reverse_steps, self.alpha, flags, eta, clamp_a, clamp_eps, self.use_graph, self.fused_mlp)
         ent = self._samplers.get(key)
         if ent is not None:
-            _lib.check(_lib.lib().dlpm_sampler_reseed(ent['h'], seed, self.sample_offset))
+            _lib.check(_lib.lib().dlpm_sampler_reseed(ent['h'], seed, offset))
             return ent['h']
         # one live native sampler per method object: they own activation workspaces sized for B
         for k in list(self._samplers):
@@ -145,7 +168,7 @@ class GenerativeLevyProcess:
             # launch-bound MLP (4 launches per step) unless the caller asked for a specific count
             gs = self.use_graph if isinstance(self.use_graph, int) and not isinstance(self.use_graph, bool) else (
                 1 if handles['unet'] else 33)
-        cfg.sample_offset, cfg.use_graph = self.sample_offset, gs
+        cfg.sample_offset, cfg.use_graph = offset, gs
         sched = self.dlpm.host_schedule
         cfg.g, cfg.bg, cfg.s, cfg.bs = (v.data_ptr() for v in sched)
         h = C.c_void_p()
@@ -182,8 +205,8 @@ class GenerativeLevyProcess:
     def _run_native(self, model, shape, flags, eta, clamp_a, clamp_eps, noise, history, progress):
         L, st = _lib.lib(), _lib.stream_ptr()
         T = self.reverse_steps
-        seed = (self.seed + 0x9E3779B97F4A7C15 * self.calls) & 0xFFFFFFFFFFFFFFFF
-        h = self._native_sampler(model, shape, flags, eta, clamp_a, clamp_eps, seed)
+        seed, offset = self._philox_key()
+        h = self._native_sampler(model, shape, flags, eta, clamp_a, clamp_eps, seed, offset)
         dev = torch.device(self.device)
         x = torch.empty(shape, dtype=torch.float32, device=dev)
         hist = []
@@ -236,7 +259,7 @@ class GenerativeLevyProcess:
         T, B = self.reverse_steps, shape[0]
         D = int(np.prod(shape[1:]))
         dev = torch.device(self.device)
-        seed = (self.seed + 0x9E3779B97F4A7C15 * self.calls) & 0xFFFFFFFFFFFFFFFF
+        seed, offset = self._philox_key()
         g, bg, s, bs = (v.to(dev) for v in self.dlpm.host_schedule)
         ca = -1.0 if clamp_a is None else float(clamp_a)
         ce = -1.0 if clamp_eps is None else float(clamp_eps)
@@ -247,9 +270,9 @@ class GenerativeLevyProcess:
         else:
             A = torch.empty((T, B), dtype=torch.float32, device=dev)
             x = torch.empty(shape, dtype=torch.float32, device=dev)
-            _lib.check(L.dlpm_skewed_levy_philox_f32(A.data_ptr(), T, B, float(self.alpha), ca, seed, self.sample_offset, st))
+            _lib.check(L.dlpm_skewed_levy_philox_f32(A.data_ptr(), T, B, float(self.alpha), ca, seed, offset, st))
             _lib.check(L.dlpm_init_state_philox_f32(x.data_ptr(), B, D, float(self.alpha), ce,
-                                                   float(self.dlpm.host_schedule[3][-1]), seed, self.sample_offset, st))
+                                                   float(self.dlpm.host_schedule[3][-1]), seed, offset, st))
         c_eps, c_noise = torch.empty_like(A), torch.empty_like(A)
         _lib.check(L.dlpm_coeff_tables_f32(A.data_ptr(), g.data_ptr(), s.data_ptr(), bs.data_ptr(), T, B,
                                           c_eps.data_ptr(), c_noise.data_ptr(), None, st))
@@ -261,7 +284,7 @@ class GenerativeLevyProcess:
         args.t_dev, args.g_dev, args.bg_dev, args.bs_dev = t_dev.data_ptr(), g.data_ptr(), bg.data_ptr(), bs.data_ptr()
         args.c_eps_dev, args.c_noise_dev, args.A_dev = c_eps.data_ptr(), c_noise.data_ptr(), A.data_ptr()
         args.B, args.D, args.T, args.flags, args.dlim_eta, args.alpha = B, D, T, flags, float(eta), float(self.alpha)
-        args.seed, args.sample_offset = seed, self.sample_offset
+        args.seed, args.sample_offset = seed, offset
         pbar = None
         if progress:
             from tqdm import tqdm
@@ -310,7 +333,10 @@ class GenerativeLevyProcess:
         run = self._run_native if native else self._run_callable
         with torch.inference_mode():
             out = run(model, shape, flags, eta, clamp_a, clamp_eps, noise, get_sample_history, print_progression)
-        self.calls += 1
+        if self._dataset is not None:
+            self._dataset['next'] += shape[0]
+        else:
+            self.calls += 1
         return out
 
     def training_losses(self, *a, **k):

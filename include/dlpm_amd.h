@@ -35,7 +35,8 @@ enum dlpm_status {
     DLPM_ERR_HIP = -2,     /* HIP runtime error; message carries hipGetErrorString */
     DLPM_ERR_UNSUPPORTED = -3,
     DLPM_ERR_STATE = -4,   /* call order (e.g. forward before finalize) */
-    DLPM_ERR_NOMEM = -5    /* workspace too small */
+    DLPM_ERR_NOMEM = -5,   /* workspace too small */
+    DLPM_ERR_IO = -6       /* host file I/O (image dump) */
 };
 
 const char *dlpm_last_error(void);
@@ -147,6 +148,29 @@ int dlpm_fill_scaled_t_f32(float *tvec_dev, const int32_t *t_dev, int32_t T, int
 /* samples_dev <- clamp(x, -c, c) then (x+1)/2 for images: GenerationManager.generate post-processing,
  * bem/GenerationManager.py:50-63, bem/datasets/__init__.py:108-109. */
 int dlpm_postprocess_f32(const float *x_dev, float *out_dev, int64_t n, float clamp, int affine, dlpm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Generated-image dump: what EvaluationManager does with each chunk of samples,
+ * bem/evaluate/EvaluationManager.py:174-196 -- `tvu.save_image(samples[i], f"{i+total}.png")` per sample.
+ * ------------------------------------------------------------------------------------------ */
+
+/* [B,C,H,W] fp32 images in [0,1] (the output of dlpm_postprocess_f32) -> [B,H,W,3] bytes with
+ * torchvision.utils.save_image's quantisation: mul(255).add_(0.5).clamp_(0,255).to(uint8), a 1-channel
+ * image replicated to RGB as make_grid does.  C must be 1 or 3.  HBM-bound: 4*C + 3 bytes per pixel. */
+int dlpm_images_to_rgb8(const float *x_dev, uint8_t *out_dev, int64_t B, int32_t C, int32_t H, int32_t W,
+                        dlpm_stream_t stream);
+
+/* [host] upper bound of one encoded H x W RGB PNG, in bytes (-1 on bad arguments). */
+int64_t dlpm_png_bound(int32_t H, int32_t W);
+
+/* [host] one H x W x 3 byte image -> PNG stream (8-bit truecolour, zlib `level` 0..9) in out[0..*len). */
+int dlpm_png_encode_rgb8(const uint8_t *hwc, int32_t H, int32_t W, int32_t level, uint8_t *out, int64_t cap,
+                         int64_t *len);
+
+/* [host] B images -> files `<dir>/<first_index + i>.png` (the reference's naming, EvaluationManager.py:190),
+ * encoded and written by `nthreads` host threads.  Blocks until all files are closed. */
+int dlpm_png_write_rgb8(const uint8_t *hwc_batch, int64_t B, int32_t H, int32_t W, const char *dir,
+                        int64_t first_index, int32_t level, int32_t nthreads);
 
 /* ------------------------------------------------------------------------------------------
  * Score networks
