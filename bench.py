@@ -95,6 +95,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='skip the instrumented eager pass (roofline = null)')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--non-iso', action='store_true',
+                    help='non-isotropic noise variant (--non_iso of the reference): [T,B,D] tables; not the headline config')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -124,7 +126,7 @@ def main():
     shape = [B, p['data']['channels'], p['data']['image_size'], p['data']['image_size']]
     ev = p['eval']['dlpm']
     meth = dlpm_amd.GenerativeLevyProcess(alpha, str(dev), T, rescale_timesteps=True, seed=0, sample_offset=rank * B,
-                                          use_graph=not args.no_graph)
+                                          use_graph=not args.no_graph, isotropic=not args.non_iso)
     st = _lib.stream_ptr()
     h = meth._native_sampler(net, shape, 0, 0.0, ev['clamp_a'], ev['clamp_eps'], 0)
     flops_per_sample = net.flops_per_sample(shape[2])
@@ -208,7 +210,7 @@ def main():
             'metric': METRIC[cfg_name], 'value': round(value, 4),
             'unit': 'samples/s', 'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(ms_per_step, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': args.workload, 'state_shape_per_gpu': shape, 'global_batch': B * world,
+            'config': {'workload': args.workload + ('+non_iso' if args.non_iso else ''), 'state_shape_per_gpu': shape, 'global_batch': B * world,
                        'reverse_steps': T, 'alpha': alpha, 'timed_steps': K, 'trajectory_steps': T - 1,
                        'init_ms': round(init_s * 1e3, 3), 'allgather_ms': round(gather_s * 1e3, 3),
                        'net': 'reference cifar10.yml UNet (mc=128, 39.6M params), random init + re-drawn zero tensors'

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libdlpm_amd.so')
 
 vp, i32, i64, u32, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
 
-UPD_DLIM, UPD_CLIP, UPD_ADVANCE, SMP_NO_FUSED_MLP = 1, 2, 4, 8
+UPD_DLIM, UPD_CLIP, UPD_ADVANCE, SMP_NO_FUSED_MLP, UPD_ELEMENTWISE = 1, 2, 4, 8, 16
 
 
 class MT19937(C.Structure):
@@ -22,7 +22,8 @@ class MT19937(C.Structure):
 class UpdateArgs(C.Structure):
     _fields_ = [('x_dev', vp), ('eps_dev', vp), ('z_dev', vp), ('t_dev', vp), ('g_dev', vp), ('bg_dev', vp),
                 ('bs_dev', vp), ('c_eps_dev', vp), ('c_noise_dev', vp), ('A_dev', vp), ('B', i64), ('D', i64),
-                ('T', i32), ('flags', i32), ('dlim_eta', f32), ('alpha', f32), ('seed', u64), ('sample_offset', i64), ('key_dev', vp)]
+                ('T', i32), ('flags', i32), ('dlim_eta', f32), ('alpha', f32), ('seed', u64), ('sample_offset', i64), ('key_dev', vp),
+                ('hist_pp', vp)]
 
 
 class UNetConfig(C.Structure):
@@ -55,6 +56,8 @@ SIGNATURES = {
     'dlpm_skewed_levy_host_f32': (C.c_int, [C.POINTER(MT19937), f64, i64, f64, vp]),
     'dlpm_randn_host_f32': (C.c_int, [C.POINTER(MT19937), i64, vp]),
     'dlpm_skewed_levy_philox_f32': (C.c_int, [vp, C.c_int, i64, f64, f64, u64, i64, vp]),
+    'dlpm_skewed_levy_elem_philox_f32': (C.c_int, [vp, C.c_int, i64, i64, f64, f64, u64, i64, vp]),
+    'dlpm_init_state_elem_philox_f32': (C.c_int, [vp, i64, i64, f64, f64, f32, u64, i64, vp]),
     'dlpm_init_state_philox_f32': (C.c_int, [vp, i64, i64, f64, f64, f32, u64, i64, vp]),
     'dlpm_coeff_tables_f32': (C.c_int, [vp, vp, vp, vp, C.c_int, i64, vp, vp, vp, vp]),
     'dlpm_update_f32': (C.c_int, [C.POINTER(UpdateArgs), vp]),
@@ -94,6 +97,7 @@ SIGNATURES = {
     'dlpm_sampler_begin_injected': (C.c_int, [vp, vp, vp, vp]),
     'dlpm_sampler_step_injected': (C.c_int, [vp, vp, vp]),
     'dlpm_sampler_steps': (C.c_int, [vp, i32, vp]),
+    'dlpm_sampler_set_history': (C.c_int, [vp, vp, vp]),
     'dlpm_sampler_copy_state': (C.c_int, [vp, vp, vp]),
     'dlpm_sampler_state': (vp, [vp]),
     'dlpm_sampler_t': (i32, [vp]),

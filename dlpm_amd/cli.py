@@ -1,7 +1,7 @@
 """`eval.py --generate`-compatible command line for the sampling path (no dataset / neptune needed).
 
 Covers the reference flags that reach the sampler (script_utils.py:11-12,35-39,56-67,82-83,155-221):
-  --config --generate --reverse_steps --deterministic --clip --alpha --set_seed/--random_seed
+  --config --generate --reverse_steps --deterministic --clip --alpha --non_iso --set_seed/--random_seed
 plus the checkpoint to evaluate, resolved like eval.py does (eval.py:21, bem/utils_exp.py:96-139):
   --name N [--models_dir models] [--epoch E]  ->  models/N/<dataset>/model_<exphash>[_<E>].pt
 or given directly with --checkpoint FILE; --ema_eval [--ema_index I] evaluates an EMA shadow.
@@ -24,6 +24,7 @@ def main(argv=None):
     ap.add_argument('--generate', type=int, default=None, help='number of samples (eval.data_to_generate)')
     ap.add_argument('--reverse_steps', type=int, default=None)
     ap.add_argument('--alpha', type=float, default=None)
+    ap.add_argument('--non_iso', action='store_true', help='non-isotropic noise (script_utils.py:26-27)')
     ap.add_argument('--deterministic', action='store_true', help='DLIM sampling')
     ap.add_argument('--clip', action='store_true', help='clip_denoised')
     ap.add_argument('--set_seed', type=int, default=None)
@@ -51,6 +52,8 @@ def main(argv=None):
     m = p['method']
     if a.alpha is not None:
         p[m]['alpha'] = a.alpha
+    if a.non_iso:
+        p[m]['isotropic'] = False
     if a.generate is not None:
         assert a.generate <= p['eval']['real_data'], 'cannot generate more data than the number of real data'
         p['eval']['data_to_generate'] = a.generate

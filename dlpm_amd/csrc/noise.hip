@@ -17,6 +17,8 @@ constexpr int kPurposeA = 1;       // rows of A[T,B]
 constexpr int kPurposeInitA = 2;   // the unclamped a of gen_sas
 constexpr int kPurposeInitZ = 3;   // x_T normals
 constexpr int kPurposeStepZ = 4;   // per-step normals
+constexpr int kPurposeAElem = 5;     // non-isotropic: A[T,B,D], counter = (sample, element, purpose | t << 8)
+constexpr int kPurposeInitAElem = 6; // non-isotropic: the unclamped per-element a of gen_sas
 
 // CMS in fp64, S1 parameterisation, beta = 1, stability a = alpha/2, as scipy's _rvs_Z1 "otherwise"
 // branch; U uniform(0,1), W standard exponential.
@@ -30,8 +32,8 @@ __device__ inline double cms_skewed(double a, double zeta, double th0, double sc
 }
 
 __device__ inline float draw_skewed(uint64_t seed, uint64_t gidx, uint32_t row, uint32_t purpose, double a,
-                                    double zeta, double th0, double scale) {
-    uint4 r = philox4x32_10(make_uint4((uint32_t)gidx, (uint32_t)(gidx >> 32), row, purpose), seed);  // step field 0
+                                    double zeta, double th0, double scale, uint32_t step = 0) {
+    uint4 r = philox4x32_10(make_uint4((uint32_t)gidx, (uint32_t)(gidx >> 32), row, purpose | (step << 8)), seed);
     // 53-bit uniforms in (0,1): never 0 or 1, so th stays inside (-pi/2, pi/2) and W is finite
     double U = ((double)(((uint64_t)r.x << 21) ^ (r.y >> 11)) + 0.5) * (1.0 / 9007199254740992.0);
     double V = ((double)(((uint64_t)r.z << 21) ^ (r.w >> 11)) + 0.5) * (1.0 / 9007199254740992.0);
@@ -86,7 +88,53 @@ __global__ void k_init_state(float *x, int64_t B, int64_t D, double alpha, float
     }
 }
 
+// Non-isotropic noise (`--non_iso`): one independent skewed-Levy draw per ELEMENT (Distributions.py:47-48).
+// A[T,B,D]; thread i -> (t, b, e), coalesced stores; keyed by (sample, element, t) so shards agree.
+__global__ void k_skewed_levy_elem(float *A, int T, int64_t B, int64_t D, double alpha, float clamp_a, int has_clamp,
+                                   uint64_t seed, int64_t off) {
+    const int64_t n = (int64_t)T * B * D;
+    const double pi = 3.141592653589793;
+    const double a = alpha * 0.5, zeta = tan(pi * a * 0.5), th0 = atan(zeta) / a;
+    const double scale = 2.0 * pow(cos(pi * alpha * 0.25), 2.0 / alpha);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t tb = i / D, e = i - tb * D;
+        const int t = (int)(tb / B);
+        const int64_t b = tb - (int64_t)t * B;
+        float v = 2.0f;
+        if (alpha != 2.0) {
+            v = draw_skewed(seed, (uint64_t)(off + b), (uint32_t)e, kPurposeAElem, a, zeta, th0, scale, (uint32_t)t);
+            if (has_clamp) v = fminf(fmaxf(v, 0.0f), clamp_a);
+        }
+        A[i] = v;
+    }
+}
+
+// x_T[b, e] = bs_last * clamp(sqrt(a0[b, e]) * z[b, e]) with a per-element unclamped a0
+__global__ void k_init_state_elem(float *x, int64_t B, int64_t D, double alpha, float clamp_eps, int has_clamp,
+                                  float bs_last, uint64_t seed, int64_t off) {
+    int64_t nq = (D + 3) / 4;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * nq) return;
+    int64_t b = i / nq, q = i - b * nq;
+    const double pi = 3.141592653589793;
+    const double a = alpha * 0.5, zeta = tan(pi * a * 0.5), th0 = atan(zeta) / a;
+    const double scale = 2.0 * pow(cos(pi * alpha * 0.25), 2.0 / alpha);
+    float4 z = philox_normal4(seed, (uint64_t)(off + b), (uint32_t)q, kPurposeInitZ, 0u);
+    float zz[4] = {z.x, z.y, z.z, z.w};
+    for (int j = 0; j < 4; j++) {
+        int64_t e = q * 4 + j;
+        if (e < D) {
+            float a0 = alpha == 2.0 ? 2.0f
+                                    : draw_skewed(seed, (uint64_t)(off + b), (uint32_t)e, kPurposeInitAElem, a, zeta, th0, scale);
+            float v = sqrtf(a0) * zz[j];
+            if (has_clamp) v = fminf(fmaxf(v, -clamp_eps), clamp_eps);
+            x[b * D + e] = bs_last * v;
+        }
+    }
+}
+
 // One thread per sample walks t = 0..T-1 (a scan over t; T*B FMAs in total).
+// c_eps may alias A (each thread reads A[t,b] before it writes c_eps[t,b]).
 __global__ void k_coeff_tables(const float *A, const float *g, const float *s, const float *bs, int T, int64_t B,
                                float *c_eps, float *c_noise, float *sig_out) {
     int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -142,6 +190,8 @@ __global__ void __launch_bounds__(256) k_update(dlpm_update_args p) {
     }
     const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float *hist = p.hist_pp ? *p.hist_pp : nullptr;
+    if (hist) hist += (int64_t)(p.T - t) * p.B * D;
     if (VEC) {
         for (int64_t base_i = tid0; base_i < total; base_i += nthreads * UNROLL) {
             float4 x[UNROLL], e[UNROLL], z[UNROLL];
@@ -182,7 +232,10 @@ __global__ void __launch_bounds__(256) k_update(dlpm_update_args p) {
                     if (dlim) m = __fadd_rn(m, __fmul_rn(dl_mean, ee));
                     o[j] = __fadd_rn(m, __fmul_rn(cn[u], zv[j]));
                 }
-                if (ok[u]) *reinterpret_cast<float4 *>(p.x_dev + b[u] * D + q[u] * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                if (ok[u]) {
+                    *reinterpret_cast<float4 *>(p.x_dev + b[u] * D + q[u] * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (hist) *reinterpret_cast<float4 *>(hist + b[u] * D + q[u] * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                }
             }
         }
     } else {
@@ -208,7 +261,84 @@ __global__ void __launch_bounds__(256) k_update(dlpm_update_args p) {
             float ee = clip ? clip_eps(xv, ev, c) : ev;
             float m = __fdiv_rn(xv - __fmul_rn(ce, ee), c.g);
             if (dlim) m = __fadd_rn(m, __fmul_rn(dl_mean, ee));
-            p.x_dev[idx] = __fadd_rn(m, __fmul_rn(cn, zv));
+            const float o = __fadd_rn(m, __fmul_rn(cn, zv));
+            p.x_dev[idx] = o;
+            if (hist) hist[idx] = o;
+        }
+    }
+}
+
+// Non-isotropic variant (DLPM_UPD_ELEMENTWISE): c_eps / c_noise / A are [T,B,D] and are streamed like x and eps
+// (20 B/element with Philox noise).  Same arithmetic as k_update, element by element.
+template <bool VEC>
+__global__ void __launch_bounds__(256) k_update_elem(dlpm_update_args p) {
+    constexpr int W = VEC ? 4 : 1;
+    if (p.key_dev) { p.seed = p.key_dev[0]; p.sample_offset = (int64_t)p.key_dev[1]; }
+    const int t = *p.t_dev;
+    StepScalars c{p.g_dev[t], p.bg_dev[t], p.bs_dev[t], p.bs_dev[t > 0 ? t - 1 : 0]};
+    const bool dlim = p.flags & DLPM_UPD_DLIM, clip = p.flags & DLPM_UPD_CLIP;
+    const int64_t D = p.D, BD = p.B * D;
+    float dl_mean = c.bs_prev, dl_sig = 0.f;
+    if (dlim && p.dlim_eta != 0.0f) {
+        dl_sig = p.dlim_eta * c.bs_prev;
+        dl_mean = powf(powf(c.bs_prev, p.alpha) - powf(dl_sig, p.alpha), 1.0f / p.alpha);
+    }
+    float *hist = p.hist_pp ? *p.hist_pp : nullptr;
+    if (hist) hist += (int64_t)(p.T - t) * BD;
+    const float *ce_t = dlim ? nullptr : p.c_eps_dev + (int64_t)t * BD;
+    const float *cn_t = dlim ? nullptr : p.c_noise_dev + (int64_t)t * BD;
+    const float *a_t = (dlim && p.dlim_eta != 0.0f) ? p.A_dev + (int64_t)t * BD : nullptr;
+    const int64_t items = BD / W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t off = i * W;
+        const int64_t b = off / D, e0 = off - b * D;
+        float xv[W], ev[W], zv[W], ce[W], cn[W];
+        if (VEC) {
+            *reinterpret_cast<float4 *>(xv) = *reinterpret_cast<const float4 *>(p.x_dev + off);
+            *reinterpret_cast<float4 *>(ev) = *reinterpret_cast<const float4 *>(p.eps_dev + off);
+            if (p.z_dev) *reinterpret_cast<float4 *>(zv) = *reinterpret_cast<const float4 *>(p.z_dev + off);
+            if (ce_t) {
+                *reinterpret_cast<float4 *>(ce) = *reinterpret_cast<const float4 *>(ce_t + off);
+                *reinterpret_cast<float4 *>(cn) = *reinterpret_cast<const float4 *>(cn_t + off);
+            } else if (a_t) {
+                *reinterpret_cast<float4 *>(cn) = *reinterpret_cast<const float4 *>(a_t + off);
+            }
+        } else {
+            xv[0] = p.x_dev[off];
+            ev[0] = p.eps_dev[off];
+            if (p.z_dev) zv[0] = p.z_dev[off];
+            if (ce_t) { ce[0] = ce_t[off]; cn[0] = cn_t[off]; }
+            else if (a_t) cn[0] = a_t[off];
+        }
+        if (dlim) {
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                ce[j] = c.bs;
+                cn[j] = (a_t && t != 1) ? dl_sig * sqrtf(cn[j]) : 0.0f;
+            }
+        }
+        if (!p.z_dev) {
+            const bool need = dlim ? (a_t && t != 1) : (t != 1);
+            float4 z = need ? philox_normal4(p.seed, (uint64_t)(p.sample_offset + b), (uint32_t)(e0 >> 2), kPurposeStepZ, (uint32_t)t)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            float zz[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+            for (int j = 0; j < W; j++) zv[j] = zz[VEC ? j : (int)(e0 & 3)];
+        }
+        float o[W];
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+            float ee = clip ? clip_eps(xv[j], ev[j], c) : ev[j];
+            float m = __fdiv_rn(xv[j] - __fmul_rn(ce[j], ee), c.g);
+            if (dlim) m = __fadd_rn(m, __fmul_rn(dl_mean, ee));
+            o[j] = __fadd_rn(m, __fmul_rn(cn[j], zv[j]));
+        }
+        if (VEC) {
+            *reinterpret_cast<float4 *>(p.x_dev + off) = *reinterpret_cast<float4 *>(o);
+            if (hist) *reinterpret_cast<float4 *>(hist + off) = *reinterpret_cast<float4 *>(o);
+        } else {
+            p.x_dev[off] = o[0];
+            if (hist) hist[off] = o[0];
         }
     }
 }
@@ -234,6 +364,8 @@ __global__ void __launch_bounds__(256) k_update_rows(dlpm_update_args p) {
     const float *zr = p.z_dev ? p.z_dev + b * p.D : nullptr;
     const uint64_t seed = p.key_dev ? p.key_dev[0] : p.seed;
     const uint64_t gidx = (uint64_t)((p.key_dev ? (int64_t)p.key_dev[1] : p.sample_offset) + b);
+    float *hr = p.hist_pp ? *p.hist_pp : nullptr;
+    if (hr) hr += ((int64_t)(p.T - t) * p.B + b) * p.D;
     for (int q0 = threadIdx.x; q0 < nq; q0 += 3 * 256) {
         float4 x[3], e[3], z[3];
         int q[3];
@@ -256,7 +388,10 @@ __global__ void __launch_bounds__(256) k_update_rows(dlpm_update_args p) {
             o.y = fmaf(cn, z[u].y, div_by(x[u].y - ce * e[u].y, g, rg));
             o.z = fmaf(cn, z[u].z, div_by(x[u].z - ce * e[u].z, g, rg));
             o.w = fmaf(cn, z[u].w, div_by(x[u].w - ce * e[u].w, g, rg));
-            if (ok[u]) reinterpret_cast<float4 *>(xr)[q[u]] = o;
+            if (ok[u]) {
+                reinterpret_cast<float4 *>(xr)[q[u]] = o;
+                if (hr) reinterpret_cast<float4 *>(hr)[q[u]] = o;
+            }
         }
     }
 }
@@ -312,6 +447,33 @@ extern "C" int dlpm_skewed_levy_philox_f32(float *A_dev, int T, int64_t B, doubl
     return DLPM_OK;
 }
 
+extern "C" int dlpm_skewed_levy_elem_philox_f32(float *A_dev, int T, int64_t B, int64_t D, double alpha, double clamp_a,
+                                                uint64_t seed, int64_t sample_offset, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(A_dev && T > 0 && B > 0 && D > 0, "dlpm_skewed_levy_elem_philox_f32: bad shape");
+    DLPM_CHECK_ARG(D < (1ll << 32), "dlpm_skewed_levy_elem_philox_f32: D must fit 32 bits");
+    DLPM_CHECK_ARG(T < (1 << 24), "dlpm_skewed_levy_elem_philox_f32: T must fit 24 bits");
+    DLPM_CHECK_ARG(alpha > 0.0 && alpha <= 2.0, "Wrong value of alpha (%g) for skewed levy r.v generation", alpha);
+    int64_t n = (int64_t)T * B * D;
+    unsigned grid = (unsigned)std::min<int64_t>(ceil_div(n, 256), 256 * 64);
+    k_skewed_levy_elem<<<grid, 256, 0, as_stream(stream)>>>(A_dev, T, B, D, alpha, (float)clamp_a, clamp_a >= 0.0, seed,
+                                                           sample_offset);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_init_state_elem_philox_f32(float *x_dev, int64_t B, int64_t D, double alpha, double clamp_eps,
+                                               float barsigma_last, uint64_t seed, int64_t sample_offset,
+                                               dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(x_dev && B > 0 && D > 0 && D < (1ll << 32), "dlpm_init_state_elem_philox_f32: bad shape");
+    DLPM_CHECK_ARG(alpha > 0.0 && alpha <= 2.0, "Wrong value of alpha (%g) for skewed levy r.v generation", alpha);
+    int64_t n = B * ((D + 3) / 4);
+    k_init_state_elem<<<(unsigned)ceil_div(n, 256), 256, 0, as_stream(stream)>>>(x_dev, B, D, alpha, (float)clamp_eps,
+                                                                                clamp_eps >= 0.0, barsigma_last, seed,
+                                                                                sample_offset);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
 extern "C" int dlpm_init_state_philox_f32(float *x_dev, int64_t B, int64_t D, double alpha, double clamp_eps,
                                           float barsigma_last, uint64_t seed, int64_t sample_offset,
                                           dlpm_stream_t stream) {
@@ -351,8 +513,16 @@ extern "C" int dlpm_update_f32(const dlpm_update_args *a, dlpm_stream_t stream) 
     // 4 quads per thread (see k_update); at most 8 blocks per CU, the rest is grid-strided
     unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(items, 256 * (vec ? 4 : 1)), 256 * 8));
     // algorithmic bytes: read x, read eps, write x (+ read z when injected)
-    ProfScope ps("update", 0.0, 4.0 * (double)a->B * a->D * (a->z_dev ? 4 : 3), as_stream(stream));
-    if (vec && !(a->flags & (DLPM_UPD_DLIM | DLPM_UPD_CLIP)) && a->B < (1 << 30))
+    const bool elem = a->flags & DLPM_UPD_ELEMENTWISE;
+    ProfScope ps(elem ? "update_elem" : "update", 0.0,
+                 4.0 * (double)a->B * a->D * ((a->z_dev ? 4 : 3) + (elem ? 2 : 0) + (a->hist_pp ? 1 : 0)), as_stream(stream));
+    if (elem) {
+        const bool evec = vec && ((reinterpret_cast<uintptr_t>(a->c_eps_dev) | reinterpret_cast<uintptr_t>(a->c_noise_dev) |
+                                   reinterpret_cast<uintptr_t>(a->A_dev)) % 16 == 0);
+        unsigned egrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(a->B * a->D / (evec ? 4 : 1), 256), 256 * 16));
+        if (evec) k_update_elem<true><<<egrid, 256, 0, as_stream(stream)>>>(*a);
+        else k_update_elem<false><<<egrid, 256, 0, as_stream(stream)>>>(*a);
+    } else if (vec && !(a->flags & (DLPM_UPD_DLIM | DLPM_UPD_CLIP)) && a->B < (1 << 30))
         k_update_rows<<<(unsigned)a->B, 256, 0, as_stream(stream)>>>(*a);
     else if (vec) k_update<true><<<grid, 256, 0, as_stream(stream)>>>(*a);
     else k_update<false><<<grid, 256, 0, as_stream(stream)>>>(*a);

@@ -18,7 +18,11 @@ struct dlpm_sampler {
     int64_t D = 0;
     float *g = nullptr, *bg = nullptr, *s = nullptr, *bs = nullptr;  // device schedule [T]
     float bs_last = 0.f;
-    float *A = nullptr, *c_eps = nullptr, *c_noise = nullptr;         // [T,B]
+    float *A = nullptr, *c_eps = nullptr, *c_noise = nullptr;         // [T,B]; [T,B,D] when non-isotropic
+    bool elem = false;             // DLPM_UPD_ELEMENTWISE: per-element tables
+    int64_t cols = 0;              // table columns: B, or B*D when non-isotropic
+    float **hist_cell = nullptr;   // device cell with the history base (see dlpm_update_args::hist_pp)
+    float *hist = nullptr;         // its current value (caller-owned [T,B,D] buffer or null)
     float *x = nullptr, *eps = nullptr, *tvec = nullptr;
     int32_t *t_dev = nullptr;
     uint64_t *key_dev = nullptr;   // {seed, sample_offset}: read by the update kernel, so reseeding keeps the graph
@@ -61,14 +65,17 @@ int one_step(dlpm_sampler *s, const float *z, bool advance, hipStream_t st) {
     a.g_dev = s->g; a.bg_dev = s->bg; a.bs_dev = s->bs;
     a.c_eps_dev = s->c_eps; a.c_noise_dev = s->c_noise; a.A_dev = s->A;
     a.B = s->cfg.B; a.D = s->D; a.T = s->cfg.T;
-    a.flags = (s->cfg.flags & (DLPM_UPD_DLIM | DLPM_UPD_CLIP)) | (advance ? DLPM_UPD_ADVANCE : 0);
+    a.flags = (s->cfg.flags & (DLPM_UPD_DLIM | DLPM_UPD_CLIP | DLPM_UPD_ELEMENTWISE)) | (advance ? DLPM_UPD_ADVANCE : 0);
+    a.hist_pp = s->hist_cell;
     a.dlim_eta = s->cfg.dlim_eta; a.alpha = (float)s->cfg.alpha;
     a.seed = s->cfg.seed; a.sample_offset = s->cfg.sample_offset; a.key_dev = s->key_dev;
     return dlpm_update_f32(&a, st);
 }
 
 int build_tables(dlpm_sampler *s, hipStream_t st) {
-    TRY(dlpm_coeff_tables_f32(s->A, s->g, s->s, s->bs, s->cfg.T, s->cfg.B, s->c_eps, s->c_noise, nullptr, st));
+    TRY(dlpm_coeff_tables_f32(s->A, s->g, s->s, s->bs, s->cfg.T, s->cols, s->c_eps, s->c_noise, nullptr, st));
+    if (s->hist)   // row 0 of the history is x_T (GenerativeLevyProcess.py:314)
+        DLPM_HIP(hipMemcpyAsync(s->hist, s->x, (size_t)s->cfg.B * s->D * sizeof(float), hipMemcpyDeviceToDevice, st));
     k_set_t<<<1, 64, 0, st>>>(s->t_dev, s->cfg.T - 1);
     DLPM_LAUNCH_CHECK();
     s->t_host = s->cfg.T - 1;
@@ -88,6 +95,13 @@ extern "C" int dlpm_sampler_create(const dlpm_sampler_config *cfg, dlpm_sampler 
     dlpm_sampler *s = new dlpm_sampler();
     s->cfg = *cfg;
     s->D = (int64_t)cfg->C * cfg->H * cfg->W;
+    s->elem = (cfg->flags & DLPM_UPD_ELEMENTWISE) != 0;
+    s->cols = s->elem ? cfg->B * s->D : cfg->B;
+    if (s->elem && cfg->mlp) {
+        set_error("dlpm_sampler_create: the toy MLP takes isotropic noise only (the reference asserts the same, Model.py:44)");
+        delete s;
+        return DLPM_ERR_UNSUPPORTED;
+    }
     const int T = cfg->T;
     const int64_t B = cfg->B;
     std::vector<float> hg(T), hbg(T), hs(T), hbs(T);
@@ -111,10 +125,19 @@ extern "C" int dlpm_sampler_create(const dlpm_sampler_config *cfg, dlpm_sampler 
         if ((e = hipMalloc(sched[i], T * sizeof(float))) != hipSuccess) return fail(e);
         if ((e = hipMemcpy(*sched[i], hsrc[i]->data(), T * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     }
-    const size_t tb = (size_t)T * B * sizeof(float);
+    const size_t tb = (size_t)T * s->cols * sizeof(float);
     if ((e = hipMalloc(&s->A, tb)) != hipSuccess) return fail(e);
-    if ((e = hipMalloc(&s->c_eps, tb)) != hipSuccess) return fail(e);
+    // Non-isotropic tables are T*B*D floats each (12.6 GB for [1024,3,32,32], T = 1000): A is only read again by
+    // DLIM with eta > 0, otherwise c_eps is computed in place over it.
+    const bool keepA = !s->elem || ((cfg->flags & DLPM_UPD_DLIM) && cfg->dlim_eta != 0.0f);
+    if (keepA) {
+        if ((e = hipMalloc(&s->c_eps, tb)) != hipSuccess) return fail(e);
+    } else {
+        s->c_eps = s->A;
+    }
     if ((e = hipMalloc(&s->c_noise, tb)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&s->hist_cell, sizeof(float *))) != hipSuccess) return fail(e);
+    if ((e = hipMemset(s->hist_cell, 0, sizeof(float *))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&s->x, (size_t)B * s->D * sizeof(float))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&s->eps, (size_t)B * s->D * sizeof(float))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&s->tvec, (size_t)B * sizeof(float))) != hipSuccess) return fail(e);
@@ -153,15 +176,20 @@ extern "C" int dlpm_sampler_begin(dlpm_sampler *s, dlpm_stream_t stream) {
     DLPM_CHECK_ARG(s, "dlpm_sampler_begin: null handle");
     hipStream_t st = as_stream(stream);
     const dlpm_sampler_config &c = s->cfg;
-    TRY(dlpm_skewed_levy_philox_f32(s->A, c.T, c.B, c.alpha, c.clamp_a, c.seed, c.sample_offset, st));
-    TRY(dlpm_init_state_philox_f32(s->x, c.B, s->D, c.alpha, c.clamp_eps, s->bs_last, c.seed, c.sample_offset, st));
+    if (s->elem) {
+        TRY(dlpm_skewed_levy_elem_philox_f32(s->A, c.T, c.B, s->D, c.alpha, c.clamp_a, c.seed, c.sample_offset, st));
+        TRY(dlpm_init_state_elem_philox_f32(s->x, c.B, s->D, c.alpha, c.clamp_eps, s->bs_last, c.seed, c.sample_offset, st));
+    } else {
+        TRY(dlpm_skewed_levy_philox_f32(s->A, c.T, c.B, c.alpha, c.clamp_a, c.seed, c.sample_offset, st));
+        TRY(dlpm_init_state_philox_f32(s->x, c.B, s->D, c.alpha, c.clamp_eps, s->bs_last, c.seed, c.sample_offset, st));
+    }
     return build_tables(s, st);
 }
 
 extern "C" int dlpm_sampler_begin_injected(dlpm_sampler *s, const float *A_dev, const float *xT_dev, dlpm_stream_t stream) {
     DLPM_CHECK_ARG(s && A_dev && xT_dev, "dlpm_sampler_begin_injected: null argument");
     hipStream_t st = as_stream(stream);
-    DLPM_HIP(hipMemcpyAsync(s->A, A_dev, (size_t)s->cfg.T * s->cfg.B * sizeof(float), hipMemcpyDeviceToDevice, st));
+    DLPM_HIP(hipMemcpyAsync(s->A, A_dev, (size_t)s->cfg.T * s->cols * sizeof(float), hipMemcpyDeviceToDevice, st));
     DLPM_HIP(hipMemcpyAsync(s->x, xT_dev, (size_t)s->cfg.B * s->D * sizeof(float), hipMemcpyDeviceToDevice, st));
     return build_tables(s, st);
 }
@@ -222,7 +250,7 @@ extern "C" int dlpm_sampler_steps(dlpm_sampler *s, int32_t nsteps, dlpm_stream_t
     // (one wave per sample: best while the batch is latency-bound; beyond ~16k samples the 4-samples-per-wave
     //  forward kernel + update kernel reuse the weights better)
     if (s->cfg.mlp && !(s->cfg.flags & (DLPM_UPD_DLIM | DLPM_UPD_CLIP | DLPM_SMP_NO_FUSED_MLP)) && s->D <= 4 && s->cfg.B <= 16384 &&
-        !prof_enabled()) {
+        !s->hist && !prof_enabled()) {
         TRY(dlpm_mlp_sample_steps_f32(s->cfg.mlp, s->x, s->c_eps, s->c_noise, s->g, s->cfg.T, s->cfg.B, s->t_host, nsteps,
                                       s->cfg.seed, s->cfg.sample_offset, s->key_dev, st));
         s->t_host -= nsteps;
@@ -243,6 +271,18 @@ extern "C" int dlpm_sampler_steps(dlpm_sampler *s, int32_t nsteps, dlpm_stream_t
     DLPM_HIP(hipEventRecord(s->ev_out, s->own));
     DLPM_HIP(hipStreamWaitEvent(st, s->ev_out, 0));    // and the caller's later work follows them
     return r;
+}
+
+extern "C" int dlpm_sampler_set_history(dlpm_sampler *s, float *hist_dev, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(s, "dlpm_sampler_set_history: null handle");
+    if (hist_dev == s->hist) return DLPM_OK;
+    // the captured update node reads the base from a device cell, so the graph follows the new buffer; the
+    // write must not overtake a replay still running on the private stream
+    if (s->own) DLPM_HIP(hipStreamSynchronize(s->own));
+    DLPM_HIP(hipStreamSynchronize(as_stream(stream)));
+    DLPM_HIP(hipMemcpy(s->hist_cell, &hist_dev, sizeof(float *), hipMemcpyHostToDevice));
+    s->hist = hist_dev;
+    return DLPM_OK;
 }
 
 extern "C" int dlpm_sampler_copy_state(dlpm_sampler *s, float *out_dev, dlpm_stream_t stream) {
@@ -271,7 +311,8 @@ extern "C" void dlpm_sampler_destroy(dlpm_sampler *s) {
     if (s->ev_in) (void)hipEventDestroy(s->ev_in);
     if (s->ev_out) (void)hipEventDestroy(s->ev_out);
     if (s->own) (void)hipStreamDestroy(s->own);
-    void *bufs[] = {s->g, s->bg, s->s, s->bs, s->A, s->c_eps, s->c_noise, s->x, s->eps, s->tvec, s->t_dev, s->key_dev, s->ws};
+    void *bufs[] = {s->g, s->bg, s->s, s->bs, s->A, s->c_eps == s->A ? nullptr : s->c_eps, s->c_noise, s->x, s->eps, s->tvec,
+                    s->t_dev, s->key_dev, s->ws, s->hist_cell};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete s;

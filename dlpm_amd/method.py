@@ -145,6 +145,8 @@ class GenerativeLevyProcess:
             assert len(shape) == 3 and shape[1] == 1, shape
             dims = (1, 1, shape[2])
             handles = dict(unet=None, mlp=model.native_handle())
+        if not self.isotropic:
+            flags |= _lib.UPD_ELEMENTWISE
         key = (id(model), handles['unet'].value if handles['unet'] else handles['mlp'].value, tuple(shape),
                self.reverse_steps, self.alpha, flags, eta, clamp_a, clamp_eps, self.use_graph, self.fused_mlp)
         ent = self._samplers.get(key)
@@ -191,12 +193,14 @@ class GenerativeLevyProcess:
         """A[T,B] and x_T from the reference's CPU streams, in its draw order."""
         st = self._streams()
         T, B = self.reverse_steps, shape[0]
-        A = torch.stack([st.skewed_levy(self.alpha, B, clamp_a) for _ in range(T)])       # dlpm.py:226-227
+        n = B if self.isotropic else int(np.prod(shape))       # non-isotropic: one draw per element (Distributions.py:48)
+        A = torch.stack([st.skewed_levy(self.alpha, n, clamp_a) for _ in range(T)])       # dlpm.py:226-227
         if noise is not None:
             xT = noise.detach().to('cpu', torch.float32)
         else:                                                                             # GLP.py:313
-            a0 = st.skewed_levy(self.alpha, B, None)           # gen_sas draws its own UNclamped a
-            e = torch.sqrt(a0.view(-1, *([1] * (len(shape) - 1)))) * st.randn(shape)
+            a0 = st.skewed_levy(self.alpha, n, None)           # gen_sas draws its own UNclamped a
+            a0 = a0.view(-1, *([1] * (len(shape) - 1))) if self.isotropic else a0.view(shape)
+            e = torch.sqrt(a0) * st.randn(shape)
             if clamp_eps is not None:
                 e = torch.clamp(e, -clamp_eps, clamp_eps)
             xT = self.dlpm.host_schedule[3][-1] * e
@@ -209,11 +213,9 @@ class GenerativeLevyProcess:
         h = self._native_sampler(model, shape, flags, eta, clamp_a, clamp_eps, seed, offset)
         dev = torch.device(self.device)
         x = torch.empty(shape, dtype=torch.float32, device=dev)
-        hist = []
-
-        def snap():
-            _lib.check(L.dlpm_sampler_copy_state(h, x.data_ptr(), st))
-            return x.clone()
+        # the update kernel stores every intermediate state into this buffer (row T - t), inside the graph
+        hist = torch.empty([T] + list(shape), dtype=torch.float32, device=dev) if history else None
+        _lib.check(L.dlpm_sampler_set_history(h, hist.data_ptr() if history else None, st))
 
         pbar = None
         if progress:
@@ -223,35 +225,28 @@ class GenerativeLevyProcess:
             A, xT = self._host_noise_prologue(shape, clamp_a, clamp_eps, noise)
             A_d, xT_d = A.to(dev), xT.to(dev)
             _lib.check(L.dlpm_sampler_begin_injected(h, A_d.data_ptr(), xT_d.data_ptr(), st))
-            if history:
-                hist.append(snap())
             need_z = not (flags & _lib.UPD_DLIM) or eta != 0.0
             for _ in range(T - 1):
                 z_d = self._streams().randn(shape).to(dev) if (need_z and self.rng == 'reference') else None
                 if z_d is None and need_z:
                     z_d = torch.randn(shape, device=dev)
                 _lib.check(L.dlpm_sampler_step_injected(h, z_d.data_ptr() if z_d is not None else None, st))
-                if history:
-                    hist.append(snap())
                 if pbar:
                     pbar.update(1)
         else:
             _lib.check(L.dlpm_sampler_begin(h, st))
-            if history or pbar:
-                if history:
-                    hist.append(snap())
+            if pbar:
                 for _ in range(T - 1):
                     _lib.check(L.dlpm_sampler_steps(h, 1, st))
-                    if history:
-                        hist.append(snap())
-                    if pbar:
-                        pbar.update(1)
+                    pbar.update(1)
             else:
                 _lib.check(L.dlpm_sampler_steps(h, T - 1, st))
         if pbar:
             pbar.close()
         _lib.check(L.dlpm_sampler_copy_state(h, x.data_ptr(), st))
-        return (x, torch.stack(hist)) if history else x
+        if history:
+            _lib.check(L.dlpm_sampler_set_history(h, None, st))
+        return (x, hist) if history else x
 
     def _run_callable(self, model, shape, flags, eta, clamp_a, clamp_eps, noise, history, progress):
         """Generic `model(x, t)` (any torch callable on the GPU): same kernels, Python between them."""
@@ -267,14 +262,22 @@ class GenerativeLevyProcess:
         if host:
             A, xT = self._host_noise_prologue(shape, clamp_a, clamp_eps, noise)
             A, x = A.to(dev), xT.to(dev).reshape(shape).contiguous()
-        else:
+        elif self.isotropic:
             A = torch.empty((T, B), dtype=torch.float32, device=dev)
             x = torch.empty(shape, dtype=torch.float32, device=dev)
             _lib.check(L.dlpm_skewed_levy_philox_f32(A.data_ptr(), T, B, float(self.alpha), ca, seed, offset, st))
             _lib.check(L.dlpm_init_state_philox_f32(x.data_ptr(), B, D, float(self.alpha), ce,
                                                    float(self.dlpm.host_schedule[3][-1]), seed, offset, st))
+        else:
+            A = torch.empty((T, B * D), dtype=torch.float32, device=dev)
+            x = torch.empty(shape, dtype=torch.float32, device=dev)
+            _lib.check(L.dlpm_skewed_levy_elem_philox_f32(A.data_ptr(), T, B, D, float(self.alpha), ca, seed, offset, st))
+            _lib.check(L.dlpm_init_state_elem_philox_f32(x.data_ptr(), B, D, float(self.alpha), ce,
+                                                        float(self.dlpm.host_schedule[3][-1]), seed, offset, st))
+        if not self.isotropic:
+            flags |= _lib.UPD_ELEMENTWISE
         c_eps, c_noise = torch.empty_like(A), torch.empty_like(A)
-        _lib.check(L.dlpm_coeff_tables_f32(A.data_ptr(), g.data_ptr(), s.data_ptr(), bs.data_ptr(), T, B,
+        _lib.check(L.dlpm_coeff_tables_f32(A.data_ptr(), g.data_ptr(), s.data_ptr(), bs.data_ptr(), T, A.shape[1],
                                           c_eps.data_ptr(), c_noise.data_ptr(), None, st))
         t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         tvec = torch.empty(B, dtype=torch.float32, device=dev)

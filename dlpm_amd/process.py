@@ -4,7 +4,8 @@ Host-side mirror of dlpm/methods/dlpm.py:56-297 for the pieces the reverse loop 
 schedule vectors, `rescale_diffusion`, and the stateful clamp parameters of the two noise generators
 (`gen_a`, `gen_eps`: bem/datasets/Data.py:17-89).  The arithmetic of the loop itself (A draws,
 Sigma recursion, x_{t-1} update) lives in libdlpm_amd and keeps [T,B] scalars instead of the
-reference's [T,B,C,H,W] tensors.
+reference's [T,B,C,H,W] tensors (non-isotropic noise, `isotropic=False`, is the one case that really
+needs a value per element: [T,B,D] tables).
 """
 import numpy as np
 import torch
@@ -36,8 +37,6 @@ class DLPM:
                  clamp_eps=None, scale='scale_preserving', native_schedule=False):
         if alpha > 2.0 or alpha <= 0.0:
             raise Exception('Wrong value of alpha ({}) for skewed levy r.v generation'.format(alpha))
-        if not isotropic:
-            raise NotImplementedError('non-isotropic noise (--non_iso) is a "next" row (SURVEY.md 8f rank 3)')
         if scale != 'scale_preserving':
             raise NotImplementedError("only scale='scale_preserving' (every shipped config) is implemented")
         self.alpha, self.device, self.time_spacing, self.isotropic, self.scale = alpha, device, time_spacing, isotropic, scale

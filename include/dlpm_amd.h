@@ -92,6 +92,18 @@ int dlpm_randn_host_f32(dlpm_mt19937 *torch_stream, int64_t n, float *out);
 int dlpm_skewed_levy_philox_f32(float *A_dev, int T, int64_t B, double alpha, double clamp_a,
                                 uint64_t seed, int64_t sample_offset, dlpm_stream_t stream);
 
+/* Non-isotropic noise (`--non_iso`, script_utils.py:26-27): A_dev[T,B,D] with one independent draw per ELEMENT
+ * (gen_skewed_levy with isotropic=False, bem/datasets/Distributions.py:47-48), Philox-keyed by (seed, global
+ * sample index, element, row t).  The Sigma recursion is then per element: call dlpm_coeff_tables_f32 with
+ * B*D in place of B and dlpm_update_f32 with DLPM_UPD_ELEMENTWISE. */
+int dlpm_skewed_levy_elem_philox_f32(float *A_dev, int T, int64_t B, int64_t D, double alpha, double clamp_a,
+                                     uint64_t seed, int64_t sample_offset, dlpm_stream_t stream);
+
+/* Non-isotropic x_T: as dlpm_init_state_philox_f32 with an independent unclamped a0 per element
+ * (gen_sas with isotropic=False, Distributions.py:57-73). */
+int dlpm_init_state_elem_philox_f32(float *x_dev, int64_t B, int64_t D, double alpha, double clamp_eps,
+                                    float barsigma_last, uint64_t seed, int64_t sample_offset, dlpm_stream_t stream);
+
 /* x_dev[B,D] <- barsigma_last * clamp(sqrt(a0[b]) * z, +-clamp_eps), a0 an UNclamped skewed-Levy
  * draw, z ~ N(0,1) (Philox).  Replaces the x_T init: GenerativeLevyProcess.py:313 -> gen_sas,
  * Distributions.py:57-73. */
@@ -112,7 +124,8 @@ enum dlpm_update_flags {
     DLPM_UPD_DLIM = 1,        /* deterministic / DLIM step instead of the stochastic DLPM step */
     DLPM_UPD_CLIP = 2,        /* clip_denoised: eps <- predict_eps(clamp(predict_xstart)) first  */
     DLPM_UPD_ADVANCE = 4,     /* after the update, thread 0 decrements *t_dev (graph replay)     */
-    DLPM_SMP_NO_FUSED_MLP = 8 /* sampler only: do not use the one-launch toy-net loop            */
+    DLPM_SMP_NO_FUSED_MLP = 8,/* sampler only: do not use the one-launch toy-net loop            */
+    DLPM_UPD_ELEMENTWISE = 16 /* non-isotropic noise: c_eps / c_noise / A are [T,B,D] (also a sampler flag) */
 };
 
 typedef struct dlpm_update_args {
@@ -132,13 +145,20 @@ typedef struct dlpm_update_args {
     int64_t sample_offset;    /* global index of sample 0 of this shard                          */
     const uint64_t *key_dev;  /* optional device pair {seed, sample_offset} overriding the two fields
                                  above: lets a captured graph be replayed under a new key          */
+    float *const *hist_pp;    /* optional DEVICE cell holding the base of a [T,B,D] history buffer (or NULL in
+                                 the cell = off): the output of step t is also stored at row T - t, the row the
+                                 reference's `samples` list gives it (GenerativeLevyProcess.py:274-288).  A cell,
+                                 not a pointer, so a captured graph follows a new buffer                        */
 } dlpm_update_args;
 
 /* One reverse step on the whole batch:
  *   DLPM: x <- (x - c_eps[t,b] eps)/g_t + c_noise[t,b] z     dlpm.py:272-278, GenerativeLevyProcess.py:225-239
  *   DLIM: x <- (x - bs_t eps)/g_t + bs_{t-1} eps  (eta = 0)   dlpm.py:281-297
  *   CLIP: eps <- (x - clamp((x - eps bs_t)/bg_t, -1, 1) bg_t)/bs_t first   GenerativeLevyProcess.py:186-207
- * HBM-bound: 12 B/element with Philox noise, 16 B/element with injected z. */
+ * DLPM_UPD_ELEMENTWISE (non-isotropic noise, `--non_iso`, Distributions.py:47-48): the three tables are
+ * [T,B,D] and indexed per element instead of per sample.
+ * HBM-bound: 12 B/element with Philox noise, 16 B/element with injected z; +8 B/element for elementwise
+ * tables, +4 B/element when a history row is written. */
 int dlpm_update_f32(const dlpm_update_args *args, dlpm_stream_t stream);
 
 /* tvec_dev[b] = float(*t_dev) * (1/T): the `t/T` the reference feeds the net
@@ -288,7 +308,7 @@ typedef struct dlpm_sampler_config {
     int32_t T;                  /* reverse steps */
     double alpha;
     double clamp_a, clamp_eps;  /* < 0: none */
-    int32_t flags;              /* DLPM_UPD_DLIM | DLPM_UPD_CLIP | DLPM_SMP_NO_FUSED_MLP */
+    int32_t flags;              /* DLPM_UPD_DLIM | DLPM_UPD_CLIP | DLPM_SMP_NO_FUSED_MLP | DLPM_UPD_ELEMENTWISE */
     float dlim_eta;
     uint64_t seed;
     int64_t sample_offset;      /* global index of this shard's first sample */
@@ -314,6 +334,12 @@ int dlpm_sampler_step_injected(dlpm_sampler *s, const float *z_dev, dlpm_stream_
 /* Run `nsteps` reverse steps (model forward + fused update), stopping at t == 0.  Loop body of
  * p_sample_loop_progressive: GenerativeLevyProcess.py:317-330. */
 int dlpm_sampler_steps(dlpm_sampler *s, int32_t nsteps, dlpm_stream_t stream);
+/* Record every intermediate state on the device: hist_dev is a caller-owned [T,B,D] buffer (or NULL to stop).
+ * dlpm_sampler_begin* stores x_T in row 0 and each later step stores its output in row T - t, i.e. the
+ * `torch.stack(x_hist)` the reference returns with get_sample_history (GenerativeLevyProcess.py:274-288) --
+ * written by the update kernel inside the captured graph, no per-step host round trip.  Call before begin. */
+int dlpm_sampler_set_history(dlpm_sampler *s, float *hist_dev, dlpm_stream_t stream);
+
 /* Copy the current state x[B,C,H,W] into a caller buffer (device to device, on `stream`). */
 int dlpm_sampler_copy_state(dlpm_sampler *s, float *out_dev, dlpm_stream_t stream);
 /* Device pointer to the current state x[B,C,H,W] and the current t (host copy). */

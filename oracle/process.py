@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY.  Restates dlpm/methods/dlpm.py with per-sample scalars
 ([T,B] tables) instead of the reference's fully expanded [T,B,C,H,W] tensors; for
-isotropic noise the arithmetic per element is identical (same fp32 op order).
+isotropic noise the arithmetic per element is identical (same fp32 op order).  Non-isotropic
+noise passes [T,B,C,H,W] tables through the same functions.
 """
 import math
 
@@ -40,6 +41,9 @@ def gamma_var(t, Sig, g):
 
 
 def _b(v, x):
+    """per-sample [B] -> broadcastable over x; per-element tables (non-isotropic noise) pass through."""
+    if v.dim() == x.dim():
+        return v
     return v.view(-1, *([1] * (x.dim() - 1)))
 
 

@@ -5,6 +5,7 @@ Restates GenerativeLevyProcess.sample -> p_sample_loop / ddim_sample_loop
 consumption order of SURVEY.md 8c-bis:
 
   1. A[k], k = 0..T-1     stream N: B uniforms then B exponentials per k, clamp_a applied
+                          (non-isotropic, Distributions.py:47-48: B*D of each, A[k] has the state's shape)
   2. x_T = bs[T-1] * sqrt(a) * randn, a unclamped (Distributions.py:63-65), clamp_eps applied
   3. i = T-1..1           stream P: B*D normals per step, also at i == 1 (masked)
 
@@ -39,14 +40,18 @@ class Streams:
 
 
 def sample(model, shape, T, alpha, streams, deterministic=False, dlim_eta=0.0, clip_denoised=False,
-           clamp_a=None, clamp_eps=None, get_sample_history=False, trace=None):
+           clamp_a=None, clamp_eps=None, get_sample_history=False, trace=None, isotropic=True):
     B = shape[0]
+    n = B if isotropic else int(np.prod(shape))
     g, bg, s, bs = P.schedule(T, alpha)
-    A = torch.stack([streams.skewed_levy(alpha, B, clamp_a) for _ in range(T)])    # dlpm.py:226-227
+    A = torch.stack([streams.skewed_levy(alpha, n, clamp_a) for _ in range(T)])    # dlpm.py:226-227
+    if not isotropic:
+        A = A.reshape([T] + list(shape))
     Sig = P.sigma_table(A, g, s)                                                    # dlpm.py:230-239
     # x_T: GenerativeLevyProcess.py:313 -> gen_sas (own unclamped a, then randn, then clamp_eps)
-    a0 = streams.skewed_levy(alpha, B, None)
-    e = torch.sqrt(P._b(a0, torch.empty(shape))) * streams.randn(shape)
+    a0 = streams.skewed_levy(alpha, n, None)
+    a0 = P._b(a0, torch.empty(shape)) if isotropic else a0.reshape(shape)
+    e = torch.sqrt(a0) * streams.randn(shape)
     if clamp_eps is not None:
         e = torch.clamp(e, -clamp_eps, clamp_eps)
     x = bs[-1] * e

@@ -130,6 +130,7 @@ TRAJ = [
     ('f5_traj_zero_toy', zero_model), ('f5_traj_synth_toy', Synth()), ('f5_traj_synth_img', Synth()),
     ('f5_traj_dlim_toy', Synth()), ('f5_traj_clip_img', Synth()), ('f5_traj_synth_img_big', Synth()),
     ('f5_traj_mlp_toy', 'mlp'),
+    ('f5_traj_noniso_img', Synth()), ('f5_traj_noniso_clip_img', Synth()), ('f5_traj_noniso_dlim_img', Synth()),
 ]
 
 
@@ -144,7 +145,8 @@ def test_trajectories_same_seeds(name, model):
     tr = {}
     x, hist = sampler.sample(model, shape, int(T), float(alpha), sampler.Streams(0, 0), deterministic=bool(det),
                              dlim_eta=float(eta), clip_denoised=bool(clip), clamp_a=None if ca < 0 else float(ca),
-                             clamp_eps=None if ce < 0 else float(ce), get_sample_history=True, trace=tr)
+                             clamp_eps=None if ce < 0 else float(ce), get_sample_history=True, trace=tr,
+                             isotropic='noniso' not in name)
     nd = len(shape) - 1
     np.testing.assert_allclose(tr['A'].numpy(), f['A'], rtol=2e-7)
     np.testing.assert_allclose(tr['xT'].numpy(), f['xT'], rtol=2e-6, atol=1e-6)

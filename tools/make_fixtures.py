@@ -241,17 +241,17 @@ class ZeroModel(torch.nn.Module):
 
 
 def run_traj(name, model, shape, T, alpha, deterministic=False, eta=0.0, clamp_a=None, clamp_eps=None,
-             clip=False, extra=None):
+             clip=False, extra=None, isotropic=True):
     np.random.seed(0)
     torch.manual_seed(0)
-    meth = GenerativeLevyProcess(alpha=alpha, device='cpu', reverse_steps=T, rescale_timesteps=True)
+    meth = GenerativeLevyProcess(alpha=alpha, device='cpu', reverse_steps=T, rescale_timesteps=True, isotropic=isotropic)
     with _Recorder() as rec:
         x, hist = meth.sample({'default': model}, shape, T, deterministic=deterministic, dlim_eta=eta,
                               clamp_a=clamp_a, clamp_eps=clamp_eps, clip_denoised=clip,
                               get_sample_history=True)
     nd = len(shape) - 1
     idx = (slice(None), slice(None)) + (0,) * nd
-    arrs = dict(final=x, history=hist, A=meth.dlpm.A[idx], xT=hist[0],
+    arrs = dict(final=x, history=hist, A=meth.dlpm.A[idx] if isotropic else meth.dlpm.A, xT=hist[0],
                 meta=np.array([T, alpha, float(deterministic), eta,
                                -1 if clamp_a is None else clamp_a, -1 if clamp_eps is None else clamp_eps,
                                float(clip)]),
@@ -274,6 +274,11 @@ def f5_trajectories():
     # every B; the single-step diagonal in f4 pins the intended arithmetic instead.
     run_traj('f5_traj_clip_img', SynthModel(), [2, 3, 4, 4], 30, 1.8, clamp_a=10, clamp_eps=50, clip=True)
     run_traj('f5_traj_synth_img_big', SynthModel(), [4, 3, 8, 8], 20, 1.7, clamp_a=10, clamp_eps=50)
+    # non-isotropic noise (--non_iso): one skewed-Levy draw per element, [T,B,C,H,W] tables
+    run_traj('f5_traj_noniso_img', SynthModel(), [2, 3, 4, 4], 40, 1.7, clamp_a=10, clamp_eps=50, isotropic=False)
+    run_traj('f5_traj_noniso_clip_img', SynthModel(), [3, 1, 4, 4], 25, 1.8, clamp_a=20, clamp_eps=200, clip=True,
+             isotropic=False)
+    run_traj('f5_traj_noniso_dlim_img', SynthModel(), [2, 3, 4, 4], 30, 1.7, deterministic=True, eta=0.0, isotropic=False)
 
     # real MLP (2d_data.yml), default torch init under manual_seed(1)
     p = yaml.safe_load(open(os.path.join(REF, 'dlpm/configs/2d_data.yml')))
