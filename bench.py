@@ -97,6 +97,9 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--non-iso', action='store_true',
                     help='non-isotropic noise variant (--non_iso of the reference): [T,B,D] tables; not the headline config')
+    ap.add_argument('--lim', action='store_true',
+                    help='LIM sampler variant (--method lim of the reference, SDE updates): T network evaluations; '
+                         'not the headline config')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -119,16 +122,17 @@ def main():
     if args.batch:
         B = args.batch
     K, W = args.steps, args.warmup
-    assert 1 <= K and W + K <= T - 1, 'at most T-1 = %d steps exist' % (T - 1)
+    nsteps = T if args.lim else T - 1        # network evaluations of one sample() call
+    assert 1 <= K and W + K <= nsteps, 'at most %d steps exist' % nsteps
     p = dlpm_amd.load_config(cfg_name)
     torch.manual_seed(1234)
     net = dlpm_amd.rerandomize_(dlpm_amd.init_model_by_parameter(p), 4321)
     shape = [B, p['data']['channels'], p['data']['image_size'], p['data']['image_size']]
     ev = p['eval']['dlpm']
     meth = dlpm_amd.GenerativeLevyProcess(alpha, str(dev), T, rescale_timesteps=True, seed=0, sample_offset=rank * B,
-                                          use_graph=not args.no_graph, isotropic=not args.non_iso)
+                                          use_graph=not args.no_graph, isotropic=not args.non_iso, LIM=args.lim)
     st = _lib.stream_ptr()
-    h = meth._native_sampler(net, shape, 0, 0.0, ev['clamp_a'], ev['clamp_eps'], 0)
+    h = meth._native_sampler(net, shape, _lib.SMP_LIM if args.lim else 0, 0.0, ev['clamp_a'], ev['clamp_eps'], 0)
     flops_per_sample = net.flops_per_sample(shape[2])
 
     def barrier():
@@ -166,7 +170,7 @@ def main():
     gather_s = time.perf_counter() - t0
     finite = bool(torch.isfinite(full).all().item())
 
-    total_s = init_s + (T - 1) * ms_per_step / 1e3 + gather_s
+    total_s = init_s + nsteps * ms_per_step / 1e3 + gather_s
     value = B * world / total_s
 
     roofline, upd, breakdown = None, None, None
@@ -210,8 +214,8 @@ def main():
             'metric': METRIC[cfg_name], 'value': round(value, 4),
             'unit': 'samples/s', 'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(ms_per_step, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': args.workload + ('+non_iso' if args.non_iso else ''), 'state_shape_per_gpu': shape, 'global_batch': B * world,
-                       'reverse_steps': T, 'alpha': alpha, 'timed_steps': K, 'trajectory_steps': T - 1,
+            'config': {'workload': args.workload + ('+non_iso' if args.non_iso else '') + ('+lim_sde' if args.lim else ''), 'state_shape_per_gpu': shape, 'global_batch': B * world,
+                       'reverse_steps': T, 'alpha': alpha, 'timed_steps': K, 'trajectory_steps': nsteps,
                        'init_ms': round(init_s * 1e3, 3), 'allgather_ms': round(gather_s * 1e3, 3),
                        'net': 'reference cifar10.yml UNet (mc=128, 39.6M params), random init + re-drawn zero tensors'
                        if cfg_name == 'cifar10' else cfg_name,

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libdlpm_amd.so')
 
 vp, i32, i64, u32, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
 
-UPD_DLIM, UPD_CLIP, UPD_ADVANCE, SMP_NO_FUSED_MLP, UPD_ELEMENTWISE = 1, 2, 4, 8, 16
+UPD_DLIM, UPD_CLIP, UPD_ADVANCE, SMP_NO_FUSED_MLP, UPD_ELEMENTWISE, SMP_LIM = 1, 2, 4, 8, 16, 32
 
 
 class MT19937(C.Structure):
@@ -24,6 +24,12 @@ class UpdateArgs(C.Structure):
                 ('bs_dev', vp), ('c_eps_dev', vp), ('c_noise_dev', vp), ('A_dev', vp), ('B', i64), ('D', i64),
                 ('T', i32), ('flags', i32), ('dlim_eta', f32), ('alpha', f32), ('seed', u64), ('sample_offset', i64), ('key_dev', vp),
                 ('hist_pp', vp)]
+
+
+class LimUpdateArgs(C.Structure):
+    _fields_ = [('x_dev', vp), ('eps_dev', vp), ('z_dev', vp), ('t_dev', vp), ('tmp_dev', vp), ('cx_dev', vp),
+                ('cs_dev', vp), ('cn_dev', vp), ('A_dev', vp), ('B', i64), ('D', i64), ('T', i32), ('flags', i32),
+                ('clamp_eps', f32), ('seed', u64), ('sample_offset', i64), ('key_dev', vp), ('hist_pp', vp)]
 
 
 class UNetConfig(C.Structure):
@@ -42,7 +48,8 @@ class ConvArgs(C.Structure):
 class SamplerConfig(C.Structure):
     _fields_ = [('unet', vp), ('mlp', vp), ('B', i64), ('C', i32), ('H', i32), ('W', i32), ('T', i32), ('alpha', f64),
                 ('clamp_a', f64), ('clamp_eps', f64), ('flags', i32), ('dlim_eta', f32), ('seed', u64),
-                ('sample_offset', i64), ('use_graph', i32), ('g', vp), ('bg', vp), ('s', vp), ('bs', vp)]
+                ('sample_offset', i64), ('use_graph', i32), ('g', vp), ('bg', vp), ('s', vp), ('bs', vp),
+                ('lim_ts', vp), ('lim_tmp', vp), ('lim_cx', vp), ('lim_cs', vp), ('lim_cn', vp)]
 
 
 # name -> (restype, argtypes); one entry per function declared in include/dlpm_amd.h
@@ -63,6 +70,9 @@ SIGNATURES = {
     'dlpm_update_f32': (C.c_int, [C.POINTER(UpdateArgs), vp]),
     'dlpm_fill_scaled_t_f32': (C.c_int, [vp, vp, i32, i64, vp]),
     'dlpm_postprocess_f32': (C.c_int, [vp, vp, i64, f32, C.c_int, vp]),
+    'dlpm_lim_tables_f32': (C.c_int, [f64, i32, i32, vp, vp, vp, vp, vp]),
+    'dlpm_lim_update_f32': (C.c_int, [C.POINTER(LimUpdateArgs), vp]),
+    'dlpm_fill_table_t_f32': (C.c_int, [vp, vp, vp, i32, i64, vp]),
     'dlpm_images_to_rgb8': (C.c_int, [vp, vp, i64, i32, i32, i32, vp]),
     'dlpm_png_bound': (i64, [i32, i32]),
     'dlpm_png_encode_rgb8': (C.c_int, [vp, i32, i32, i32, vp, i64, C.POINTER(i64)]),

@@ -1,7 +1,7 @@
 """`eval.py --generate`-compatible command line for the sampling path (no dataset / neptune needed).
 
 Covers the reference flags that reach the sampler (script_utils.py:11-12,35-39,56-67,82-83,155-221):
-  --config --generate --reverse_steps --deterministic --clip --alpha --non_iso --set_seed/--random_seed
+  --config --method --generate --reverse_steps --deterministic --clip --alpha --non_iso --set_seed/--random_seed
 plus the checkpoint to evaluate, resolved like eval.py does (eval.py:21, bem/utils_exp.py:96-139):
   --name N [--models_dir models] [--epoch E]  ->  models/N/<dataset>/model_<exphash>[_<E>].pt
 or given directly with --checkpoint FILE; --ema_eval [--ema_index I] evaluates an EMA shadow.
@@ -21,6 +21,7 @@ from dlpm_amd.config import sample_shape
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument('--config', required=True, help='config name (dlpm_amd/configs) or path to a reference-schema YAML')
+    ap.add_argument('--method', default=None, choices=['dlpm', 'lim'], help='generative method (script_utils.py:6-7)')
     ap.add_argument('--generate', type=int, default=None, help='number of samples (eval.data_to_generate)')
     ap.add_argument('--reverse_steps', type=int, default=None)
     ap.add_argument('--alpha', type=float, default=None)
@@ -49,6 +50,8 @@ def main(argv=None):
 
     p = dlpm_amd.load_config(a.config)
     p['device'] = 'cuda'
+    if a.method is not None:
+        p['method'] = a.method
     m = p['method']
     if a.alpha is not None:
         p[m]['alpha'] = a.alpha

@@ -247,3 +247,40 @@ extern "C" int dlpm_randn_host_f32(dlpm_mt19937 *st, int64_t n, float *out) {
     }
     return DLPM_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- LIM tables
+// VPSDE, cosine schedule (dlpm/methods/LIM/functions/sde.py:5-49) and the per-step coefficients of
+// ode_score_update / sde_score_update (dlpm/methods/LIM/functions/sampler.py:85-152).
+extern "C" int dlpm_lim_tables_f32(double alpha, int32_t steps, int32_t ode, float *ts, float *tmp, float *cx, float *cs,
+                                   float *cn) {
+    DLPM_CHECK_ARG(ts && tmp && cx && cs && cn, "dlpm_lim_tables_f32: null pointer");
+    DLPM_CHECK_ARG(steps >= 1, "dlpm_lim_tables_f32: steps must be >= 1, got %d", steps);
+    DLPM_CHECK_ARG(alpha > 0.0 && alpha <= 2.0, "Wrong value of alpha (%g) for skewed levy r.v generation", alpha);
+    const double pi = 3.141592653589793, cs_ = 0.008, Tend = 0.9946, eps = 1e-5;
+    const double log_a0 = std::log(std::cos(cs_ / (1.0 + cs_) * pi / 2.0));
+    auto logmean = [&](double t) { return std::log(std::cos((t + cs_) / (1.0 + cs_) * pi / 2.0)) - log_a0; };
+    auto stdv = [&](double t) { return std::pow(1.0 - std::exp(logmean(t) * alpha), 1.0 / alpha); };
+    auto beta = [&](double t) { return pi / 2.0 * alpha / (cs_ + 1.0) * std::tan((t + cs_) / (1.0 + cs_) * pi / 2.0); };
+    // torch.linspace(T, eps, steps + 1) in fp32: start + i*step for the first half, end - (n-1-i)*step for the second
+    const int n = steps + 1;
+    const float fstart = (float)Tend, fend = (float)eps;
+    const float fstep = (fend - fstart) / (float)(n - 1);
+    for (int i = 0; i < n; i++) ts[i] = i < n / 2 ? fstart + fstep * (float)i : fend - fstep * (float)(n - 1 - i);
+    for (int i = 0; i < steps; i++) {
+        const double s = ts[i], t = ts[i + 1];
+        const double beta_step = beta(s) * (s - t);
+        if (alpha == 2.0) {
+            tmp[i] = (float)std::pow(stdv(s) + 1e-5, -(alpha - 1.0));
+            cx[i] = (float)(1.0 + beta_step / alpha);
+            cs[i] = (float)(ode ? beta_step / 2.0 : beta_step);
+            cn[i] = ode ? 0.0f : (float)std::pow(beta_step, 1.0 / alpha);
+        } else {
+            tmp[i] = (float)std::pow(stdv(s), -(alpha - 1.0));
+            const double a = std::exp(logmean(t) - logmean(s));
+            cx[i] = (float)a;
+            cs[i] = (float)(ode ? -alpha * (1.0 - a) : alpha * alpha * (a - 1.0));
+            cn[i] = ode ? 0.0f : (float)std::pow(std::pow(a, alpha) - 1.0, 1.0 / alpha);
+        }
+    }
+    return DLPM_OK;
+}

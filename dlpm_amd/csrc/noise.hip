@@ -396,6 +396,70 @@ __global__ void __launch_bounds__(256) k_update_rows(dlpm_update_args p) {
     }
 }
 
+// LIM update (sde_score_update / ode_score_update, dlpm/methods/LIM/functions/sampler.py:85-152): per step the
+// coefficients are four scalars; the SDE noise is gen_sas's clamp(sqrt(a_b) z) with a fresh per-sample a.
+// One workgroup per sample (wave-uniform coefficients, Philox counter = (sample, quad)); VEC needs D % 4 == 0.
+template <bool VEC>
+__global__ void __launch_bounds__(256) k_update_lim(dlpm_lim_update_args p) {
+    const int t = *p.t_dev;
+    const int i = (p.T - 1) - t;
+    const float tmp = p.tmp_dev[i], cx = p.cx_dev[i], cs = p.cs_dev[i], cn = p.cn_dev[i];
+    const bool ode = p.flags & DLPM_UPD_DLIM;
+    const int64_t b = blockIdx.x;
+    const float sa = p.A_dev ? sqrtf(p.A_dev[(int64_t)i * p.B + b]) : 1.0f;
+    const bool clamp = p.A_dev && p.clamp_eps >= 0.0f;
+    const uint64_t seed = p.key_dev ? p.key_dev[0] : p.seed;
+    const uint64_t gidx = (uint64_t)((p.key_dev ? (int64_t)p.key_dev[1] : p.sample_offset) + b);
+    float *xr = p.x_dev + b * p.D;
+    const float *er = p.eps_dev + b * p.D;
+    const float *zr = p.z_dev ? p.z_dev + b * p.D : nullptr;
+    float *hr = p.hist_pp ? *p.hist_pp : nullptr;
+    if (hr) hr += ((int64_t)(p.T - t) * p.B + b) * p.D;
+    constexpr int W = VEC ? 4 : 1;
+    const int n = (int)(p.D / W);
+    for (int q = threadIdx.x; q < n; q += blockDim.x) {
+        float xv[W], ev[W], zv[W], o[W];
+        if (VEC) {
+            *reinterpret_cast<float4 *>(xv) = reinterpret_cast<const float4 *>(xr)[q];
+            *reinterpret_cast<float4 *>(ev) = reinterpret_cast<const float4 *>(er)[q];
+            if (zr) *reinterpret_cast<float4 *>(zv) = reinterpret_cast<const float4 *>(zr)[q];
+        } else {
+            xv[0] = xr[q];
+            ev[0] = er[q];
+            if (zr) zv[0] = zr[q];
+        }
+        if (!ode && !zr) {
+            float4 z = philox_normal4(seed, gidx, (uint32_t)(VEC ? q : q >> 2), kPurposeStepZ, (uint32_t)t);
+            float zz[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+            for (int j = 0; j < W; j++) zv[j] = zz[VEC ? j : (q & 3)];
+        }
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+            const float score = __fmul_rn(ev[j], tmp);
+            float v = __fadd_rn(__fmul_rn(cx, xv[j]), __fmul_rn(cs, score));
+            if (!ode) {
+                float e = __fmul_rn(sa, zv[j]);
+                if (clamp) e = fminf(fmaxf(e, -p.clamp_eps), p.clamp_eps);
+                v = __fadd_rn(v, __fmul_rn(cn, e));
+            }
+            o[j] = v;
+        }
+        if (VEC) {
+            reinterpret_cast<float4 *>(xr)[q] = *reinterpret_cast<float4 *>(o);
+            if (hr) reinterpret_cast<float4 *>(hr)[q] = *reinterpret_cast<float4 *>(o);
+        } else {
+            xr[q] = o[0];
+            if (hr) hr[q] = o[0];
+        }
+    }
+}
+
+__global__ void k_fill_table_t(float *tv, const int32_t *t, const float *ts, int32_t T, int64_t B) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) tv[i] = ts[(T - 1) - *t];
+}
+
 __global__ void k_advance(int32_t *t) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *t = *t - 1;
 }
@@ -531,6 +595,35 @@ extern "C" int dlpm_update_f32(const dlpm_update_args *a, dlpm_stream_t stream) 
         k_advance<<<1, 64, 0, as_stream(stream)>>>(const_cast<int32_t *>(a->t_dev));
         DLPM_LAUNCH_CHECK();
     }
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_lim_update_f32(const dlpm_lim_update_args *a, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(a && a->x_dev && a->eps_dev && a->t_dev && a->tmp_dev && a->cx_dev && a->cs_dev && a->cn_dev,
+                   "dlpm_lim_update_f32: null pointer");
+    DLPM_CHECK_ARG(a->B > 0 && a->B < (1ll << 31) && a->D > 0 && a->D < (1ll << 31) && a->T >= 2, "dlpm_lim_update_f32: bad shape");
+    const bool vec = (a->D % 4 == 0) && ((reinterpret_cast<uintptr_t>(a->x_dev) | reinterpret_cast<uintptr_t>(a->eps_dev) |
+                                          reinterpret_cast<uintptr_t>(a->z_dev)) % 16 == 0);
+    const bool ode = a->flags & DLPM_UPD_DLIM;
+    ProfScope ps("lim_update", 0.0, 4.0 * (double)a->B * a->D * ((a->z_dev && !ode ? 4 : 3) + (a->hist_pp ? 1 : 0)),
+                 as_stream(stream));
+    const int64_t items = vec ? a->D / 4 : a->D;
+    const unsigned threads = items >= 256 ? 256 : 64;
+    if (vec) k_update_lim<true><<<(unsigned)a->B, threads, 0, as_stream(stream)>>>(*a);
+    else k_update_lim<false><<<(unsigned)a->B, threads, 0, as_stream(stream)>>>(*a);
+    DLPM_LAUNCH_CHECK();
+    if (a->flags & DLPM_UPD_ADVANCE) {
+        k_advance<<<1, 64, 0, as_stream(stream)>>>(const_cast<int32_t *>(a->t_dev));
+        DLPM_LAUNCH_CHECK();
+    }
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_fill_table_t_f32(float *tvec_dev, const int32_t *t_dev, const float *ts_dev, int32_t T, int64_t B,
+                                     dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(tvec_dev && t_dev && ts_dev && T >= 2 && B > 0, "dlpm_fill_table_t_f32: bad argument");
+    k_fill_table_t<<<(unsigned)ceil_div(B, 256), 256, 0, as_stream(stream)>>>(tvec_dev, t_dev, ts_dev, T, B);
+    DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }
 

@@ -21,6 +21,8 @@ struct dlpm_sampler {
     float *A = nullptr, *c_eps = nullptr, *c_noise = nullptr;         // [T,B]; [T,B,D] when non-isotropic
     bool elem = false;             // DLPM_UPD_ELEMENTWISE: per-element tables
     int64_t cols = 0;              // table columns: B, or B*D when non-isotropic
+    bool lim = false;              // DLPM_SMP_LIM: continuous-time LIM updates (T = steps + 1)
+    float *lim_ts = nullptr, *lim_tmp = nullptr, *lim_cx = nullptr, *lim_cs = nullptr, *lim_cn = nullptr;
     float **hist_cell = nullptr;   // device cell with the history base (see dlpm_update_args::hist_pp)
     float *hist = nullptr;         // its current value (caller-owned [T,B,D] buffer or null)
     float *x = nullptr, *eps = nullptr, *tvec = nullptr;
@@ -58,6 +60,20 @@ int model_forward(dlpm_sampler *s, hipStream_t st) {
 }
 
 int one_step(dlpm_sampler *s, const float *z, bool advance, hipStream_t st) {
+    if (s->lim) {
+        TRY(dlpm_fill_table_t_f32(s->tvec, s->t_dev, s->lim_ts, s->cfg.T, s->cfg.B, st));
+        TRY(model_forward(s, st));
+        dlpm_lim_update_args a{};
+        a.x_dev = s->x; a.eps_dev = s->eps; a.z_dev = z; a.t_dev = s->t_dev;
+        a.tmp_dev = s->lim_tmp; a.cx_dev = s->lim_cx; a.cs_dev = s->lim_cs; a.cn_dev = s->lim_cn;
+        a.A_dev = s->cfg.alpha == 2.0 ? nullptr : s->A;      // alpha = 2: e_B = randn_like(x) (sampler.py:135)
+        a.B = s->cfg.B; a.D = s->D; a.T = s->cfg.T;
+        a.flags = (s->cfg.flags & DLPM_UPD_DLIM) | (advance ? DLPM_UPD_ADVANCE : 0);
+        a.clamp_eps = (float)s->cfg.clamp_eps;
+        a.seed = s->cfg.seed; a.sample_offset = s->cfg.sample_offset; a.key_dev = s->key_dev;
+        a.hist_pp = s->hist_cell;
+        return dlpm_lim_update_f32(&a, st);
+    }
     TRY(dlpm_fill_scaled_t_f32(s->tvec, s->t_dev, s->cfg.T, s->cfg.B, st));
     TRY(model_forward(s, st));
     dlpm_update_args a{};
@@ -73,7 +89,8 @@ int one_step(dlpm_sampler *s, const float *z, bool advance, hipStream_t st) {
 }
 
 int build_tables(dlpm_sampler *s, hipStream_t st) {
-    TRY(dlpm_coeff_tables_f32(s->A, s->g, s->s, s->bs, s->cfg.T, s->cols, s->c_eps, s->c_noise, nullptr, st));
+    if (!s->lim)
+        TRY(dlpm_coeff_tables_f32(s->A, s->g, s->s, s->bs, s->cfg.T, s->cols, s->c_eps, s->c_noise, nullptr, st));
     if (s->hist)   // row 0 of the history is x_T (GenerativeLevyProcess.py:314)
         DLPM_HIP(hipMemcpyAsync(s->hist, s->x, (size_t)s->cfg.B * s->D * sizeof(float), hipMemcpyDeviceToDevice, st));
     k_set_t<<<1, 64, 0, st>>>(s->t_dev, s->cfg.T - 1);
@@ -92,9 +109,16 @@ extern "C" int dlpm_sampler_create(const dlpm_sampler_config *cfg, dlpm_sampler 
     DLPM_CHECK_ARG(cfg->alpha > 0.0 && cfg->alpha <= 2.0, "Wrong value of alpha (%g) for skewed levy r.v generation", cfg->alpha);
     const bool have = cfg->g && cfg->bg && cfg->s && cfg->bs;
     DLPM_CHECK_ARG(have || (!cfg->g && !cfg->bg && !cfg->s && !cfg->bs), "dlpm_sampler_create: give all four schedule arrays or none");
+    const bool is_lim = (cfg->flags & DLPM_SMP_LIM) != 0;
+    const bool have_lim = cfg->lim_ts && cfg->lim_tmp && cfg->lim_cx && cfg->lim_cs && cfg->lim_cn;
+    DLPM_CHECK_ARG(!is_lim || have_lim || (!cfg->lim_ts && !cfg->lim_tmp && !cfg->lim_cx && !cfg->lim_cs && !cfg->lim_cn),
+                   "dlpm_sampler_create: give all five LIM tables or none");
+    DLPM_CHECK_ARG(!is_lim || !(cfg->flags & (DLPM_UPD_CLIP | DLPM_UPD_ELEMENTWISE)),
+                   "dlpm_sampler_create: the LIM sampler has no clip_denoised / non-isotropic variant (the reference's are commented out)");
     dlpm_sampler *s = new dlpm_sampler();
     s->cfg = *cfg;
     s->D = (int64_t)cfg->C * cfg->H * cfg->W;
+    s->lim = is_lim;
     s->elem = (cfg->flags & DLPM_UPD_ELEMENTWISE) != 0;
     s->cols = s->elem ? cfg->B * s->D : cfg->B;
     if (s->elem && cfg->mlp) {
@@ -105,13 +129,25 @@ extern "C" int dlpm_sampler_create(const dlpm_sampler_config *cfg, dlpm_sampler 
     const int T = cfg->T;
     const int64_t B = cfg->B;
     std::vector<float> hg(T), hbg(T), hs(T), hbs(T);
-    if (have) {
+    std::vector<float> lts(T), ltmp(T), lcx(T), lcs(T), lcn(T);
+    if (is_lim) {
+        if (have_lim) {
+            for (int i = 0; i < T; i++) lts[i] = cfg->lim_ts[i];
+            for (int i = 0; i < T - 1; i++) { ltmp[i] = cfg->lim_tmp[i]; lcx[i] = cfg->lim_cx[i]; lcs[i] = cfg->lim_cs[i]; lcn[i] = cfg->lim_cn[i]; }
+        } else {
+            int r = dlpm_lim_tables_f32(cfg->alpha, T - 1, (cfg->flags & DLPM_UPD_DLIM) != 0, lts.data(), ltmp.data(), lcx.data(),
+                                        lcs.data(), lcn.data());
+            if (r != DLPM_OK) { delete s; return r; }
+        }
+        hbs[T - 1] = 1.0f;   // x_0 = gen_eps.generate(shape), unscaled (GenerativeLevyProcess.py:464)
+    } else if (have) {
         for (int i = 0; i < T; i++) { hg[i] = cfg->g[i]; hbg[i] = cfg->bg[i]; hs[i] = cfg->s[i]; hbs[i] = cfg->bs[i]; }
     } else {
         int r = dlpm_schedule_f32(T, cfg->alpha, hg.data(), hbg.data(), hs.data(), hbs.data());
         if (r != DLPM_OK) { delete s; return r; }
     }
     s->cfg.g = s->cfg.bg = s->cfg.s = s->cfg.bs = nullptr;  // host pointers are not retained
+    s->cfg.lim_ts = s->cfg.lim_tmp = s->cfg.lim_cx = s->cfg.lim_cs = s->cfg.lim_cn = nullptr;
     s->bs_last = hbs[T - 1];
     auto fail = [&](hipError_t e) {
         set_error("dlpm_sampler_create: %s", hipGetErrorString(e));
@@ -125,17 +161,28 @@ extern "C" int dlpm_sampler_create(const dlpm_sampler_config *cfg, dlpm_sampler 
         if ((e = hipMalloc(sched[i], T * sizeof(float))) != hipSuccess) return fail(e);
         if ((e = hipMemcpy(*sched[i], hsrc[i]->data(), T * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     }
+    if (is_lim) {
+        float **ld[5] = {&s->lim_ts, &s->lim_tmp, &s->lim_cx, &s->lim_cs, &s->lim_cn};
+        std::vector<float> *lsrc[5] = {&lts, &ltmp, &lcx, &lcs, &lcn};
+        for (int i = 0; i < 5; i++) {
+            if ((e = hipMalloc(ld[i], T * sizeof(float))) != hipSuccess) return fail(e);
+            if ((e = hipMemcpy(*ld[i], lsrc[i]->data(), T * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+        }
+    }
     const size_t tb = (size_t)T * s->cols * sizeof(float);
     if ((e = hipMalloc(&s->A, tb)) != hipSuccess) return fail(e);
     // Non-isotropic tables are T*B*D floats each (12.6 GB for [1024,3,32,32], T = 1000): A is only read again by
     // DLIM with eta > 0, otherwise c_eps is computed in place over it.
     const bool keepA = !s->elem || ((cfg->flags & DLPM_UPD_DLIM) && cfg->dlim_eta != 0.0f);
-    if (keepA) {
+    if (is_lim) {
+        s->c_eps = s->A;     // LIM has no coefficient tables: A[i,b] is read directly by the update
+        s->c_noise = nullptr;
+    } else if (keepA) {
         if ((e = hipMalloc(&s->c_eps, tb)) != hipSuccess) return fail(e);
     } else {
         s->c_eps = s->A;
     }
-    if ((e = hipMalloc(&s->c_noise, tb)) != hipSuccess) return fail(e);
+    if (!is_lim && (e = hipMalloc(&s->c_noise, tb)) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&s->hist_cell, sizeof(float *))) != hipSuccess) return fail(e);
     if ((e = hipMemset(s->hist_cell, 0, sizeof(float *))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&s->x, (size_t)B * s->D * sizeof(float))) != hipSuccess) return fail(e);
@@ -176,7 +223,12 @@ extern "C" int dlpm_sampler_begin(dlpm_sampler *s, dlpm_stream_t stream) {
     DLPM_CHECK_ARG(s, "dlpm_sampler_begin: null handle");
     hipStream_t st = as_stream(stream);
     const dlpm_sampler_config &c = s->cfg;
-    if (s->elem) {
+    if (s->lim) {
+        // per-step a (unclamped: gen_sas draws its own, Distributions.py:63-64) for steps i = 0..T-2, then x_0
+        if (c.alpha != 2.0 && !(c.flags & DLPM_UPD_DLIM))
+            TRY(dlpm_skewed_levy_philox_f32(s->A, c.T - 1, c.B, c.alpha, -1.0, c.seed, c.sample_offset, st));
+        TRY(dlpm_init_state_philox_f32(s->x, c.B, s->D, c.alpha, c.clamp_eps, 1.0f, c.seed, c.sample_offset, st));
+    } else if (s->elem) {
         TRY(dlpm_skewed_levy_elem_philox_f32(s->A, c.T, c.B, s->D, c.alpha, c.clamp_a, c.seed, c.sample_offset, st));
         TRY(dlpm_init_state_elem_philox_f32(s->x, c.B, s->D, c.alpha, c.clamp_eps, s->bs_last, c.seed, c.sample_offset, st));
     } else {
@@ -189,7 +241,8 @@ extern "C" int dlpm_sampler_begin(dlpm_sampler *s, dlpm_stream_t stream) {
 extern "C" int dlpm_sampler_begin_injected(dlpm_sampler *s, const float *A_dev, const float *xT_dev, dlpm_stream_t stream) {
     DLPM_CHECK_ARG(s && A_dev && xT_dev, "dlpm_sampler_begin_injected: null argument");
     hipStream_t st = as_stream(stream);
-    DLPM_HIP(hipMemcpyAsync(s->A, A_dev, (size_t)s->cfg.T * s->cols * sizeof(float), hipMemcpyDeviceToDevice, st));
+    DLPM_HIP(hipMemcpyAsync(s->A, A_dev, (size_t)(s->lim ? s->cfg.T - 1 : s->cfg.T) * s->cols * sizeof(float),
+                            hipMemcpyDeviceToDevice, st));
     DLPM_HIP(hipMemcpyAsync(s->x, xT_dev, (size_t)s->cfg.B * s->D * sizeof(float), hipMemcpyDeviceToDevice, st));
     return build_tables(s, st);
 }
@@ -249,8 +302,8 @@ extern "C" int dlpm_sampler_steps(dlpm_sampler *s, int32_t nsteps, dlpm_stream_t
     // toy net, plain stochastic DLPM steps: the whole run of steps is one launch (state in registers)
     // (one wave per sample: best while the batch is latency-bound; beyond ~16k samples the 4-samples-per-wave
     //  forward kernel + update kernel reuse the weights better)
-    if (s->cfg.mlp && !(s->cfg.flags & (DLPM_UPD_DLIM | DLPM_UPD_CLIP | DLPM_SMP_NO_FUSED_MLP)) && s->D <= 4 && s->cfg.B <= 16384 &&
-        !s->hist && !prof_enabled()) {
+    if (s->cfg.mlp && !(s->cfg.flags & (DLPM_UPD_DLIM | DLPM_UPD_CLIP | DLPM_SMP_NO_FUSED_MLP | DLPM_SMP_LIM)) && s->D <= 4 &&
+        s->cfg.B <= 16384 && !s->hist && !prof_enabled()) {
         TRY(dlpm_mlp_sample_steps_f32(s->cfg.mlp, s->x, s->c_eps, s->c_noise, s->g, s->cfg.T, s->cfg.B, s->t_host, nsteps,
                                       s->cfg.seed, s->cfg.sample_offset, s->key_dev, st));
         s->t_host -= nsteps;
@@ -312,7 +365,7 @@ extern "C" void dlpm_sampler_destroy(dlpm_sampler *s) {
     if (s->ev_out) (void)hipEventDestroy(s->ev_out);
     if (s->own) (void)hipStreamDestroy(s->own);
     void *bufs[] = {s->g, s->bg, s->s, s->bs, s->A, s->c_eps == s->A ? nullptr : s->c_eps, s->c_noise, s->x, s->eps, s->tvec,
-                    s->t_dev, s->key_dev, s->ws, s->hist_cell};
+                    s->t_dev, s->key_dev, s->ws, s->hist_cell, s->lim_ts, s->lim_tmp, s->lim_cx, s->lim_cs, s->lim_cn};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete s;

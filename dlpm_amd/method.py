@@ -81,8 +81,12 @@ class GenerativeLevyProcess:
         assert (model_mean_type == ModelMeanType.EPSILON) and (model_var_type == ModelVarType.FIXED), \
             'Only epsilon prediction and fixed variance are supported for the moment'
         if LIM:
-            raise NotImplementedError("method='lim' (continuous-time LIM sampler) is outside this build's "
-                                      'hot path (SURVEY.md 8f rank 4)')
+            assert rescale_timesteps, 'LIM only supports epsilon prediction, fixed variance and rescaled timesteps'
+            if not isotropic:
+                raise NotImplementedError('the LIM sampler is isotropic only (its non-isotropic branch is commented '
+                                          'out in the reference, LIM/functions/sampler.py:144-148)')
+            from .lim import VPSDE
+            self.sde = VPSDE(alpha, 'cosine')
         if input_scaling and scale == 'scale_exploding':
             raise NotImplementedError('input_scaling is only active for scale_exploding, which is not implemented')
         assert rng in ('philox', 'reference')
@@ -135,6 +139,7 @@ class GenerativeLevyProcess:
 
     def _native_sampler(self, model, shape, flags, eta, clamp_a, clamp_eps, seed, offset=None):
         offset = self.sample_offset if offset is None else offset
+        lim = bool(flags & _lib.SMP_LIM)
         from .unet import UNetModel
         B = shape[0]
         if isinstance(model, UNetModel):
@@ -158,7 +163,7 @@ class GenerativeLevyProcess:
             _lib.lib().dlpm_sampler_destroy(self._samplers.pop(k)['h'])
         cfg = _lib.SamplerConfig()
         cfg.unet, cfg.mlp = handles['unet'], handles['mlp']
-        cfg.B, (cfg.C, cfg.H, cfg.W), cfg.T = B, dims, self.reverse_steps
+        cfg.B, (cfg.C, cfg.H, cfg.W), cfg.T = B, dims, self.reverse_steps + (1 if lim else 0)
         cfg.alpha = float(self.alpha)
         cfg.clamp_a = -1.0 if clamp_a is None else float(clamp_a)
         cfg.clamp_eps = -1.0 if clamp_eps is None else float(clamp_eps)
@@ -173,6 +178,10 @@ class GenerativeLevyProcess:
         cfg.sample_offset, cfg.use_graph = offset, gs
         sched = self.dlpm.host_schedule
         cfg.g, cfg.bg, cfg.s, cfg.bs = (v.data_ptr() for v in sched)
+        if lim:
+            from .lim import lim_tables
+            tabs = lim_tables(self.sde, self.reverse_steps, bool(flags & _lib.UPD_DLIM))     # kept alive until create returns
+            cfg.lim_ts, cfg.lim_tmp, cfg.lim_cx, cfg.lim_cs, cfg.lim_cn = (v.data_ptr() for v in tabs)
         h = C.c_void_p()
         _lib.check(_lib.lib().dlpm_sampler_create(C.byref(cfg), C.byref(h)))
         self._samplers[key] = dict(h=h)
@@ -206,9 +215,21 @@ class GenerativeLevyProcess:
             xT = self.dlpm.host_schedule[3][-1] * e
         return A.contiguous(), xT.contiguous()
 
+    def _host_noise_prologue_lim(self, shape, clamp_eps):
+        """x_0 = gen_eps.generate(shape) then one unclamped a per (step, sample), in the reference's draw order on
+        stream N: a_0 first (GenerativeLevyProcess.py:464), then step by step (LIM/functions/sampler.py:143)."""
+        st = self._streams()
+        steps, B = self.reverse_steps, shape[0]
+        a0 = st.skewed_levy(self.alpha, B, None) if self.alpha != 2.0 else torch.full((B,), 2.0)
+        e = torch.sqrt(a0.view(-1, *([1] * (len(shape) - 1)))) * st.randn(shape)
+        if clamp_eps is not None:
+            e = torch.clamp(e, -clamp_eps, clamp_eps)
+        return a0, e.contiguous()
+
     def _run_native(self, model, shape, flags, eta, clamp_a, clamp_eps, noise, history, progress):
         L, st = _lib.lib(), _lib.stream_ptr()
-        T = self.reverse_steps
+        lim = bool(flags & _lib.SMP_LIM)
+        T = self.reverse_steps + (1 if lim else 0)      # LIM runs `reverse_steps` updates, DLPM reverse_steps - 1
         seed, offset = self._philox_key()
         h = self._native_sampler(model, shape, flags, eta, clamp_a, clamp_eps, seed, offset)
         dev = torch.device(self.device)
@@ -221,7 +242,21 @@ class GenerativeLevyProcess:
         if progress:
             from tqdm import tqdm
             pbar = tqdm(total=T)
-        if self.rng == 'reference' or noise is not None:
+        if lim and self.rng == 'reference':
+            # stream N interleaves with the model calls in the reference but is independent of stream P, so all the
+            # per-step a's can be drawn up front
+            _, x0 = self._host_noise_prologue_lim(shape, clamp_eps)
+            ode = bool(flags & _lib.UPD_DLIM)
+            A = torch.ones((T - 1, shape[0])) if (ode or self.alpha == 2.0) else torch.stack(
+                [self._streams().skewed_levy(self.alpha, shape[0], None) for _ in range(T - 1)])
+            A_d, x0_d = A.contiguous().to(dev), x0.to(dev)
+            _lib.check(L.dlpm_sampler_begin_injected(h, A_d.data_ptr(), x0_d.data_ptr(), st))
+            for _ in range(T - 1):
+                z_d = None if ode else self._streams().randn(shape).to(dev)
+                _lib.check(L.dlpm_sampler_step_injected(h, z_d.data_ptr() if z_d is not None else None, st))
+                if pbar:
+                    pbar.update(1)
+        elif self.rng == 'reference' or noise is not None:
             A, xT = self._host_noise_prologue(shape, clamp_a, clamp_eps, noise)
             A_d, xT_d = A.to(dev), xT.to(dev)
             _lib.check(L.dlpm_sampler_begin_injected(h, A_d.data_ptr(), xT_d.data_ptr(), st))
@@ -311,6 +346,57 @@ class GenerativeLevyProcess:
             pbar.close()
         return (x, torch.stack(hist)) if history else x
 
+    def _run_callable_lim(self, model, shape, flags, clamp_eps, history, progress):
+        """LIM loop around a generic `model(x, t)` callable: same kernels, Python between them."""
+        from .lim import lim_tables
+        L, st = _lib.lib(), _lib.stream_ptr()
+        steps, B = self.reverse_steps, shape[0]
+        T = steps + 1
+        D = int(np.prod(shape[1:]))
+        dev = torch.device(self.device)
+        ode = bool(flags & _lib.UPD_DLIM)
+        seed, offset = self._philox_key()
+        ts, tmp, cx, cs, cn = (v.to(dev) for v in lim_tables(self.sde, steps, ode))
+        ce = -1.0 if clamp_eps is None else float(clamp_eps)
+        host = self.rng == 'reference'
+        gauss = self.alpha == 2.0
+        A = None
+        if host:
+            _, x0 = self._host_noise_prologue_lim(shape, clamp_eps)
+            x = x0.to(dev)
+            if not (ode or gauss):
+                A = torch.stack([self._streams().skewed_levy(self.alpha, B, None) for _ in range(steps)]).contiguous().to(dev)
+        else:
+            x = torch.empty(shape, dtype=torch.float32, device=dev)
+            _lib.check(L.dlpm_init_state_philox_f32(x.data_ptr(), B, D, float(self.alpha), ce, 1.0, seed, offset, st))
+            if not (ode or gauss):
+                A = torch.empty((steps, B), dtype=torch.float32, device=dev)
+                _lib.check(L.dlpm_skewed_levy_philox_f32(A.data_ptr(), steps, B, float(self.alpha), -1.0, seed, offset, st))
+        t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        a = _lib.LimUpdateArgs()
+        a.t_dev, a.tmp_dev, a.cx_dev, a.cs_dev, a.cn_dev = t_dev.data_ptr(), tmp.data_ptr(), cx.data_ptr(), cs.data_ptr(), cn.data_ptr()
+        a.A_dev = A.data_ptr() if A is not None else None
+        a.B, a.D, a.T, a.flags, a.clamp_eps = B, D, T, (_lib.UPD_DLIM if ode else 0), ce
+        a.seed, a.sample_offset = seed, offset
+        hist = [x.clone()] if history else []
+        pbar = None
+        if progress:
+            from tqdm import tqdm
+            pbar = tqdm(total=steps)
+        for i in range(steps):
+            t_dev.fill_(T - 1 - i)
+            eps = model(x, torch.ones(B, device=dev) * ts[i]).contiguous().float()      # sampler.py:233
+            z = self._streams().randn(shape).to(dev) if (host and not ode) else None
+            a.x_dev, a.eps_dev, a.z_dev = x.data_ptr(), eps.data_ptr(), z.data_ptr() if z is not None else None
+            _lib.check(L.dlpm_lim_update_f32(C.byref(a), st))
+            if history:
+                hist.append(x.clone())
+            if pbar:
+                pbar.update(1)
+        if pbar:
+            pbar.close()
+        return (x, torch.stack(hist)) if history else x
+
     # -------------------------------------------------------------------------------- BEM: SAMPLING
     def sample(self, models, shape, reverse_steps, time_spacing=None, initial_data=None, clip_denoised=False,
                deterministic=False, dlim_eta=1.0, print_progression=False, get_sample_history=False, clamp_a=None,
@@ -328,6 +414,7 @@ class GenerativeLevyProcess:
             self.reverse_steps = reverse_steps            # (the reference never restores it: SURVEY.md 3.4)
         if hasattr(model, 'eval'):
             model.eval()
+        shape_arg = list(shape)
         shape = list(initial_data.shape) if (deterministic and initial_data is not None) else list(shape)
         noise = initial_data if deterministic else None
         flags = (_lib.UPD_DLIM if deterministic else 0) | (_lib.UPD_CLIP if clip_denoised else 0)
@@ -335,7 +422,16 @@ class GenerativeLevyProcess:
         native = isinstance(model, (UNetModel, MLPModel)) and self.rescale_timesteps
         run = self._run_native if native else self._run_callable
         with torch.inference_mode():
-            out = run(model, shape, flags, eta, clamp_a, clamp_eps, noise, get_sample_history, print_progression)
+            if self.LIM:
+                # lim_sample (GenerativeLevyProcess.py:454-507): `deterministic` selects the ODE; clip_denoised and
+                # initial_data are accepted and ignored, as in the reference
+                shape, flags = shape_arg, _lib.SMP_LIM | (_lib.UPD_DLIM if deterministic else 0)
+                if native:
+                    out = self._run_native(model, shape, flags, 0.0, None, clamp_eps, None, get_sample_history, print_progression)
+                else:
+                    out = self._run_callable_lim(model, shape, flags, clamp_eps, get_sample_history, print_progression)
+            else:
+                out = run(model, shape, flags, eta, clamp_a, clamp_eps, noise, get_sample_history, print_progression)
         if self._dataset is not None:
             self._dataset['next'] += shape[0]
         else:

@@ -125,7 +125,8 @@ enum dlpm_update_flags {
     DLPM_UPD_CLIP = 2,        /* clip_denoised: eps <- predict_eps(clamp(predict_xstart)) first  */
     DLPM_UPD_ADVANCE = 4,     /* after the update, thread 0 decrements *t_dev (graph replay)     */
     DLPM_SMP_NO_FUSED_MLP = 8,/* sampler only: do not use the one-launch toy-net loop            */
-    DLPM_UPD_ELEMENTWISE = 16 /* non-isotropic noise: c_eps / c_noise / A are [T,B,D] (also a sampler flag) */
+    DLPM_UPD_ELEMENTWISE = 16,/* non-isotropic noise: c_eps / c_noise / A are [T,B,D] (also a sampler flag) */
+    DLPM_SMP_LIM = 32         /* sampler only: continuous-time LIM sampler (`method: lim`); DLPM_UPD_DLIM = its ODE */
 };
 
 typedef struct dlpm_update_args {
@@ -168,6 +169,47 @@ int dlpm_fill_scaled_t_f32(float *tvec_dev, const int32_t *t_dev, int32_t T, int
 /* samples_dev <- clamp(x, -c, c) then (x+1)/2 for images: GenerationManager.generate post-processing,
  * bem/GenerationManager.py:50-63, bem/datasets/__init__.py:108-109. */
 int dlpm_postprocess_f32(const float *x_dev, float *out_dev, int64_t n, float clamp, int affine, dlpm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LIM sampler (`method: lim`): same score net and noise, continuous-time coefficients.
+ * Reference: dlpm/methods/LIM/functions/sde.py:5-49 (VPSDE, cosine schedule, T = 0.9946),
+ * dlpm/methods/LIM/functions/sampler.py:85-181,217-258 (ode_score_update / sde_score_update, time grid),
+ * GenerativeLevyProcess.lim_sample (dlpm/methods/GenerativeLevyProcess.py:454-507).
+ * ------------------------------------------------------------------------------------------ */
+
+/* [host] per-step scalars of a `steps`-step LIM run, step i going from time ts[i] to ts[i+1],
+ * ts = linspace(0.9946, 1e-5, steps + 1):
+ *   ts[steps+1]  the grid (ts[i] is also what the net is fed at step i)
+ *   tmp[steps]   marginal_std(s)^-(alpha-1)        (alpha = 2: (marginal_std(s) + 1e-5)^-1)
+ *   cx, cs, cn   x / score / noise coefficients of the SDE update, or of the ODE update when ode != 0 (cn = 0)
+ * Evaluated in double and rounded to fp32 (the reference evaluates in fp32 torch ops; dlpm_amd's Python mirror
+ * reproduces those bit for bit and passes its own tables -- this entry point serves non-Python hosts). */
+int dlpm_lim_tables_f32(double alpha, int32_t steps, int32_t ode, float *ts, float *tmp, float *cx, float *cs, float *cn);
+
+typedef struct dlpm_lim_update_args {
+    float *x_dev;             /* [B,D] state, updated in place                                          */
+    const float *eps_dev;     /* [B,D] model output                                                     */
+    const float *z_dev;       /* [B,D] injected N(0,1), or NULL = in-kernel Philox                      */
+    const int32_t *t_dev;     /* device countdown T-1 .. 1; the step index is i = (T-1) - *t_dev        */
+    const float *tmp_dev, *cx_dev, *cs_dev, *cn_dev;   /* [T-1] from dlpm_lim_tables_f32 (device copies) */
+    const float *A_dev;       /* [T-1,B] per-step, per-sample skewed-Levy a (gen_sas draws a fresh one each
+                                 step, Distributions.py:63-65), or NULL = 1 (alpha = 2: plain Gaussian) */
+    int64_t B, D;
+    int32_t T;                /* steps + 1                                                              */
+    int32_t flags;            /* DLPM_UPD_DLIM = ODE update (no noise); DLPM_UPD_ADVANCE                */
+    float clamp_eps;          /* < 0: none; clamps sqrt(a) z (gen_sas), not applied when A_dev is NULL  */
+    uint64_t seed;
+    int64_t sample_offset;
+    const uint64_t *key_dev;  /* as in dlpm_update_args                                                 */
+    float *const *hist_pp;    /* as in dlpm_update_args: row T - t of a [T,B,D] buffer                  */
+} dlpm_lim_update_args;
+
+/* x <- cx x + cs (eps tmp) [+ cn clamp(sqrt(a) z)]   -- sde_score_update / ode_score_update. */
+int dlpm_lim_update_f32(const dlpm_lim_update_args *args, dlpm_stream_t stream);
+
+/* tvec_dev[b] = ts_dev[(T-1) - *t_dev]: the continuous time the LIM loop feeds the net (sampler.py:233). */
+int dlpm_fill_table_t_f32(float *tvec_dev, const int32_t *t_dev, const float *ts_dev, int32_t T, int64_t B,
+                          dlpm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Generated-image dump: what EvaluationManager does with each chunk of samples,
@@ -308,13 +350,16 @@ typedef struct dlpm_sampler_config {
     int32_t T;                  /* reverse steps */
     double alpha;
     double clamp_a, clamp_eps;  /* < 0: none */
-    int32_t flags;              /* DLPM_UPD_DLIM | DLPM_UPD_CLIP | DLPM_SMP_NO_FUSED_MLP | DLPM_UPD_ELEMENTWISE */
+    int32_t flags;              /* DLPM_UPD_DLIM | DLPM_UPD_CLIP | DLPM_SMP_NO_FUSED_MLP | DLPM_UPD_ELEMENTWISE | DLPM_SMP_LIM */
     float dlim_eta;
     uint64_t seed;
     int64_t sample_offset;      /* global index of this shard's first sample */
     int32_t use_graph;          /* > 0: capture this many consecutive reverse steps into one hipGraph and
                                    replay it (1 suits the UNets; launch-bound nets want tens)          */
     const float *g, *bg, *s, *bs; /* host schedule [T] each, or all NULL = dlpm_schedule_f32(T, alpha) */
+    /* DLPM_SMP_LIM: T = steps + 1 and the schedule above is unused; host tables of dlpm_lim_tables_f32
+     * (ts[T], the others [T-1]), or all NULL = computed by it */
+    const float *lim_ts, *lim_tmp, *lim_cx, *lim_cs, *lim_cn;
 } dlpm_sampler_config;
 
 typedef struct dlpm_sampler dlpm_sampler;
@@ -327,7 +372,8 @@ int dlpm_sampler_reseed(dlpm_sampler *s, uint64_t seed, int64_t sample_offset);
  * GenerativeLevyProcess.py:306-315. */
 int dlpm_sampler_begin(dlpm_sampler *s, dlpm_stream_t stream);
 /* Same prologue with caller-provided noise (parity with the CPU reference on identical seeds):
- * A_dev[T,B] and xT_dev[B,C,H,W] are copied in; the tables are built from A. */
+ * A_dev[T,B] and xT_dev[B,C,H,W] are copied in; the tables are built from A.  (Non-isotropic: A_dev[T,B,D].
+ * LIM: A_dev[T-1,B] holds the per-step a of gen_sas, row i for step i; xT_dev is x_0 = gen_eps.generate.) */
 int dlpm_sampler_begin_injected(dlpm_sampler *s, const float *A_dev, const float *xT_dev, dlpm_stream_t stream);
 /* One reverse step with caller-provided N(0,1) noise z_dev[B,C,H,W] (eager, no graph). */
 int dlpm_sampler_step_injected(dlpm_sampler *s, const float *z_dev, dlpm_stream_t stream);

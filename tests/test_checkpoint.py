@@ -22,9 +22,11 @@ with open(os.path.join(GOLDEN, 'f9_paths.json')) as _f:
 def test_experiment_and_eval_hashes_match_reference(name):
     p = dlpm_amd.load_config(name)
     assert [ck.get_exp_hash(p), ck.get_eval_hash(p)] == PATHS['hashes'][name]
-    p = yaml.safe_load(yaml.safe_dump(p))
     p['dlpm']['alpha'] = 1.7                       # what --alpha 1.7 does before the paths are derived
     assert [ck.get_exp_hash(p), ck.get_eval_hash(p)] == PATHS['hashes'][name + '@alpha1.7']
+    p = dlpm_amd.load_config(name)
+    p['method'] = 'lim'                            # --method lim
+    assert [ck.get_exp_hash(p), ck.get_eval_hash(p)] == PATHS['hashes'][name + '@lim']
 
 
 @pytest.mark.parametrize('i', range(len(PATHS['layouts'])))

@@ -185,7 +185,9 @@ def test_product_never_imports_oracle():
 
 def test_unsupported_paths_fail_loudly():
     with pytest.raises(NotImplementedError):
-        dlpm_amd.GenerativeLevyProcess(1.7, 'cpu', 10, LIM=True, rescale_timesteps=True)
+        dlpm_amd.GenerativeLevyProcess(1.7, 'cpu', 10, LIM=True, rescale_timesteps=True, isotropic=False)
+    with pytest.raises(NotImplementedError):
+        dlpm_amd.GenerativeLevyProcess(1.7, 'cpu', 10, scale='scale_exploding')
     with pytest.raises(Exception, match='Wrong value of alpha'):
         dlpm_amd.DLPM(2.5, 'cpu', 10)
     m = dlpm_amd.GenerativeLevyProcess(1.7, 'cpu', 10, rescale_timesteps=False)

@@ -17,6 +17,7 @@ Fixture families:
   F6 unet / mlp forward  UNetModel.forward, MLPModel.forward      dlpm/models/unet.py:463-492, Model.py:148-211
   F7 layers              GroupNorm32, QKVAttention, embedding...  dlpm/models/unet.py, nn.py
   F8 generation manager  clamp + inverse affine                   bem/GenerationManager.py:29-63
+  F10 LIM sampler        VPSDE, LIM_sampler sde/ode updates        dlpm/methods/LIM/functions/{sde,sampler}.py
   F9 checkpoints         TrainingManager.save/load, EMAHelper,    bem/TrainingManager.py:240-285, bem/utils_ema.py,
                          FileHandler path hashing                 bem/utils_exp.py:52-151, dlpm/dlpm_experiment.py:11-19
 """
@@ -487,9 +488,13 @@ def f9_checkpoints():
     for n in ['cifar10', 'mnist', '2d_data', 'cifar10_lt']:
         p = ue.FileHandler.get_param_from_config(os.path.join(REF, 'dlpm', 'configs'), n + '.yml')
         info['hashes'][n] = [fh.get_exp_hash(p), fh.get_eval_hash(p)]
-        p2 = yaml.safe_load(yaml.safe_dump(p))
+        import copy
+        p2 = copy.deepcopy(p)                                  # (a YAML round trip would sort the keys)
         p2['dlpm']['alpha'] = 1.7                              # what --alpha 1.7 does before hashing
         info['hashes'][n + '@alpha1.7'] = [fh.get_exp_hash(p2), fh.get_eval_hash(p2)]
+        p3 = copy.deepcopy(p)
+        p3['method'] = 'lim'                                   # what --method lim does before hashing
+        info['hashes'][n + '@lim'] = [fh.get_exp_hash(p3), fh.get_eval_hash(p3)]
     p = ue.FileHandler.get_param_from_config(os.path.join(REF, 'dlpm', 'configs'), 'mnist.yml')
     h = fh.get_exp_hash(p)
     for files, epoch in [(['model_%s_300.pt', 'model_%s_900.pt', 'model_%s_600.pt'], None),
@@ -565,9 +570,65 @@ def f9_checkpoints():
     print('reference TrainingManager.load accepted a dlpm_amd.checkpoint.save_checkpoint file')
 
 
+def f10_lim():
+    """LIM sampler (method: lim): VPSDE function values and full sample() trajectories of the reference with
+    LIM=True (SDE and ODE), on identical seeds."""
+    from dlpm.methods.LIM.functions.sde import VPSDE
+    arrs = {}
+    for al in (1.5, 1.7, 1.8, 2.0):
+        sde = VPSDE(al, 'cosine')
+        for steps in (10, 100, 1000):
+            ts = torch.linspace(sde.T, 1e-5, steps + 1)
+            tag = 'a%s_n%d_' % (str(al).replace('.', 'p'), steps)
+            arrs[tag + 'ts'] = ts
+            arrs[tag + 'beta'] = sde.beta(ts)
+            arrs[tag + 'logmean'] = sde.marginal_log_mean_coeff(ts)
+            arrs[tag + 'diff'] = sde.diffusion_coeff(ts)
+            arrs[tag + 'std'] = sde.marginal_std(ts)
+    save('f10_lim_vpsde', **arrs)
+
+    class _Rec:
+        def __enter__(self):
+            self.noise = []
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    def run(name, model, shape, steps, alpha, ode, clamp_eps=None, extra=None):
+        np.random.seed(0)
+        torch.manual_seed(0)
+        meth = GenerativeLevyProcess(alpha=alpha, device='cpu', reverse_steps=steps, rescale_timesteps=True, LIM=True)
+        x, hist = meth.sample({'default': model}, shape, steps, deterministic=ode, clamp_a=None, clamp_eps=clamp_eps,
+                              get_sample_history=True)
+        arrs = dict(final=x, history=hist, meta=np.array([steps, alpha, float(ode), -1 if clamp_eps is None else clamp_eps]),
+                    shape=np.array(shape))
+        if extra:
+            arrs.update(extra)
+        save(name, **arrs)
+
+    run('f10_lim_sde_toy', SynthModel(), [4, 1, 2], 50, 1.7, False)
+    run('f10_lim_ode_toy', SynthModel(), [4, 1, 2], 50, 1.7, True)
+    run('f10_lim_sde_img', SynthModel(), [2, 3, 4, 4], 30, 1.8, False, clamp_eps=50)
+    run('f10_lim_ode_img', SynthModel(), [2, 3, 4, 4], 30, 1.8, True, clamp_eps=50)
+    run('f10_lim_sde_img_b20', SynthModel(), [20, 1, 4, 4], 12, 1.5, False, clamp_eps=20)
+    run('f10_lim_sde_gauss', SynthModel(), [4, 3, 4, 4], 20, 2.0, False)
+    p = yaml.safe_load(open(os.path.join(REF, 'dlpm/configs/2d_data.yml')))
+    p['device'] = 'cpu'
+    torch.manual_seed(1)
+    mlp = ref_mlp.MLPModel(p).eval()
+    sd = {'w__' + k: v for k, v in mlp.state_dict().items()}
+    run('f10_lim_sde_mlp', mlp, [32, 1, 2], 25, 1.8, False, extra=sd)
+    run('f10_lim_ode_mlp', mlp, [32, 1, 2], 25, 1.8, True)
+    torch.manual_seed(1234)
+    net = make_unet(3, 32, [1, 2], [2], 4, 1).eval()
+    rerandomize(net, 4321)
+    run('f10_lim_sde_unet_tiny', net, [2, 3, 16, 16], 20, 1.8, False, clamp_eps=50, extra=dict(weight_digest=np.array(weight_digest(net))))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f5u', 'f6', 'f7', 'f8', 'f9']
-    table = dict(f1=f1_schedule, f2=f2_noise, f3=f3_tables, f4=f4_single_step, f5=f5_trajectories, f5u=f5_unet_trajectory,
+    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f5u', 'f6', 'f7', 'f8', 'f9', 'f10']
+    table = dict(f10=f10_lim, f1=f1_schedule, f2=f2_noise, f3=f3_tables, f4=f4_single_step, f5=f5_trajectories, f5u=f5_unet_trajectory,
                  f6=f6_models, f7=f7_layers, f8=f8_generation_manager, f9=f9_checkpoints)
     with torch.no_grad():
         for w in which:
