@@ -49,7 +49,7 @@ class SamplerConfig(C.Structure):
     _fields_ = [('unet', vp), ('mlp', vp), ('B', i64), ('C', i32), ('H', i32), ('W', i32), ('T', i32), ('alpha', f64),
                 ('clamp_a', f64), ('clamp_eps', f64), ('flags', i32), ('dlim_eta', f32), ('seed', u64),
                 ('sample_offset', i64), ('use_graph', i32), ('g', vp), ('bg', vp), ('s', vp), ('bs', vp),
-                ('lim_ts', vp), ('lim_tmp', vp), ('lim_cx', vp), ('lim_cs', vp), ('lim_cn', vp)]
+                ('lim_ts', vp), ('lim_tmp', vp), ('lim_cx', vp), ('lim_cs', vp), ('lim_cn', vp), ('in_scale', vp)]
 
 
 # name -> (restype, argtypes); one entry per function declared in include/dlpm_amd.h
@@ -59,6 +59,7 @@ SIGNATURES = {
     'dlpm_prof_enable': (C.c_int, [C.c_int]),
     'dlpm_prof_report': (C.c_int, [C.c_char_p, i64]),
     'dlpm_schedule_f32': (C.c_int, [C.c_int, f64, vp, vp, vp, vp]),
+    'dlpm_schedule_exploding_f32': (C.c_int, [C.c_int, f64, vp, vp, vp, vp]),
     'dlpm_mt19937_seed': (C.c_int, [C.POINTER(MT19937), u32]),
     'dlpm_skewed_levy_host_f32': (C.c_int, [C.POINTER(MT19937), f64, i64, f64, vp]),
     'dlpm_randn_host_f32': (C.c_int, [C.POINTER(MT19937), i64, vp]),
@@ -70,6 +71,7 @@ SIGNATURES = {
     'dlpm_update_f32': (C.c_int, [C.POINTER(UpdateArgs), vp]),
     'dlpm_fill_scaled_t_f32': (C.c_int, [vp, vp, i32, i64, vp]),
     'dlpm_postprocess_f32': (C.c_int, [vp, vp, i64, f32, C.c_int, vp]),
+    'dlpm_scale_by_table_f32': (C.c_int, [vp, vp, i64, vp, vp, vp]),
     'dlpm_lim_tables_f32': (C.c_int, [f64, i32, i32, vp, vp, vp, vp, vp]),
     'dlpm_lim_update_f32': (C.c_int, [C.POINTER(LimUpdateArgs), vp]),
     'dlpm_fill_table_t_f32': (C.c_int, [vp, vp, vp, i32, i64, vp]),

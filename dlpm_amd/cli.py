@@ -1,7 +1,7 @@
 """`eval.py --generate`-compatible command line for the sampling path (no dataset / neptune needed).
 
 Covers the reference flags that reach the sampler (script_utils.py:11-12,35-39,56-67,82-83,155-221):
-  --config --method --generate --reverse_steps --deterministic --clip --alpha --non_iso --set_seed/--random_seed
+  --config --method --generate --reverse_steps --deterministic --clip --alpha --non_iso --scale --input_scaling --set_seed/--random_seed
 plus the checkpoint to evaluate, resolved like eval.py does (eval.py:21, bem/utils_exp.py:96-139):
   --name N [--models_dir models] [--epoch E]  ->  models/N/<dataset>/model_<exphash>[_<E>].pt
 or given directly with --checkpoint FILE; --ema_eval [--ema_index I] evaluates an EMA shadow.
@@ -26,6 +26,8 @@ def main(argv=None):
     ap.add_argument('--reverse_steps', type=int, default=None)
     ap.add_argument('--alpha', type=float, default=None)
     ap.add_argument('--non_iso', action='store_true', help='non-isotropic noise (script_utils.py:26-27)')
+    ap.add_argument('--scale', default=None, choices=['scale_preserving', 'scale_exploding'], help='script_utils.py:104-105')
+    ap.add_argument('--input_scaling', action='store_true', help='script_utils.py:107-108')
     ap.add_argument('--deterministic', action='store_true', help='DLIM sampling')
     ap.add_argument('--clip', action='store_true', help='clip_denoised')
     ap.add_argument('--set_seed', type=int, default=None)
@@ -57,6 +59,10 @@ def main(argv=None):
         p[m]['alpha'] = a.alpha
     if a.non_iso:
         p[m]['isotropic'] = False
+    if a.scale is not None:
+        p[m]['scale'] = a.scale
+    if a.input_scaling:
+        p[m]['input_scaling'] = True
     if a.generate is not None:
         assert a.generate <= p['eval']['real_data'], 'cannot generate more data than the number of real data'
         p['eval']['data_to_generate'] = a.generate

@@ -130,6 +130,26 @@ extern "C" int dlpm_schedule_f32(int T, double alpha, float *g, float *bg, float
     return DLPM_OK;
 }
 
+extern "C" int dlpm_schedule_exploding_f32(int T, double alpha, float *g, float *bg, float *s, float *bs) {
+    DLPM_CHECK_ARG(T >= 2, "dlpm_schedule_exploding_f32: T must be >= 2, got %d", T);
+    DLPM_CHECK_ARG(alpha > 0.0 && alpha <= 2.0, "dlpm_schedule_exploding_f32: alpha must be in (0,2], got %g", alpha);
+    DLPM_CHECK_ARG(g && bg && s && bs, "dlpm_schedule_exploding_f32: null output");
+    const double smin = 0.002, smax = 80.0, rho = 7.0;
+    const double lo = std::pow(smin, 1.0 / rho), hi = std::pow(smax, 1.0 / rho);
+    double run = 0.0;   // sum of sigmas^alpha so far
+    for (int i = 0; i < T; i++) {
+        g[i] = 1.0f;
+        bg[i] = 1.0f;
+        const double b = std::pow(lo + ((double)i / (double)(T - 1)) * (hi - lo), rho);
+        bs[i] = (float)b;
+        const double ba = std::pow((double)bs[i], alpha);
+        const double sa = i == 0 ? ba : ba - run;
+        run += sa;
+        s[i] = (float)std::pow(sa, 1.0 / alpha);
+    }
+    return DLPM_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // MT19937 with numpy / torch draw semantics
 // ---------------------------------------------------------------------------------------------

@@ -469,6 +469,12 @@ __global__ void k_fill_t(float *tv, const int32_t *t, int32_t T, int64_t B) {
     if (i < B) tv[i] = __fmul_rn((float)(*t), 1.0f / (float)T);  // t.float() * (1.0 / T)
 }
 
+__global__ void k_scale_by_table(const float *x, float *o, int64_t n, const int32_t *t, const float *tab) {
+    const float sc = tab[*t];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        o[i] = __fmul_rn(x[i], sc);
+}
+
 __global__ void k_postprocess(const float *x, float *o, int64_t n, float c, int affine) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -630,6 +636,15 @@ extern "C" int dlpm_fill_table_t_f32(float *tvec_dev, const int32_t *t_dev, cons
 extern "C" int dlpm_fill_scaled_t_f32(float *tvec_dev, const int32_t *t_dev, int32_t T, int64_t B, dlpm_stream_t stream) {
     DLPM_CHECK_ARG(tvec_dev && t_dev && T > 0 && B > 0, "dlpm_fill_scaled_t_f32: bad argument");
     k_fill_t<<<(unsigned)ceil_div(B, 256), 256, 0, as_stream(stream)>>>(tvec_dev, t_dev, T, B);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_scale_by_table_f32(const float *x_dev, float *out_dev, int64_t n, const int32_t *t_dev,
+                                       const float *table_dev, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(x_dev && out_dev && t_dev && table_dev && n > 0, "dlpm_scale_by_table_f32: bad argument");
+    unsigned grid = (unsigned)std::min<int64_t>(ceil_div(n, 256), 256 * 16);
+    k_scale_by_table<<<grid, 256, 0, as_stream(stream)>>>(x_dev, out_dev, n, t_dev, table_dev);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }

@@ -23,6 +23,7 @@ struct dlpm_sampler {
     int64_t cols = 0;              // table columns: B, or B*D when non-isotropic
     bool lim = false;              // DLPM_SMP_LIM: continuous-time LIM updates (T = steps + 1)
     float *lim_ts = nullptr, *lim_tmp = nullptr, *lim_cx = nullptr, *lim_cs = nullptr, *lim_cn = nullptr;
+    float *in_scale = nullptr, *xin = nullptr;   // input_scaling table [T] and the scaled copy the net reads
     float **hist_cell = nullptr;   // device cell with the history base (see dlpm_update_args::hist_pp)
     float *hist = nullptr;         // its current value (caller-owned [T,B,D] buffer or null)
     float *x = nullptr, *eps = nullptr, *tvec = nullptr;
@@ -54,9 +55,14 @@ __global__ void k_set_t(int32_t *t, int32_t v) {
     } while (0)
 
 int model_forward(dlpm_sampler *s, hipStream_t st) {
+    const float *xin = s->x;
+    if (s->in_scale) {
+        TRY(dlpm_scale_by_table_f32(s->x, s->xin, s->cfg.B * s->D, s->t_dev, s->in_scale, st));
+        xin = s->xin;
+    }
     if (s->cfg.unet)
-        return dlpm_unet_forward(s->cfg.unet, s->x, s->tvec, s->eps, s->cfg.B, s->ws, s->ws_bytes, st);
-    return dlpm_mlp_forward(s->cfg.mlp, s->x, s->tvec, s->eps, s->cfg.B, st);
+        return dlpm_unet_forward(s->cfg.unet, xin, s->tvec, s->eps, s->cfg.B, s->ws, s->ws_bytes, st);
+    return dlpm_mlp_forward(s->cfg.mlp, xin, s->tvec, s->eps, s->cfg.B, st);
 }
 
 int one_step(dlpm_sampler *s, const float *z, bool advance, hipStream_t st) {
@@ -109,6 +115,7 @@ extern "C" int dlpm_sampler_create(const dlpm_sampler_config *cfg, dlpm_sampler 
     DLPM_CHECK_ARG(cfg->alpha > 0.0 && cfg->alpha <= 2.0, "Wrong value of alpha (%g) for skewed levy r.v generation", cfg->alpha);
     const bool have = cfg->g && cfg->bg && cfg->s && cfg->bs;
     DLPM_CHECK_ARG(have || (!cfg->g && !cfg->bg && !cfg->s && !cfg->bs), "dlpm_sampler_create: give all four schedule arrays or none");
+    DLPM_CHECK_ARG(!(cfg->in_scale && (cfg->flags & DLPM_SMP_LIM)), "dlpm_sampler_create: input scaling belongs to the DLPM loop");
     const bool is_lim = (cfg->flags & DLPM_SMP_LIM) != 0;
     const bool have_lim = cfg->lim_ts && cfg->lim_tmp && cfg->lim_cx && cfg->lim_cs && cfg->lim_cn;
     DLPM_CHECK_ARG(!is_lim || have_lim || (!cfg->lim_ts && !cfg->lim_tmp && !cfg->lim_cx && !cfg->lim_cs && !cfg->lim_cn),
@@ -148,6 +155,8 @@ extern "C" int dlpm_sampler_create(const dlpm_sampler_config *cfg, dlpm_sampler 
     }
     s->cfg.g = s->cfg.bg = s->cfg.s = s->cfg.bs = nullptr;  // host pointers are not retained
     s->cfg.lim_ts = s->cfg.lim_tmp = s->cfg.lim_cx = s->cfg.lim_cs = s->cfg.lim_cn = nullptr;
+    const float *h_in_scale = cfg->in_scale;
+    s->cfg.in_scale = nullptr;
     s->bs_last = hbs[T - 1];
     auto fail = [&](hipError_t e) {
         set_error("dlpm_sampler_create: %s", hipGetErrorString(e));
@@ -168,6 +177,11 @@ extern "C" int dlpm_sampler_create(const dlpm_sampler_config *cfg, dlpm_sampler 
             if ((e = hipMalloc(ld[i], T * sizeof(float))) != hipSuccess) return fail(e);
             if ((e = hipMemcpy(*ld[i], lsrc[i]->data(), T * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
         }
+    }
+    if (h_in_scale) {
+        if ((e = hipMalloc(&s->in_scale, T * sizeof(float))) != hipSuccess) return fail(e);
+        if ((e = hipMemcpy(s->in_scale, h_in_scale, T * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+        if ((e = hipMalloc(&s->xin, (size_t)B * s->D * sizeof(float))) != hipSuccess) return fail(e);
     }
     const size_t tb = (size_t)T * s->cols * sizeof(float);
     if ((e = hipMalloc(&s->A, tb)) != hipSuccess) return fail(e);
@@ -303,7 +317,7 @@ extern "C" int dlpm_sampler_steps(dlpm_sampler *s, int32_t nsteps, dlpm_stream_t
     // (one wave per sample: best while the batch is latency-bound; beyond ~16k samples the 4-samples-per-wave
     //  forward kernel + update kernel reuse the weights better)
     if (s->cfg.mlp && !(s->cfg.flags & (DLPM_UPD_DLIM | DLPM_UPD_CLIP | DLPM_SMP_NO_FUSED_MLP | DLPM_SMP_LIM)) && s->D <= 4 &&
-        s->cfg.B <= 16384 && !s->hist && !prof_enabled()) {
+        s->cfg.B <= 16384 && !s->hist && !s->in_scale && !prof_enabled()) {
         TRY(dlpm_mlp_sample_steps_f32(s->cfg.mlp, s->x, s->c_eps, s->c_noise, s->g, s->cfg.T, s->cfg.B, s->t_host, nsteps,
                                       s->cfg.seed, s->cfg.sample_offset, s->key_dev, st));
         s->t_host -= nsteps;
@@ -365,7 +379,8 @@ extern "C" void dlpm_sampler_destroy(dlpm_sampler *s) {
     if (s->ev_out) (void)hipEventDestroy(s->ev_out);
     if (s->own) (void)hipStreamDestroy(s->own);
     void *bufs[] = {s->g, s->bg, s->s, s->bs, s->A, s->c_eps == s->A ? nullptr : s->c_eps, s->c_noise, s->x, s->eps, s->tvec,
-                    s->t_dev, s->key_dev, s->ws, s->hist_cell, s->lim_ts, s->lim_tmp, s->lim_cx, s->lim_cs, s->lim_cn};
+                    s->t_dev, s->key_dev, s->ws, s->hist_cell, s->lim_ts, s->lim_tmp, s->lim_cx, s->lim_cs, s->lim_cn,
+                    s->in_scale, s->xin};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete s;

@@ -87,8 +87,6 @@ class GenerativeLevyProcess:
                                           'out in the reference, LIM/functions/sampler.py:144-148)')
             from .lim import VPSDE
             self.sde = VPSDE(alpha, 'cosine')
-        if input_scaling and scale == 'scale_exploding':
-            raise NotImplementedError('input_scaling is only active for scale_exploding, which is not implemented')
         assert rng in ('philox', 'reference')
         self.alpha, self.device, self.reverse_steps = alpha, device, reverse_steps
         self.model_mean_type, self.model_var_type = model_mean_type, model_var_type
@@ -132,6 +130,13 @@ class GenerativeLevyProcess:
             self._dataset = None
             self.calls += 1
 
+    def _input_scale(self):
+        """[T] host table 1/(1 + barsigma_t), or None: the factor the net input is multiplied by when input_scaling
+        is on and the process was built scale_exploding (GenerativeLevyProcess.py:176-180)."""
+        if self.input_scaling and self.dlpm.scale == 'scale_exploding':
+            return (1 / (1 + self.dlpm.host_schedule[3])).contiguous()
+        return None
+
     def _streams(self):
         if self.reference_streams is None:
             self.reference_streams = ReferenceStreams(self.seed, self.seed)
@@ -153,7 +158,8 @@ class GenerativeLevyProcess:
         if not self.isotropic:
             flags |= _lib.UPD_ELEMENTWISE
         key = (id(model), handles['unet'].value if handles['unet'] else handles['mlp'].value, tuple(shape),
-               self.reverse_steps, self.alpha, flags, eta, clamp_a, clamp_eps, self.use_graph, self.fused_mlp)
+               self.reverse_steps, self.alpha, flags, eta, clamp_a, clamp_eps, self.use_graph, self.fused_mlp,
+               self.dlpm.host_schedule[3].data_ptr(), self._input_scale() is not None)
         ent = self._samplers.get(key)
         if ent is not None:
             _lib.check(_lib.lib().dlpm_sampler_reseed(ent['h'], seed, offset))
@@ -178,6 +184,9 @@ class GenerativeLevyProcess:
         cfg.sample_offset, cfg.use_graph = offset, gs
         sched = self.dlpm.host_schedule
         cfg.g, cfg.bg, cfg.s, cfg.bs = (v.data_ptr() for v in sched)
+        isc = None if lim else self._input_scale()
+        if isc is not None:
+            cfg.in_scale = isc.data_ptr()
         if lim:
             from .lim import lim_tables
             tabs = lim_tables(self.sde, self.reverse_steps, bool(flags & _lib.UPD_DLIM))     # kept alive until create returns
@@ -316,6 +325,8 @@ class GenerativeLevyProcess:
                                           c_eps.data_ptr(), c_noise.data_ptr(), None, st))
         t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         tvec = torch.empty(B, dtype=torch.float32, device=dev)
+        isc = self._input_scale()
+        isc = None if isc is None else isc.to(dev)
         hist = [x.clone()] if history else []
         need_z = not (flags & _lib.UPD_DLIM) or eta != 0.0
         args = _lib.UpdateArgs()
@@ -330,7 +341,8 @@ class GenerativeLevyProcess:
         for i in range(T - 1, 0, -1):
             t_dev.fill_(i)
             _lib.check(L.dlpm_fill_scaled_t_f32(tvec.data_ptr(), t_dev.data_ptr(), T, B, st))
-            eps = model(x, tvec if self.rescale_timesteps else torch.full((B,), i, device=dev))
+            xin = x if isc is None else x * isc[i]
+            eps = model(xin, tvec if self.rescale_timesteps else torch.full((B,), i, device=dev))
             eps = eps.contiguous().float()
             z = None
             if host and need_z:

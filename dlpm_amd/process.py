@@ -37,13 +37,12 @@ class DLPM:
                  clamp_eps=None, scale='scale_preserving', native_schedule=False):
         if alpha > 2.0 or alpha <= 0.0:
             raise Exception('Wrong value of alpha ({}) for skewed levy r.v generation'.format(alpha))
-        if scale != 'scale_preserving':
-            raise NotImplementedError("only scale='scale_preserving' (every shipped config) is implemented")
+        assert scale in ('scale_preserving', 'scale_exploding'), 'Unknown scale'
         self.alpha, self.device, self.time_spacing, self.isotropic, self.scale = alpha, device, time_spacing, isotropic, scale
         self.native_schedule = native_schedule
         self.gen_a = NoiseParams('skewed_levy', alpha=alpha, device=device, isotropic=isotropic, clamp_a=clamp_a)
         self.gen_eps = NoiseParams('sas', alpha=alpha, device=device, isotropic=isotropic, clamp_eps=clamp_eps)
-        self._set_schedule(diffusion_steps)
+        self._set_schedule(diffusion_steps, scale)
 
     def get_timesteps(self, steps):
         if self.time_spacing == 'linear':
@@ -61,12 +60,23 @@ class DLPM:
         reference, which also builds it on the CPU and copies it over, dlpm.py:76-77).
         `native_schedule=True` uses libdlpm_amd's dlpm_schedule_f32 instead (<= 1 ulp on gammas).
         """
-        assert scale == 'scale_preserving'
         T = diffusion_steps
         if self.native_schedule:
             out = [np.empty(T, np.float32) for _ in range(4)]
-            _lib.check(_lib.lib().dlpm_schedule_f32(T, float(self.alpha), *[o.ctypes.data for o in out]))
+            fn = _lib.lib().dlpm_schedule_f32 if scale == 'scale_preserving' else _lib.lib().dlpm_schedule_exploding_f32
+            _lib.check(fn(T, float(self.alpha), *[o.ctypes.data for o in out]))
             return tuple(torch.from_numpy(o) for o in out)
+        if scale == 'scale_exploding':                                              # dlpm.py:134-149
+            ts = self.get_timesteps(T)
+            sigma_min, sigma_max, rho = 0.002, 80, 7
+            g, bg = torch.ones_like(ts), torch.ones_like(ts)
+            bsig = (sigma_min ** (1 / rho) + (ts / (T - 1)) * (sigma_max ** (1 / rho) - sigma_min ** (1 / rho))) ** rho
+            bsa = bsig ** self.alpha
+            sa = torch.ones_like(bsig) * bsa[0]
+            for i in range(1, len(bsig)):                 # the reference's running sums, summation order included
+                sa[i] = bsa[i] - torch.sum(sa[:i])
+            return g, bg, sa ** (1 / self.alpha), bsig
+        assert scale == 'scale_preserving', 'Unknown scale'
         s = 0.008
         ts = self.get_timesteps(T)
         f = torch.cos((ts / T + s) / (1 + s) * torch.pi / 2) ** 2
@@ -78,8 +88,8 @@ class DLPM:
         bsig = (1 - bg ** self.alpha) ** (1 / self.alpha)
         return g, bg, sig, bsig
 
-    def _set_schedule(self, T):
-        self.host_schedule = tuple(v.contiguous() for v in self.gen_noise_schedule(T))
+    def _set_schedule(self, T, scale='scale_preserving'):
+        self.host_schedule = tuple(v.contiguous() for v in self.gen_noise_schedule(T, scale))
         self.gammas, self.bargammas, self.sigmas, self.barsigmas = (v.to(self.device) for v in self.host_schedule)
         self.diffusion_steps = T
 
@@ -87,4 +97,6 @@ class DLPM:
         assert isinstance(diffusion_steps, int), 'Diffusion steps must be an integer'
         if time_spacing is not None:
             self.time_spacing = time_spacing
+        # as in the reference (dlpm.py:182-183) the regenerated schedule is ALWAYS scale_preserving, whatever
+        # self.scale says: a scale_exploding process sampled with reverse_steps != its own switches schedule
         self._set_schedule(diffusion_steps)

@@ -57,6 +57,12 @@ int dlpm_prof_report(char *buf, int64_t buf_bytes);
  * dlpm/methods/dlpm.py:103-156; also what rescale_diffusion (:176-185) recomputes. */
 int dlpm_schedule_f32(int T, double alpha, float *g, float *bg, float *s, float *bs);
 
+/* The 'scale_exploding' schedule (`--scale scale_exploding`, dlpm/methods/dlpm.py:134-149): gammas = bargammas = 1,
+ * barsigmas = Karras grid (sigma_min 0.002, sigma_max 80, rho 7), sigmas^alpha = successive differences of
+ * barsigmas^alpha (the reference accumulates them with an O(T^2) loop of running sums; this evaluates the same
+ * recurrence in double). */
+int dlpm_schedule_exploding_f32(int T, double alpha, float *g, float *bg, float *s, float *bs);
+
 /* MT19937 stream with numpy/torch semantics.  `cached`/`has_cached` is the spare double normal
  * torch's CPU generator keeps for its scalar (n < 16) path. */
 typedef struct dlpm_mt19937 {
@@ -165,6 +171,11 @@ int dlpm_update_f32(const dlpm_update_args *args, dlpm_stream_t stream);
 /* tvec_dev[b] = float(*t_dev) * (1/T): the `t/T` the reference feeds the net
  * (GenerativeLevyProcess._scale_timesteps, :92-96). */
 int dlpm_fill_scaled_t_f32(float *tvec_dev, const int32_t *t_dev, int32_t T, int64_t B, dlpm_stream_t stream);
+
+/* out_dev[i] = x_dev[i] * table_dev[*t_dev]: the `input_scaling` 1/(1 + barsigma_t) applied to the net input when
+ * the schedule is scale_exploding (GenerativeLevyProcess.py:176-180). */
+int dlpm_scale_by_table_f32(const float *x_dev, float *out_dev, int64_t n, const int32_t *t_dev, const float *table_dev,
+                            dlpm_stream_t stream);
 
 /* samples_dev <- clamp(x, -c, c) then (x+1)/2 for images: GenerationManager.generate post-processing,
  * bem/GenerationManager.py:50-63, bem/datasets/__init__.py:108-109. */
@@ -360,6 +371,7 @@ typedef struct dlpm_sampler_config {
     /* DLPM_SMP_LIM: T = steps + 1 and the schedule above is unused; host tables of dlpm_lim_tables_f32
      * (ts[T], the others [T-1]), or all NULL = computed by it */
     const float *lim_ts, *lim_tmp, *lim_cx, *lim_cs, *lim_cn;
+    const float *in_scale;      /* optional host table [T]: the net sees x * in_scale[t] (input_scaling), NULL = x */
 } dlpm_sampler_config;
 
 typedef struct dlpm_sampler dlpm_sampler;

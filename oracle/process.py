@@ -23,6 +23,15 @@ def schedule(T, alpha, scale='scale_preserving'):
         s = (1 - g ** alpha) ** (1 / alpha)
         bs = (1 - bg ** alpha) ** (1 / alpha)
         return g, bg, s, bs
+    if scale == 'scale_exploding':                                                  # dlpm.py:134-149
+        sigma_min, sigma_max, rho = 0.002, 80, 7
+        g, bg = torch.ones_like(ts), torch.ones_like(ts)
+        bs = (sigma_min ** (1 / rho) + (ts / (T - 1)) * (sigma_max ** (1 / rho) - sigma_min ** (1 / rho))) ** rho
+        bsa = bs ** alpha
+        sa = torch.ones_like(bs) * bsa[0]
+        for i in range(1, T):
+            sa[i] = bsa[i] - torch.sum(sa[:i])
+        return g, bg, sa ** (1 / alpha), bs
     raise NotImplementedError(scale)
 
 

@@ -40,10 +40,11 @@ class Streams:
 
 
 def sample(model, shape, T, alpha, streams, deterministic=False, dlim_eta=0.0, clip_denoised=False,
-           clamp_a=None, clamp_eps=None, get_sample_history=False, trace=None, isotropic=True):
+           clamp_a=None, clamp_eps=None, get_sample_history=False, trace=None, isotropic=True,
+           scale='scale_preserving', input_scaling=False):
     B = shape[0]
     n = B if isotropic else int(np.prod(shape))
-    g, bg, s, bs = P.schedule(T, alpha)
+    g, bg, s, bs = P.schedule(T, alpha, scale)
     A = torch.stack([streams.skewed_levy(alpha, n, clamp_a) for _ in range(T)])    # dlpm.py:226-227
     if not isotropic:
         A = A.reshape([T] + list(shape))
@@ -60,7 +61,8 @@ def sample(model, shape, T, alpha, streams, deterministic=False, dlim_eta=0.0, c
         trace.update(A=A, Sigmas=Sig, xT=x, z=[])
     for i in range(T - 1, 0, -1):
         t = torch.full((B,), i, dtype=torch.int64)
-        eps = model(x, t.float() * (1.0 / T))                                       # :92-96,180
+        xin = x * (1 / (1 + bs[i])) if input_scaling else x                         # :176-179 (scale_exploding only)
+        eps = model(xin, t.float() * (1.0 / T))                                     # :92-96,180
         if clip_denoised:
             eps = P.clipped_eps(x, eps, i, bg, bs)
         if deterministic:

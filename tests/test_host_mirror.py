@@ -171,6 +171,26 @@ def test_no_cpu_fallback():
         gm._post(torch.zeros(2, 3, 4, 4))
 
 
+@pytest.mark.parametrize('T,alpha', [(100, 1.7), (1000, 1.8), (30, 1.5)])
+def test_exploding_schedule_mirror_exact_native_close(T, alpha):
+    f = golden('f1_schedule')
+    tag = 'expl_T%d_a%s' % (T, str(alpha).replace('.', 'p'))
+    d = dlpm_amd.DLPM(alpha, 'cpu', T, scale='scale_exploding')
+    for name, v in zip(['g', 'bg', 's', 'bs'], d.host_schedule):
+        assert np.array_equal(v.numpy(), f[tag + '_' + name]), name
+    n = dlpm_amd.DLPM(alpha, 'cpu', T, scale='scale_exploding', native_schedule=True)
+    for name, v in zip(['g', 'bg', 's', 'bs'], n.host_schedule):
+        # sigmas are differences of nearly equal fp32 powers accumulated in fp32 by the reference: the double
+        # recurrence is the accurate side; agreement degrades towards t = 0 where sigma_t^alpha is ~1e-5 of the sum
+        np.testing.assert_allclose(v.numpy(), f[tag + '_' + name], rtol=2e-3 if name == 's' else 1e-6, err_msg=name)
+    # reference quirk: rescale_diffusion regenerates a scale_PRESERVING schedule
+    d.rescale_diffusion(20)
+    assert d.scale == 'scale_exploding' and float(d.host_schedule[0][5]) < 1.0
+    m = dlpm_amd.GenerativeLevyProcess(alpha, 'cpu', T, scale='scale_exploding', input_scaling=True)
+    assert torch.equal(m._input_scale(), 1 / (1 + m.dlpm.host_schedule[3]))
+    assert dlpm_amd.GenerativeLevyProcess(alpha, 'cpu', T, input_scaling=True)._input_scale() is None
+
+
 def test_product_never_imports_oracle():
     import subprocess, sys
     code = ("import sys; import dlpm_amd; "
@@ -186,8 +206,8 @@ def test_product_never_imports_oracle():
 def test_unsupported_paths_fail_loudly():
     with pytest.raises(NotImplementedError):
         dlpm_amd.GenerativeLevyProcess(1.7, 'cpu', 10, LIM=True, rescale_timesteps=True, isotropic=False)
-    with pytest.raises(NotImplementedError):
-        dlpm_amd.GenerativeLevyProcess(1.7, 'cpu', 10, scale='scale_exploding')
+    with pytest.raises(AssertionError, match='Unknown scale'):
+        dlpm_amd.GenerativeLevyProcess(1.7, 'cpu', 10, scale='scale_imploding')
     with pytest.raises(Exception, match='Wrong value of alpha'):
         dlpm_amd.DLPM(2.5, 'cpu', 10)
     m = dlpm_amd.GenerativeLevyProcess(1.7, 'cpu', 10, rescale_timesteps=False)

@@ -24,6 +24,14 @@ def test_schedule_bit_exact(T, alpha):
         assert np.array_equal(v.numpy(), f[tag + '_' + name]), name
 
 
+@pytest.mark.parametrize('T,alpha', [(100, 1.7), (1000, 1.8), (30, 1.5), (1000, 2.0)])
+def test_schedule_exploding_bit_exact(T, alpha):
+    f = golden('f1_schedule')
+    tag = 'expl_T%d_a%s' % (T, str(alpha).replace('.', 'p'))
+    for name, v in zip(['g', 'bg', 's', 'bs'], P.schedule(T, alpha, 'scale_exploding')):
+        assert np.array_equal(v.numpy(), f[tag + '_' + name], equal_nan=True), name
+
+
 # ---------------------------------------------------------------- F2
 @pytest.mark.parametrize('tag', ['s0_a1p7', 's1_a1p5', 's2_a1p8', 's3_a1p9', 's5_a1p2'])
 def test_skewed_levy_stream(tag):
@@ -131,6 +139,7 @@ TRAJ = [
     ('f5_traj_dlim_toy', Synth()), ('f5_traj_clip_img', Synth()), ('f5_traj_synth_img_big', Synth()),
     ('f5_traj_mlp_toy', 'mlp'),
     ('f5_traj_noniso_img', Synth()), ('f5_traj_noniso_clip_img', Synth()), ('f5_traj_noniso_dlim_img', Synth()),
+    ('f5_traj_exploding_img', Synth()), ('f5_traj_exploding_inscale_img', Synth()), ('f5_traj_exploding_inscale_toy', Synth()),
 ]
 
 
@@ -146,7 +155,9 @@ def test_trajectories_same_seeds(name, model):
     x, hist = sampler.sample(model, shape, int(T), float(alpha), sampler.Streams(0, 0), deterministic=bool(det),
                              dlim_eta=float(eta), clip_denoised=bool(clip), clamp_a=None if ca < 0 else float(ca),
                              clamp_eps=None if ce < 0 else float(ce), get_sample_history=True, trace=tr,
-                             isotropic='noniso' not in name)
+                             isotropic='noniso' not in name,
+                             scale='scale_exploding' if 'exploding' in name else 'scale_preserving',
+                             input_scaling='inscale' in name)
     nd = len(shape) - 1
     np.testing.assert_allclose(tr['A'].numpy(), f['A'], rtol=2e-7)
     np.testing.assert_allclose(tr['xT'].numpy(), f['xT'], rtol=2e-6, atol=1e-6)

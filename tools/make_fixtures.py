@@ -121,6 +121,10 @@ def f1_schedule():
     d = DLPM(1.7, 'cpu', 4000)
     d.rescale_diffusion(100)
     arrs['rescaled_4000_to_100_a1p7_bg'] = d.bargammas
+    for T, alpha in [(100, 1.7), (1000, 1.8), (30, 1.5), (1000, 2.0)]:             # --scale scale_exploding
+        d = DLPM(alpha, 'cpu', T, scale='scale_exploding')
+        tag = 'expl_T%d_a%s' % (T, str(alpha).replace('.', 'p'))
+        arrs[tag + '_g'], arrs[tag + '_bg'], arrs[tag + '_s'], arrs[tag + '_bs'] = d.gammas, d.bargammas, d.sigmas, d.barsigmas
     save('f1_schedule', **arrs)
 
 
@@ -242,10 +246,11 @@ class ZeroModel(torch.nn.Module):
 
 
 def run_traj(name, model, shape, T, alpha, deterministic=False, eta=0.0, clamp_a=None, clamp_eps=None,
-             clip=False, extra=None, isotropic=True):
+             clip=False, extra=None, isotropic=True, scale='scale_preserving', input_scaling=False, T_train=None):
     np.random.seed(0)
     torch.manual_seed(0)
-    meth = GenerativeLevyProcess(alpha=alpha, device='cpu', reverse_steps=T, rescale_timesteps=True, isotropic=isotropic)
+    meth = GenerativeLevyProcess(alpha=alpha, device='cpu', reverse_steps=T_train or T, rescale_timesteps=True,
+                                 isotropic=isotropic, scale=scale, input_scaling=input_scaling)
     with _Recorder() as rec:
         x, hist = meth.sample({'default': model}, shape, T, deterministic=deterministic, dlim_eta=eta,
                               clamp_a=clamp_a, clamp_eps=clamp_eps, clip_denoised=clip,
@@ -280,6 +285,15 @@ def f5_trajectories():
     run_traj('f5_traj_noniso_clip_img', SynthModel(), [3, 1, 4, 4], 25, 1.8, clamp_a=20, clamp_eps=200, clip=True,
              isotropic=False)
     run_traj('f5_traj_noniso_dlim_img', SynthModel(), [2, 3, 4, 4], 30, 1.7, deterministic=True, eta=0.0, isotropic=False)
+    # --scale scale_exploding (gamma = 1, Karras barsigma grid), with and without --input_scaling
+    run_traj('f5_traj_exploding_img', SynthModel(), [2, 3, 4, 4], 40, 1.7, clamp_a=10, clamp_eps=50, scale='scale_exploding')
+    run_traj('f5_traj_exploding_inscale_img', SynthModel(), [2, 3, 4, 4], 40, 1.7, clamp_a=10, clamp_eps=50,
+             scale='scale_exploding', input_scaling=True)
+    run_traj('f5_traj_exploding_inscale_toy', SynthModel(), [4, 1, 2], 30, 1.8, scale='scale_exploding', input_scaling=True)
+    # reference quirk: sampling a scale_exploding process with reverse_steps != its own regenerates a
+    # scale_PRESERVING schedule (rescale_diffusion, dlpm.py:182-183) while input_scaling stays on
+    run_traj('f5_traj_exploding_rescaled_img', SynthModel(), [2, 3, 4, 4], 25, 1.7, clamp_a=10, clamp_eps=50,
+             scale='scale_exploding', input_scaling=True, T_train=40)
 
     # real MLP (2d_data.yml), default torch init under manual_seed(1)
     p = yaml.safe_load(open(os.path.join(REF, 'dlpm/configs/2d_data.yml')))
