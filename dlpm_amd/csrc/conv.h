@@ -13,6 +13,8 @@ struct ConvLaunch {
     const float *w = nullptr;      // igemm: [ks*ks][Cout][Cin]   direct: [ks*ks][Cin][Cout]
     const float *w_frag = nullptr; // optional, 3x3 only: MFMA B-fragment order [Cout/32][Cin/32][9][4][64 lanes][4]
                                    // (see k_conv3x3_halo_ws): each wave streams it straight into registers
+    const float *w_wino = nullptr; // optional, 3x3 s1 only: Winograd-domain weights U = G g G^T in fragment order
+                                   // (see conv_wino.hip); when the shape qualifies the F(2x2,3x3) kernel runs
     const float *bias = nullptr;   // [Cout] or null
     const float *coefA = nullptr, *coefB = nullptr;  // [B, Cin] fused GroupNorm affine, or null
     int act_silu = 0;
@@ -22,9 +24,10 @@ struct ConvLaunch {
     int Cout = 0;
     int in_nchw = 0, out_nchw = 0;  // boundary layouts
     int abl = 0;                    // timing-only ablation bits (DLPM_ABL env; results are wrong when set)
-    // Optional fused GroupNorm statistics of the OUTPUT: per (image, 128-pixel tile, channel) the
+    // Optional fused GroupNorm statistics of the OUTPUT: per (image, pixel tile, channel) the
     // pair (mean, centred sum of squares) over the tile's pixels, written by the MFMA kernels'
-    // epilogue when the tile lies inside one image (Hout*Wout % 128 == 0).  [B][HW/128][Cout] float2.
+    // epilogue when the tile lies inside one image.  [B][HW/tile][Cout] float2 with tile =
+    // conv_stats_pixels(launch): 128 for the implicit-GEMM kernels, 256 for the Winograd kernel.
     float2 *stats_out = nullptr;
 };
 
@@ -33,6 +36,13 @@ bool igemm_supported(const ConvLaunch &c);
 int launch_conv_igemm(const ConvLaunch &c, hipStream_t st);
 int launch_conv_direct(const ConvLaunch &c, hipStream_t st);
 int launch_conv_stem(const ConvLaunch &c, hipStream_t st);
+// Winograd F(2x2,3x3) path (conv_wino.hip)
+bool wino_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg);
+int launch_conv_wino(const ConvLaunch &c, hipStream_t st);
+int64_t wino_weight_floats(int Cout, int Cin);
+int relayout_weight_wino(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st);
+// pixels behind one stats_out partial for this launch (0: the launch cannot emit statistics)
+int conv_stats_pixels(const ConvLaunch &c);
 // non-MFMA shapes: the stem kernel when it applies, the generic direct kernel otherwise
 inline int launch_conv_fallback(const ConvLaunch &L, hipStream_t st) {
     if (L.in_nchw && !L.out_nchw && L.ks == 3 && L.stride == 1 && !L.ups && L.C1 == 0 && L.Cout % 4 == 0 && !L.coefA &&
@@ -51,8 +61,8 @@ int launch_gn_coeffs(const float *src0, const float *src1, int C0, int C1, int B
                      const float *gamma, const float *beta, const float *ss, int64_t ss_stride, int64_t ss_offset,
                      float *coefA, float *coefB, hipStream_t st);
 // GroupNorm coefficients from per-tile channel statistics (see ConvLaunch::stats_out) instead of the
-// activations: st0/st1 = statistics of the two concat sources, nt = tiles per image.
-int launch_gn_coeffs_from_stats(const float2 *st0, const float2 *st1, int C0, int C1, int B, int nt, int HW, int groups,
+// activations: st0/st1 = statistics of the two concat sources, nt0/nt1 = their tiles per image.
+int launch_gn_coeffs_from_stats(const float2 *st0, const float2 *st1, int C0, int C1, int B, int nt0, int nt1, int HW, int groups,
                                 const float *gamma, const float *beta, const float *ss, int64_t ss_stride,
                                 int64_t ss_offset, float *coefA, float *coefB, hipStream_t st);
 int launch_attention(const float *qkv, float *out, int B, int T, int C, int heads, hipStream_t st);

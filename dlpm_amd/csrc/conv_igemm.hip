@@ -874,6 +874,13 @@ int launch_conv_stem(const ConvLaunch &c, hipStream_t st) {
     return DLPM_OK;
 }
 
+int conv_stats_pixels(const ConvLaunch &c) {
+    int a, b, n;
+    if (wino_geometry(c, &a, &b, &n)) return n == 1 ? 256 : 0;
+    if (c.out_nchw || (c.Cout & 3) || (c.R0 & 3)) return 0;
+    return ((int64_t)c.Hout * c.Wout) % BM == 0 ? BM : 0;
+}
+
 int launch_conv_igemm(const ConvLaunch &c, hipStream_t st) {
     const int64_t M = (int64_t)c.B * c.Hout * c.Wout;
     const int64_t mt = ceil_div(M, BM);
@@ -887,6 +894,17 @@ int launch_conv_igemm(const ConvLaunch &c, hipStream_t st) {
                  c.stride, c.ups, c.coefA ? 1 : 0);
     else
         snprintf(pname, sizeof(pname), "%s", c.ks == 3 ? (halo_ok(c, &th, &nimg) ? "conv3x3_halo" : "conv3x3_igemm") : "conv1x1_igemm");
+    {
+        int wb, ww, wi;
+        if (wino_geometry(c, &wb, &ww, &wi)) {
+            if (prof_enabled() && prof_detail())
+                snprintf(pname, sizeof(pname), "conv3x3_wino:H%d:Cin%d+%d:Cout%d:u%d:coef%d", c.Hout, c.C0, c.C1, c.Cout, c.ups, c.coefA ? 1 : 0);
+            else
+                snprintf(pname, sizeof(pname), "conv3x3_wino");
+            ProfScope psw(pname, 2.0 * M * c.Cout * K, bytes, st);   // ALGORITHMIC flops (direct-conv count)
+            return launch_conv_wino(c, st);
+        }
+    }
     ProfScope ps(pname, 2.0 * M * c.Cout * K, bytes, st);
     static int abl = -1;
     if (abl < 0) { const char *e = getenv("DLPM_ABL"); abl = e ? atoi(e) : 0; }

@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(512) k_gn_coeffs_v4(const float *__restrict__ 
 // stats_out): the activation itself is never re-read, so GroupNorm costs O(B*C) instead of a full
 // 4 B/element pass.  Tiles, then channels of a group, are merged with Chan's parallel update.
 __global__ void __launch_bounds__(256) k_gn_coeffs_stats(const float2 *__restrict__ st0, const float2 *__restrict__ st1, int C0,
-                                                         int C1, int nt, int HW, int G, const float *__restrict__ gamma,
+                                                         int C1, int nt0, int nt1, int HW, int G, const float *__restrict__ gamma,
                                                          const float *__restrict__ beta, const float *__restrict__ ss,
                                                          int64_t ss_stride, int64_t ss_offset, float *__restrict__ coefA,
                                                          float *__restrict__ coefB, float eps) {
@@ -185,8 +185,9 @@ __global__ void __launch_bounds__(256) k_gn_coeffs_stats(const float2 *__restric
     const int C = C0 + C1, cg = C / G;
     float *cmean = sh, *cm2 = sh + C, *mean = cm2 + C, *rstd = mean + G;
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-    const float npt = (float)(HW / nt);  // pixels per tile
     for (int c = tid; c < C; c += nthr) {
+        const int nt = (c < C0) ? nt0 : nt1;
+        const float npt = (float)(HW / nt);  // pixels per tile
         const float2 *sp = (c < C0) ? st0 + (int64_t)b * nt * C0 + c : st1 + (int64_t)b * nt * C1 + (c - C0);
         const int ld = (c < C0) ? C0 : C1;
         float m = sp[0].x, M2 = sp[0].y, na = npt;
@@ -232,13 +233,13 @@ __global__ void __launch_bounds__(256) k_gn_coeffs_stats(const float2 *__restric
 
 }  // namespace
 
-int launch_gn_coeffs_from_stats(const float2 *st0, const float2 *st1, int C0, int C1, int B, int nt, int HW, int groups,
+int launch_gn_coeffs_from_stats(const float2 *st0, const float2 *st1, int C0, int C1, int B, int nt0, int nt1, int HW, int groups,
                                 const float *gamma, const float *beta, const float *ss, int64_t ss_stride,
                                 int64_t ss_offset, float *coefA, float *coefB, hipStream_t st) {
     const int C = C0 + C1;
-    ProfScope ps("groupnorm_from_stats", 0.0, 8.0 * (double)B * nt * C + 8.0 * B * C, st);
+    ProfScope ps("groupnorm_from_stats", 0.0, 8.0 * (double)B * (nt0 * C0 + nt1 * C1) + 8.0 * B * C, st);
     k_gn_coeffs_stats<<<(unsigned)B, 256, (size_t)(2 * C + 2 * groups) * sizeof(float), st>>>(
-        st0, st1, C0, C1, nt, HW, groups, gamma, beta, ss, ss_stride, ss_offset, coefA, coefB, 1e-5f);
+        st0, st1, C0, C1, nt0, nt1 > 0 ? nt1 : 1, HW, groups, gamma, beta, ss, ss_stride, ss_offset, coefA, coefB, 1e-5f);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }

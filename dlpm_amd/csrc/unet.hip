@@ -40,6 +40,7 @@ struct ConvW {            // one convolution's weights
     bool use_igemm = false;
     float *w_dev = nullptr;  // re-laid-out copy (or the original for 1x1 igemm)
     float *w_frag = nullptr; // 3x3 only: MFMA fragment order for the weight-streaming halo kernel
+    float *w_wino = nullptr; // 3x3 only: Winograd-domain weights in fragment order (conv_wino.hip)
     bool owns = false;
 };
 
@@ -57,7 +58,8 @@ struct Layer {
 struct Tensor4 {
     float *p = nullptr;
     int C = 0, H = 0, W = 0;
-    float2 *stats = nullptr;  // per (image, 128-pixel tile, channel) (mean, M2) emitted by the producing conv, or null
+    float2 *stats = nullptr;  // per (image, pixel tile, channel) (mean, M2) emitted by the producing conv, or null
+    int stats_px = 0;         // pixels per tile of `stats` (128: implicit-GEMM kernels, 256: Winograd kernel)
 };
 
 struct Bump {
@@ -73,16 +75,22 @@ struct Bump {
     }
 };
 
-// GroupNorm statistics can ride on the producing conv's epilogue when its 128-pixel tiles stay inside
-// one image and the conv runs on the MFMA kernels with the row epilogue
-bool can_emit_stats(const ConvW &c, int H, int W) {
+// GroupNorm statistics can ride on the producing conv's epilogue when its pixel tiles stay inside one image
+// and the conv runs on the MFMA kernels with the row epilogue.  Decides (at plan time) whether `t`, produced by
+// conv `c` with the given geometry, carries statistics, and allocates them: tile size per conv_stats_pixels.
+void plan_stats(Bump &ws, Tensor4 &t, const ConvW &c, int B, int C0, int stride, int ups) {
     static int off = -1;
     if (off < 0) { const char *e = getenv("DLPM_NO_GN_FUSION"); off = (e && e[0] == '1') ? 1 : 0; }
-    return !off && c.use_igemm && (H * W) % 128 == 0 && (c.cout & 3) == 0;
-}
-
-float2 *alloc_stats(Bump &ws, int B, int H, int W, int C) {
-    return reinterpret_cast<float2 *>(ws.alloc((int64_t)2 * B * (H * W / 128) * C));
+    t.stats = nullptr;
+    t.stats_px = 0;
+    if (off || !c.use_igemm) return;
+    ConvLaunch L;
+    L.w_wino = c.w_wino; L.ks = c.ks; L.stride = stride; L.ups = ups; L.Hout = t.H; L.Wout = t.W; L.Cout = c.cout;
+    L.C0 = C0; L.C1 = c.cin - C0; L.B = B;
+    const int px = conv_stats_pixels(L);
+    if (px <= 0) return;
+    t.stats_px = px;
+    t.stats = reinterpret_cast<float2 *>(ws.alloc((int64_t)2 * B * (t.H * t.W / px) * t.C));
 }
 
 // GroupNorm(+scale/shift) coefficients of the virtual concat [x0 | x1]
@@ -90,8 +98,8 @@ int gn_any(Tensor4 x0, Tensor4 x1, int B, int groups, const float *gamma, const 
            int64_t ss_stride, int64_t ss_offset, float *cA, float *cB, hipStream_t st) {
     const int HW = x0.H * x0.W;
     if (x0.stats && (x1.C == 0 || x1.stats))
-        return launch_gn_coeffs_from_stats(x0.stats, x1.stats, x0.C, x1.C, B, HW / 128, HW, groups, gamma, beta, ss, ss_stride,
-                                           ss_offset, cA, cB, st);
+        return launch_gn_coeffs_from_stats(x0.stats, x1.stats, x0.C, x1.C, B, HW / x0.stats_px, x1.C ? HW / x1.stats_px : 1, HW,
+                                           groups, gamma, beta, ss, ss_stride, ss_offset, cA, cB, st);
     return launch_gn_coeffs(x0.p, x1.p, x0.C, x1.C, B, HW, groups, gamma, beta, ss, ss_stride, ss_offset, cA, cB, st);
 }
 
@@ -247,6 +255,11 @@ int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 no
         DLPM_HIP(hipMalloc(&c.w_frag, (size_t)frag_weight_floats(c.cout, c.cin) * sizeof(float)));
         int r = relayout_weight_frag(src, c.w_frag, c.cout, c.cin, nullptr);
         if (r != DLPM_OK) return r;
+        if (c.cout % 64 == 0 && c.cin % 16 == 0 && boundary == 0) {   // Winograd-domain copy (stride-1 launches pick it up)
+            DLPM_HIP(hipMalloc(&c.w_wino, (size_t)wino_weight_floats(c.cout, c.cin) * sizeof(float)));
+            r = relayout_weight_wino(src, c.w_wino, c.cout, c.cin, nullptr);
+            if (r != DLPM_OK) return r;
+        }
     }
     return relayout_weight(src, c.w_dev, c.cout, c.cin, c.ks, c.use_igemm, nullptr);
 }
@@ -254,6 +267,7 @@ int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 no
 int run_conv(const ConvW &c, ConvLaunch L, hipStream_t st) {
     L.w = c.w_dev;
     L.w_frag = c.w_frag;
+    L.w_wino = c.w_wino;
     L.ks = c.ks;
     L.Cout = c.cout;
     return c.use_igemm ? launch_conv_igemm(L, st) : launch_conv_fallback(L, st);
@@ -282,12 +296,12 @@ int run_res(Ctx &cx, const Layer &L, Tensor4 x0, Tensor4 x1, Tensor4 *out) {
     Tensor4 h1;
     h1.C = Co; h1.H = H; h1.W = W;
     h1.p = cx.ws.alloc((int64_t)B * HW * Co);
-    if (can_emit_stats(L.c1, H, W)) h1.stats = alloc_stats(cx.ws, B, H, W, Co);
+    plan_stats(cx.ws, h1, L.c1, B, C0, 1, 0);
     float *cA2 = cx.ws.alloc((int64_t)B * Co), *cB2 = cx.ws.alloc((int64_t)B * Co);
     float *sk = L.has_skip ? cx.ws.alloc((int64_t)B * HW * Co) : nullptr;
     float *o = cx.ws.alloc((int64_t)B * HW * Co);
     out->p = o; out->C = Co; out->H = H; out->W = W;
-    out->stats = can_emit_stats(L.c2, H, W) ? alloc_stats(cx.ws, B, H, W, Co) : nullptr;
+    plan_stats(cx.ws, *out, L.c2, B, Co, 1, 0);
     if (cx.dry()) return DLPM_OK;
     const int G1 = Cin < 32 ? Cin : 32, G2 = Co < 32 ? Co : 32;
     TRY(gn_any(x0, x1, B, G1, u->params[L.p_gn1_w].dev, u->params[L.p_gn1_b].dev, nullptr, 0, 0, cA1, cB1, cx.st));
@@ -322,7 +336,7 @@ int run_attn(Ctx &cx, const Layer &L, Tensor4 x, Tensor4 *out) {
     const Tensor4 xin = x;
     *out = x;
     out->p = o;
-    out->stats = can_emit_stats(L.c2, x.H, x.W) ? alloc_stats(cx.ws, B, x.H, x.W, C) : nullptr;
+    plan_stats(cx.ws, *out, L.c2, B, C, 1, 0);
     if (cx.dry()) return DLPM_OK;
     TRY(gn_any(xin, Tensor4(), B, C < 32 ? C : 32, u->params[L.p_gn1_w].dev, u->params[L.p_gn1_b].dev, nullptr, 0, 0, cA, cB,
                cx.st));
@@ -370,7 +384,7 @@ int run_seq(Ctx &cx, const std::vector<Layer> &seq, Tensor4 x0, Tensor4 x1, cons
                 o.H = up ? h.H * 2 : (h.H - 1) / 2 + 1;
                 o.W = up ? h.W * 2 : (h.W - 1) / 2 + 1;
                 o.p = cx.ws.alloc((int64_t)B * o.H * o.W * o.C);
-                if (can_emit_stats(L.c1, o.H, o.W)) o.stats = alloc_stats(cx.ws, B, o.H, o.W, o.C);
+                plan_stats(cx.ws, o, L.c1, B, h.C, up ? 1 : 2, up ? 1 : 0);
                 if (!cx.dry()) {
                     ConvLaunch a;
                     a.src0 = h.p; a.C0 = h.C; a.B = B; a.Hin = h.H; a.Win = h.W; a.Hout = o.H; a.Wout = o.W;
@@ -513,6 +527,8 @@ static void free_conv(ConvW &c) {
     if (c.owns && c.w_dev) (void)hipFree(c.w_dev);
     if (c.w_frag) (void)hipFree(c.w_frag);
     c.w_frag = nullptr;
+    if (c.w_wino) (void)hipFree(c.w_wino);
+    c.w_wino = nullptr;
     c.w_dev = nullptr;
     c.owns = false;
 }
@@ -686,7 +702,7 @@ extern "C" int dlpm_conv2d_f32(const dlpm_conv_args *a, float *scratch_dev, dlpm
     L.bias = a->bias; L.coefA = a->coefA; L.coefB = a->coefB; L.act_silu = a->act_silu;
     L.res0 = a->res0; L.res1 = a->res1; L.R0 = a->R0; L.out = a->out; L.Cout = a->Cout;
     L.in_nchw = a->in_nchw; L.out_nchw = a->out_nchw;
-    const bool ig = !a->force_direct && igemm_supported(L);
+    const bool ig = !(a->force_direct & 1) && igemm_supported(L);
     if ((a->in_nchw || a->out_nchw) && a->C1 != 0) {
         set_error("dlpm_conv2d_f32: NCHW boundary layouts do not combine with a concat input");
         return DLPM_ERR_UNSUPPORTED;
@@ -699,9 +715,16 @@ extern "C" int dlpm_conv2d_f32(const dlpm_conv_args *a, float *scratch_dev, dlpm
         float *wf = scratch_dev + (int64_t)a->Cout * (a->C0 + a->C1) * 9;
         TRY(relayout_weight_frag(a->weight, wf, a->Cout, a->C0 + a->C1, st));
         L.w_frag = wf;
+        const int64_t used = (int64_t)a->Cout * (a->C0 + a->C1) * 9 + frag_weight_floats(a->Cout, a->C0 + a->C1);
+        if (!(a->force_direct & 2) && a->stride == 1 && a->Cout % 64 == 0 && !a->in_nchw && !a->out_nchw &&
+            a->scratch_floats >= used + wino_weight_floats(a->Cout, a->C0 + a->C1)) {
+            float *ww = scratch_dev + used;
+            TRY(relayout_weight_wino(a->weight, ww, a->Cout, a->C0 + a->C1, st));
+            L.w_wino = ww;
+        }
     }
     if (ig) return launch_conv_igemm(L, st);
-    return a->force_direct ? launch_conv_direct(L, st) : launch_conv_fallback(L, st);
+    return (a->force_direct & 1) ? launch_conv_direct(L, st) : launch_conv_fallback(L, st);
 }
 
 extern "C" int dlpm_groupnorm_coeffs_f32(const float *src0, const float *src1, int32_t C0, int32_t C1, int32_t B, int32_t HW,

@@ -65,7 +65,7 @@ def run_conv(x0, w, bias=None, x1=None, stride=1, ups=0, coef=None, silu=False, 
     out = torch.empty((B, Cout, Hout, Wout) if out_nchw else (B, Hout, Wout, Cout), device=DEV)
     a.out, a.Cout = out.data_ptr(), Cout
     a.in_nchw, a.out_nchw, a.force_direct = int(in_nchw), int(out_nchw), int(force_direct)
-    scratch = torch.empty(3 * w.numel() + 16 * 1024 * (1 + Cout // 32), device=DEV)
+    scratch = torch.empty(5 * w.numel() + 16 * 1024 * (1 + Cout // 32), device=DEV)
     a.scratch_floats = scratch.numel()
     _lib.check(L().dlpm_conv2d_f32(C.byref(a), scratch.data_ptr(), st()))
     torch.cuda.synchronize()
@@ -133,6 +133,13 @@ def test_conv(case):
     got = run_conv(x0, w, bias, x1, stride, ups, coef, silu, res)
     assert got.shape == want.shape
     assert (got - want).abs().max().item() < conv_tol(w, Cin), name
+    if 'igemm' in name and ks == 3 and stride == 1:
+        # force_direct bit 1: no Winograd -- the same shape through the implicit-GEMM halo kernel (where the shape
+        # qualified for F(2x2,3x3) the run above took the Winograd kernel)
+        got_h = run_conv(x0, w, bias, x1, stride, ups, coef, silu, res, force_direct=2)
+        assert (got_h - want).abs().max().item() < conv_tol(w, Cin), name + ' (implicit GEMM)'
+        print('%s: winograd/auto err %.2e, implicit-GEMM err %.2e, tol %.2e' % (
+            name, (got - want).abs().max().item(), (got_h - want).abs().max().item(), conv_tol(w, Cin)))
     if 'igemm' in name:  # same shape through the direct kernel: the two kernels agree with each other
         got_d = run_conv(x0, w, bias, x1, stride, ups, coef, silu, res, force_direct=True)
         assert (got_d - want).abs().max().item() < conv_tol(w, Cin), name + ' (direct)'
