@@ -19,6 +19,7 @@ SOURCES = ['host.cpp', 'png.cpp', 'images.hip', 'noise.hip', 'conv_igemm.hip', '
            'embed.hip', 'unet.hip', 'mlp.hip', 'sampler.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
+FLAGS += ['-D' + d for d in os.environ.get('DLPM_BUILD_DEFS', '').split()]   # e.g. DLPM_WINO_ABLATIONS (timing experiments)
 
 
 def _stale(target, deps):

@@ -38,8 +38,9 @@ constexpr int RAW_NIT = RAW_MAXPIX * 4 / 256;   // 9 float4 per thread
 constexpr int WRING = 4;      // weight prefetch ring (groups of 4 MFMAs)
 constexpr int WGRP = 32;      // fragment groups per chunk: 16 positions x 2 k-quads
 
-template <bool UPS>
+template <bool UPS, int ABL>
 __global__ void __launch_bounds__(256, 1) k_conv3x3_wino(ConvLaunch p, int bh, int bw, int nimg) {
+    constexpr int abl = ABL;   // compile-time timing ablations (a runtime flag perturbs the schedule)
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float *V = wsm;                            // [16][WT][VLD]
     float *raw = wsm + 16 * WT * VLD;          // [npix][RLD]
@@ -199,8 +200,8 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_wino(ConvLaunch p, int bh, i
         if (more) load_raw(chunk + 1);
         if (chunk + 2 < nch) load_coef(chunk + 2);
 #pragma unroll
-        for (int g = 0; g < WGRP; g++) {
-            bq[(g + AHEAD) % WRING] = wbase[woff + AHEAD * 64];
+        for (int g = 0; g < ((abl & 1) ? 0 : WGRP); g++) {
+            if (!(abl & 16)) bq[(g + AHEAD) % WRING] = wbase[woff + AHEAD * 64];
             woff += 64;
             __builtin_amdgcn_sched_barrier(0);
             const int q = g >> 1, jq = g & 1;
@@ -212,14 +213,37 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_wino(ConvLaunch p, int bh, i
             acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, b.w, acc[q], 0, 0, 0);
         }
         if (more) {
-            store_raw((chunk + 1) & 1);   // raw is free: transform(chunk) finished before the last barrier
-            __syncthreads();              // raw(chunk+1) complete; every wave is done reading V(chunk)
-            transform();
+            if (!(abl & 4)) store_raw((chunk + 1) & 1);   // raw is free: transform(chunk) finished before the last barrier
+            if (!(abl & 8)) __syncthreads();              // raw(chunk+1) complete; every wave is done reading V(chunk)
+            if (!(abl & 2)) transform();
             store_coef(chunk & 1);        // coefficients of chunk + 2 into the slot store_raw(chunk) used
-            __syncthreads();
+            if (!(abl & 8)) __syncthreads();
         }
     }
     __syncthreads();   // the epilogue reuses V
+
+    // ---- epilogue addressing + residual prefetch: with one wave per SIMD nothing else hides a global load, so all 16
+    // residual rows of this thread are requested before the output transform and consumed after it
+    const int c4 = tid & 15, rg = tid >> 4;
+    const int n = n0 + c4 * 4;
+    const int R1 = p.Cout - p.R0;
+    int64_t mrow[16];
+    float4 resq[16];
+#pragma unroll
+    for (int pass = 0; pass < 16; pass++) {
+        const int row = pass * 16 + rg;
+        const int tile = row >> 2, i = (row >> 1) & 1, j = row & 1;
+        const int timg = tile / (bh * bw), r = tile - timg * (bh * bw);
+        const int ty = r / bw, tx = r - ty * bw;
+        const bool ok = img0 + timg < p.B;
+        const int64_t m = ((int64_t)min(img0 + timg, p.B - 1) * H + 2 * (ty0 + ty) + i) * W + 2 * (tx0 + tx) + j;
+        mrow[pass] = ok ? m : -1;
+        if (p.res0)
+            resq[pass] = (n < p.R0) ? *reinterpret_cast<const float4 *>(p.res0 + m * p.R0 + n)
+                                    : *reinterpret_cast<const float4 *>(p.res1 + m * R1 + (n - p.R0));
+    }
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bias = *reinterpret_cast<const float4 *>(p.bias + n);
 
     // ---- output transform in registers: Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]
     floatx16 y[4];
@@ -247,26 +271,18 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_wino(ConvLaunch p, int bh, i
             img[(tile * 4 + ij) * ELD + wn * 32 + l31] = y[ij][r];
         }
     __syncthreads();
-    const int c4 = tid & 15, rg = tid >> 4;
-    const int n = n0 + c4 * 4;
-    const int R1 = p.Cout - p.R0;
     const bool do_stats = p.stats_out != nullptr && nimg == 1;
     float4 K = make_float4(0.f, 0.f, 0.f, 0.f), s1 = K, s2 = K;
     int cnt = 0;
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias) bias = *reinterpret_cast<const float4 *>(p.bias + n);
+#pragma unroll
     for (int pass = 0; pass < 16; pass++) {
         const int row = pass * 16 + rg;
-        const int tile = row >> 2, i = (row >> 1) & 1, j = row & 1;
-        const int timg = tile / (bh * bw), r = tile - timg * (bh * bw);
-        const int ty = r / bw, tx = r - ty * bw;
-        if (img0 + timg >= p.B) continue;
-        const int64_t m = ((int64_t)(img0 + timg) * H + 2 * (ty0 + ty) + i) * W + 2 * (tx0 + tx) + j;
+        const int64_t m = mrow[pass];
+        if (m < 0) continue;
         float4 v = *reinterpret_cast<const float4 *>(img + row * ELD + c4 * 4);
         v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
         if (p.res0) {
-            const float4 q = (n < p.R0) ? *reinterpret_cast<const float4 *>(p.res0 + m * p.R0 + n)
-                                        : *reinterpret_cast<const float4 *>(p.res1 + m * R1 + (n - p.R0));
+            const float4 q = resq[pass];
             v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
         }
         if (do_stats) {
@@ -306,6 +322,401 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_wino(ConvLaunch p, int bh, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_conv3x3_wino_p: the same algorithm, software-pipelined.  With 16 accumulator tiles per wave only ONE wave fits
+// a SIMD, so nothing but the wave's own instruction stream can fill the MFMA shadow: here every phase (one
+// 8-channel chunk) is a single straight-line block in which the 64 MFMAs of chunk c are interleaved by the
+// scheduler with   S(c+2) GroupNorm+SiLU and LDS store of the raw patch prefetched a phase ago,
+//                  G(c+3) the global loads of the next raw patch,
+//                  X(c+1) the input transform raw -> V for the next chunk,
+// on double-buffered raw and V tiles (one barrier per phase).  All stages run unconditionally on a clamped chunk
+// index (the tail repeats the last chunk into dead buffers): a load inside a conditional would end the block.
+// ---------------------------------------------------------------------------------------------
+constexpr int PKC = 8;        // input channels per chunk
+constexpr int PVLD = 12;      // padded V row (floats): conflict-free ds_read_b128 over 16 consecutive tiles
+constexpr int PRLD = 12;      // padded raw row
+constexpr int PRAW_NIT = (RAW_MAXPIX * 2 + 255) / 256;   // 5 float4 per thread
+constexpr int PRAW_ROWS = PRAW_NIT * 128;                // 640 rows: every staging item has a slot, no store guards
+constexpr int PRING = 8;      // weight ring: 7 slots (1792 MFMA cycles) of prefetch distance
+
+// ACT: fused GroupNorm affine + SiLU on the input (the ResBlock convs) or a plain input (the Upsample conv); other
+// combinations take the phase-separated kernel.  Compile-time so that the phase has no branches at all.
+template <bool UPS, bool ACT>
+__global__ void __launch_bounds__(256, 1) k_conv3x3_wino_p(ConvLaunch p, int bh, int bw, int nimg) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float *V = wsm;                                  // [2][16][WT][PVLD]
+    float *raw = wsm + 2 * 16 * WT * PVLD;           // [2][PRAW_ROWS][PRLD]
+    float *Cf = raw + 2 * PRAW_ROWS * PRLD;          // [2 slots][16 images][2][8]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int W = p.Wout, H = p.Hout, TW = W >> 1, TH = H >> 1;
+    const int Ws = UPS ? (W >> 1) : W, Hs = UPS ? (H >> 1) : H;
+    const int Cin = p.C0 + p.C1, nch = Cin / PKC;
+    const int ntn = p.Cout / WN;
+    const int mb = blockIdx.x / ntn, n0 = (blockIdx.x % ntn) * WN;
+    int img0, ty0, tx0, blk_in_img = 0;
+    if (nimg == 1) {
+        const int bpr = TW / bw, bpi = (TH / bh) * bpr;
+        img0 = mb / bpi;
+        blk_in_img = mb - img0 * bpi;
+        ty0 = (blk_in_img / bpr) * bh;
+        tx0 = (blk_in_img % bpr) * bw;
+    } else {
+        img0 = mb * nimg;
+        ty0 = tx0 = 0;
+    }
+    const int RH = UPS ? bh + 2 : 2 * bh + 2, RW = UPS ? bw + 2 : 2 * bw + 2;
+    const int oy = UPS ? ty0 - 1 : 2 * ty0 - 1, ox = UPS ? tx0 - 1 : 2 * tx0 - 1;
+    const int rpi = RH * RW, npix = nimg * rpi;
+
+    // ---- raw staging: item = (pixel, channel quad of the 8-channel chunk)
+    const int squad = tid & 1;
+    int off[PRAW_NIT], cfo[PRAW_NIT];
+#pragma unroll
+    for (int it = 0; it < PRAW_NIT; it++) {
+        const int pix = it * 128 + (tid >> 1);
+        const int img = min(pix / rpi, nimg - 1), r = pix - img * rpi;
+        const int ry = r / RW, rx = r - ry * RW;
+        const int iy = oy + ry, ix = ox + rx;
+        const bool pad = pix >= npix || iy < 0 || iy >= Hs || ix < 0 || ix >= Ws || (img0 + img) >= p.B;
+        off[it] = pad ? -1 : (((img0 + img) * Hs + iy) * Ws + ix);
+        cfo[it] = img * 16 + squad * 4;
+    }
+    constexpr bool has_coef = ACT;
+    const int cf_img = tid >> 2, cf_isb = (tid >> 1) & 1;
+    const bool cf_mine = has_coef && tid < nimg * 4;
+    const float *cf_base = has_coef ? ((cf_isb ? p.coefB : p.coefA) + (int64_t)min(img0 + cf_img, p.B - 1) * Cin + squad * 4) : nullptr;
+    float4 xr[PRAW_NIT], cfr = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_raw = [&](int chunk) {
+        const int c = chunk * PKC + squad * 4;
+        const bool first = c < p.C0;
+        const float *sb = first ? p.src0 + c : p.src1 + (c - p.C0);
+        const int ld = first ? p.C0 : p.C1;
+#pragma unroll
+        for (int it = 0; it < PRAW_NIT; it++) xr[it] = *reinterpret_cast<const float4 *>(sb + (int64_t)max(off[it], 0) * ld);
+    };
+    auto load_coef = [&](int chunk) {
+        if (has_coef) cfr = *reinterpret_cast<const float4 *>(cf_base + chunk * PKC);
+    };
+    const int cf_dst = cf_mine ? cf_img * 16 + cf_isb * 8 + squad * 4 : -1;
+    auto store_coef = [&](int slot) {   // unconditional (threads without a coefficient write a dummy cell: no branch)
+        if (has_coef) *reinterpret_cast<float4 *>(Cf + (cf_dst >= 0 ? slot * 256 + cf_dst : 512 + squad * 4)) = cfr;
+    };
+    auto store_raw_item = [&](int slot, int it) {
+        float *rb = raw + slot * PRAW_ROWS * PRLD;
+        {
+            float4 x = xr[it];
+            if (ACT) {
+                const float4 ca = *reinterpret_cast<const float4 *>(Cf + slot * 256 + cfo[it]);
+                const float4 cb = *reinterpret_cast<const float4 *>(Cf + slot * 256 + cfo[it] + 8);
+                x.x = silu_f(fmaf(x.x, ca.x, cb.x));
+                x.y = silu_f(fmaf(x.y, ca.y, cb.y));
+                x.z = silu_f(fmaf(x.z, ca.z, cb.z));
+                x.w = silu_f(fmaf(x.w, ca.w, cb.w));
+            }
+            if (off[it] < 0) x = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding applies AFTER the activation
+            *reinterpret_cast<float4 *>(rb + (it * 128 + (tid >> 1)) * PRLD + squad * 4) = x;
+        }
+    };
+    auto store_raw = [&](int slot) {
+#pragma unroll
+        for (int it = 0; it < PRAW_NIT; it++) store_raw_item(slot, it);
+    };
+    // the same item in four pieces (one channel each), for the MFMA-interleaved phase body
+    float4 sca, scb, sx;
+    float4 nca[PRAW_NIT], ncb[PRAW_NIT];   // coefficient pairs read from LDS one slot ahead of their item
+    auto coef_prefetch = [&](int slot, int it) {
+        if (ACT) {
+            nca[it] = *reinterpret_cast<const float4 *>(Cf + slot * 256 + cfo[it]);
+            ncb[it] = *reinterpret_cast<const float4 *>(Cf + slot * 256 + cfo[it] + 8);
+        }
+    };
+    auto store_raw_piece = [&](int slot, int it, int j) {
+        if (j == 0) {
+            sx = xr[it];
+            if (ACT) { sca = nca[it]; scb = ncb[it]; }
+        }
+        if (ACT) {
+            if (j == 0) sx.x = silu_f(fmaf(sx.x, sca.x, scb.x));
+            if (j == 1) sx.y = silu_f(fmaf(sx.y, sca.y, scb.y));
+            if (j == 2) sx.z = silu_f(fmaf(sx.z, sca.z, scb.z));
+            if (j == 3) sx.w = silu_f(fmaf(sx.w, sca.w, scb.w));
+        }
+        if (j == 3) {
+            if (off[it] < 0) sx = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(raw + slot * PRAW_ROWS * PRLD + (it * 128 + (tid >> 1)) * PRLD + squad * 4) = sx;
+        }
+    };
+
+    // ---- input transform: (tile, quad) pairs over lanes, the row half is wave-uniform
+    const int half = wave & 1;
+    int rowoff[3], coloff[4];
+    int vofs;
+    {
+        const int pair = (wave >> 1) * 64 + lane;
+        const int tile = pair >> 1, tquad = pair & 1;
+        const int timg = tile / (bh * bw), r = tile - timg * (bh * bw);
+        const int ty = r / bw, tx = r - ty * bw;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int cc = UPS ? tx + ((k + 1) >> 1) : 2 * tx + k;
+            coloff[k] = cc * PRLD;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {   // patch rows half .. half + 2
+            const int kk = k + half;
+            const int rr = UPS ? ty + ((kk + 1) >> 1) : 2 * ty + kk;
+            rowoff[k] = (timg * rpi + rr * RW) * PRLD + tquad * 4;
+        }
+        vofs = tile * PVLD + tquad * 4;
+    }
+    const float sg = half ? -1.f : 1.f;
+    const int rowA = half ? 3 : 0, rowB = half ? 2 : 1;   // V rows produced from ta / tb
+    float4 ta[4], tb[4];
+    auto transform_col = [&](int slot, int c) {   // B^T d for patch column c (3 LDS reads)
+        const float *rb = raw + slot * PRAW_ROWS * PRLD;
+        const float4 e0 = *reinterpret_cast<const float4 *>(rb + rowoff[0] + coloff[c]);
+        const float4 e1 = *reinterpret_cast<const float4 *>(rb + rowoff[1] + coloff[c]);
+        const float4 e2 = *reinterpret_cast<const float4 *>(rb + rowoff[2] + coloff[c]);
+        // branch-free on the wave-uniform half (a branch would split the phase's straight-line block):
+        //   half 0 (e = d0,d1,d2): ta = d0 - d2 -> row 0,  tb = d1 + d2 -> row 1
+        //   half 1 (e = d1,d2,d3): ta = d1 - d3 -> row 3,  tb = d2 - d1 -> row 2
+        const float4 w = half ? e0 : e2;
+        ta[c] = make_float4(e0.x - e2.x, e0.y - e2.y, e0.z - e2.z, e0.w - e2.w);
+        tb[c] = make_float4(fmaf(sg, w.x, e1.x), fmaf(sg, w.y, e1.y), fmaf(sg, w.z, e1.z), fmaf(sg, w.w, e1.w));
+    };
+    auto transform_out = [&](int slot, int k) {   // (.) B for V row (k >> 2 ? rowB : rowA), column k & 3 (1 LDS write)
+        const int rr = k >> 2, cc = k & 3;
+        const float4 a = rr ? tb[0] : ta[0], b = rr ? tb[1] : ta[1], c = rr ? tb[2] : ta[2], d = rr ? tb[3] : ta[3];
+        float *o = V + slot * 16 * WT * PVLD + vofs + ((rr ? rowB : rowA) * 4 + cc) * WT * PVLD;
+        float4 v;
+        if (cc == 0) v = make_float4(a.x - c.x, a.y - c.y, a.z - c.z, a.w - c.w);
+        else if (cc == 1) v = make_float4(b.x + c.x, b.y + c.y, b.z + c.z, b.w + c.w);
+        else if (cc == 2) v = make_float4(c.x - b.x, c.y - b.y, c.z - b.z, c.w - b.w);
+        else v = make_float4(b.x - d.x, b.y - d.y, b.z - d.z, b.w - d.w);
+        *reinterpret_cast<float4 *>(o) = v;
+    };
+    float4 te0, te1, te2;
+    float4 ne[4][3];                        // patch columns read from LDS one slot ahead of their transform
+    auto col_prefetch = [&](int slot, int c) {
+        const float *rb = raw + slot * PRAW_ROWS * PRLD;
+        ne[c][0] = *reinterpret_cast<const float4 *>(rb + rowoff[0] + coloff[c]);
+        ne[c][1] = *reinterpret_cast<const float4 *>(rb + rowoff[1] + coloff[c]);
+        ne[c][2] = *reinterpret_cast<const float4 *>(rb + rowoff[2] + coloff[c]);
+    };
+    auto transform_col_piece = [&](int slot, int c, int j) {
+        if (j == 0) { te0 = ne[c][0]; te1 = ne[c][1]; te2 = ne[c][2]; }
+        if (j == 0) { ta[c].x = te0.x - te2.x; tb[c].x = fmaf(sg, half ? te0.x : te2.x, te1.x); }
+        if (j == 1) { ta[c].y = te0.y - te2.y; tb[c].y = fmaf(sg, half ? te0.y : te2.y, te1.y); }
+        if (j == 2) { ta[c].z = te0.z - te2.z; tb[c].z = fmaf(sg, half ? te0.z : te2.z, te1.z); }
+        if (j == 3) { ta[c].w = te0.w - te2.w; tb[c].w = fmaf(sg, half ? te0.w : te2.w, te1.w); }
+    };
+    auto transform = [&](int slot) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) transform_col(slot, c);
+#pragma unroll
+        for (int k = 0; k < 8; k++) transform_out(slot, k);
+    };
+
+    // ---- weight stream: Wf[nb][chunk][pos][lane][4], one float4 per position and chunk
+    const float4 *__restrict__ wbase = reinterpret_cast<const float4 *>(p.w_wino) + lane;
+    int64_t woff = (int64_t)((n0 >> 5) + wn) * nch * 16 * 64;
+    constexpr int AHEAD = PRING - 1;
+    float4 bq[PRING];
+    const float *asrc = V + (wm * 32 + l31) * PVLD + kh * 4;
+
+    floatx16 acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
+
+    // ---- prologue: S(0), S(1), X(0), G(2) and the coefficient slots
+    const int last = nch - 1;
+    load_raw(0);
+    load_coef(0);
+#pragma unroll
+    for (int a = 0; a < AHEAD; a++) bq[a] = wbase[woff + a * 64];
+    store_coef(0);
+    load_coef(min(1, last));
+    __syncthreads();
+    store_raw(0);
+    load_raw(min(1, last));
+    store_coef(1);
+    load_coef(min(2, last));
+    __syncthreads();
+    transform(0);
+    store_raw(1);
+    load_raw(min(2, last));
+    store_coef(0);   // coefficients of chunk 2 (slot 0 was last read by S(0), a barrier ago)
+    __syncthreads();
+
+    for (int chunk = 0; chunk < nch; chunk++) {
+        const int cur = chunk & 1, nxt = cur ^ 1;
+        load_coef(min(chunk + 3, last));
+        const float *ab = asrc + cur * 16 * WT * PVLD;
+        // One wave per SIMD: nothing hides a latency except this wave's own instruction stream, and the wave issues in
+        // order -- only what sits BETWEEN two MFMAs runs in an MFMA's 64-cycle shadow.  The phase is therefore laid out
+        // as 16 slots (one per position) x 4 MFMAs, each MFMA followed by a quarter of the slot's slice, the order
+        // pinned with sched_barrier; every LDS read is issued one slot (256 cycles) before its first use.
+        //   slot 1..5    S(chunk+2) item q-1 -> raw[cur]   (raw[cur] was read by X(chunk), a barrier ago)
+        //   slot 6       G(chunk+3): reload the staging registers
+        //   slot 7..10   X(chunk+1) column q-7: raw[nxt] -> registers
+        //   slot 11..14  X(chunk+1) outputs 2(q-11), 2(q-11)+1 -> V[nxt]
+        float4 afn = *reinterpret_cast<const float4 *>(ab);
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const float4 af = afn;
+            if (q < 15) afn = *reinterpret_cast<const float4 *>(ab + (q + 1) * WT * PVLD);
+            if (q < PRAW_NIT) coef_prefetch(cur, q);             // for the item staged in slot q + 1
+            if (q >= 6 && q < 10) col_prefetch(nxt, q - 6);       // for the column transformed in slot q + 1
+            bq[(q + AHEAD) % PRING] = wbase[woff + AHEAD * 64];
+            woff += 64;
+            const float4 b = bq[q % PRING];
+            if (q == 6) load_raw(min(chunk + 3, last));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float av = j == 0 ? af.x : j == 1 ? af.y : j == 2 ? af.z : af.w;
+                const float bv = j == 0 ? b.x : j == 1 ? b.y : j == 2 ? b.z : b.w;
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[q], 0, 0, 0);
+                if (q >= 1 && q <= PRAW_NIT) store_raw_piece(cur, q - 1, j);
+                if (q >= 7 && q < 11) transform_col_piece(nxt, q - 7, j);
+                if (q >= 11 && q < 15 && j == 1) transform_out(nxt, 2 * (q - 11));
+                if (q >= 11 && q < 15 && j == 3) transform_out(nxt, 2 * (q - 11) + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        store_coef(nxt);                        // coefficients of chunk+3 -> slot (chunk+3)&1
+        __syncthreads();
+    }
+    // (the last barrier of the loop also fences V: the epilogue reuses it)
+
+    const int c4 = tid & 15, rg = tid >> 4;
+    const int n = n0 + c4 * 4;
+    const int R1 = p.Cout - p.R0;
+    int64_t mrow[16];
+    float4 resq[16];
+#pragma unroll
+    for (int pass = 0; pass < 16; pass++) {
+        const int row = pass * 16 + rg;
+        const int tile = row >> 2, i = (row >> 1) & 1, j = row & 1;
+        const int timg = tile / (bh * bw), r = tile - timg * (bh * bw);
+        const int ty = r / bw, tx = r - ty * bw;
+        const bool ok = img0 + timg < p.B;
+        const int64_t m = ((int64_t)min(img0 + timg, p.B - 1) * H + 2 * (ty0 + ty) + i) * W + 2 * (tx0 + tx) + j;
+        mrow[pass] = ok ? m : -1;
+        if (p.res0)
+            resq[pass] = (n < p.R0) ? *reinterpret_cast<const float4 *>(p.res0 + m * p.R0 + n)
+                                    : *reinterpret_cast<const float4 *>(p.res1 + m * R1 + (n - p.R0));
+    }
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bias = *reinterpret_cast<const float4 *>(p.bias + n);
+
+    floatx16 y[4];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        float s0[4], s1[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            s0[a] = acc[a * 4 + 0][r] + acc[a * 4 + 1][r] + acc[a * 4 + 2][r];
+            s1[a] = acc[a * 4 + 1][r] - acc[a * 4 + 2][r] - acc[a * 4 + 3][r];
+        }
+        y[0][r] = s0[0] + s0[1] + s0[2];
+        y[1][r] = s1[0] + s1[1] + s1[2];
+        y[2][r] = s0[1] - s0[2] - s0[3];
+        y[3][r] = s1[1] - s1[2] - s1[3];
+    }
+    constexpr int ELD = WN + 4;
+    float *img = wsm;
+#pragma unroll
+    for (int ij = 0; ij < 4; ij++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int tile = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            img[(tile * 4 + ij) * ELD + wn * 32 + l31] = y[ij][r];
+        }
+    __syncthreads();
+    const bool do_stats = p.stats_out != nullptr && nimg == 1;
+    float4 K = make_float4(0.f, 0.f, 0.f, 0.f), s1 = K, s2 = K;
+    int cnt = 0;
+#pragma unroll
+    for (int pass = 0; pass < 16; pass++) {
+        const int row = pass * 16 + rg;
+        const int64_t m = mrow[pass];
+        if (m < 0) continue;
+        float4 v = *reinterpret_cast<const float4 *>(img + row * ELD + c4 * 4);
+        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+        if (p.res0) {
+            const float4 q = resq[pass];
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        if (do_stats) {
+            if (cnt == 0) K = v;
+            float d;
+            d = v.x - K.x; s1.x += d; s2.x = fmaf(d, d, s2.x);
+            d = v.y - K.y; s1.y += d; s2.y = fmaf(d, d, s2.y);
+            d = v.z - K.z; s1.z += d; s2.z = fmaf(d, d, s2.z);
+            d = v.w - K.w; s1.w += d; s2.w = fmaf(d, d, s2.w);
+            cnt++;
+        }
+        *reinterpret_cast<float4 *>(p.out + m * p.Cout + n) = v;
+    }
+    if (do_stats) {
+        __syncthreads();
+        float2 *part = reinterpret_cast<float2 *>(wsm);
+        const float fc = (float)(cnt > 0 ? cnt : 1);
+        const float mx = s1.x / fc, my = s1.y / fc, mz = s1.z / fc, mw = s1.w / fc;
+        part[rg * WN + c4 * 4 + 0] = make_float2(K.x + mx, fmaxf(s2.x - s1.x * mx, 0.f));
+        part[rg * WN + c4 * 4 + 1] = make_float2(K.y + my, fmaxf(s2.y - s1.y * my, 0.f));
+        part[rg * WN + c4 * 4 + 2] = make_float2(K.z + mz, fmaxf(s2.z - s1.z * mz, 0.f));
+        part[rg * WN + c4 * 4 + 3] = make_float2(K.w + mw, fmaxf(s2.w - s1.w * mw, 0.f));
+        __syncthreads();
+        if (tid < WN) {
+            const float npart = 16.0f;
+            float mean = part[tid].x, M2 = part[tid].y, na = npart;
+            for (int g = 1; g < 16; g++) {
+                const float2 q = part[g * WN + tid];
+                const float d = q.x - mean, N = na + npart;
+                mean += d * (npart / N);
+                M2 += q.y + d * d * (na * npart / N);
+                na = N;
+            }
+            const int nt = (H * W) / 256;
+            p.stats_out[((int64_t)img0 * nt + blk_in_img) * p.Cout + n0 + tid] = make_float2(mean, M2);
+        }
+    }
+}
+
+// OIHW (3x3) -> U = G g G^T in the pipelined kernel's fragment order  Wf[nb][chunk8][pos][lane][4]:
+// lane = h*32 + n holds U_pos[cin = chunk*8 + h*4 + e][cout = nb*32 + n].
+__global__ void k_relayout_weight_wino_p(const float *oihw, float *dst, int Cout, int Cin) {
+    const int nbk = Cout / 32, nch = Cin / PKC;
+    const int64_t total = (int64_t)nbk * nch * 16 * 64 * 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int e = (int)(i & 3);
+    const int lane = (int)((i >> 2) & 63);
+    int64_t r = i >> 8;
+    const int pos = (int)(r & 15); r >>= 4;
+    const int chunk = (int)(r % nch);
+    const int nb = (int)(r / nch);
+    const int h = lane >> 5, nn = lane & 31;
+    const int cin = chunk * PKC + h * 4 + e, cout = nb * 32 + nn;
+    const float *g = oihw + ((int64_t)cout * Cin + cin) * 9;
+    const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+    const int a = pos >> 2, b = pos & 3;
+    float u = 0.f;
+    for (int ii = 0; ii < 3; ii++) {
+        float row = 0.f;
+        for (int jj = 0; jj < 3; jj++) row += g[ii * 3 + jj] * G[b][jj];
+        u += G[a][ii] * row;
+    }
+    dst[i] = u;
+}
+
 // OIHW (3x3) -> U = G g G^T in fragment order  Wf[nb][chunk][pos][jq][lane][4]:
 // lane = h*32 + n holds U_pos[cin = chunk*16 + h*8 + jq*4 + e][cout = nb*32 + n].
 __global__ void k_relayout_weight_wino(const float *oihw, float *dst, int Cout, int Cin) {
@@ -335,6 +746,12 @@ __global__ void k_relayout_weight_wino(const float *oihw, float *dst, int Cout, 
 }
 
 }  // namespace
+
+static bool wino_pipelined() {   // DLPM_WINO_P=0 selects the phase-separated kernel (and its weight layout)
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DLPM_WINO_P"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
 
 static bool wino_disabled() {
     static int v = -1;
@@ -379,18 +796,41 @@ int launch_conv_wino(const ConvLaunch &c, hipStream_t st) {
     const int64_t mblocks = nimg == 1 ? tiles / WT : ceil_div(c.B, nimg);
     const int64_t grid = mblocks * (c.Cout / WN);
     const size_t shmem = (size_t)(16 * WT * VLD + RAW_MAXPIX * RLD + 2 * 512) * sizeof(float);
-    static bool attr[2] = {false, false};
-    if (!attr[c.ups ? 1 : 0]) {
-        if (c.ups)
-            DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_wino<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        else
-            DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_wino<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr[c.ups ? 1 : 0] = true;
+    static int abl = -1;   // timing-only ablations (results are wrong when set): 1 no MFMA loop, 2 no transform,
+    if (abl < 0) { const char *e = getenv("DLPM_WABL"); abl = e ? atoi(e) : 0; }   // 4 no raw store, 8 no barriers, 16 no weight loads
+    using KFn = void (*)(ConvLaunch, int, int, int);
+    KFn fn = c.ups ? &k_conv3x3_wino<true, 0> : &k_conv3x3_wino<false, 0>;
+    size_t shmem_p = (size_t)(2 * 16 * WT * PVLD + 2 * PRAW_ROWS * PRLD + 512 + 8) * sizeof(float);
+    const bool act = c.coefA && c.act_silu, plain = !c.coefA && !c.act_silu;
+    const bool piped = wino_pipelined() && (act || plain);
+    if (piped) {
+        if (act) fn = c.ups ? &k_conv3x3_wino_p<true, true> : &k_conv3x3_wino_p<false, true>;
+        else fn = c.ups ? &k_conv3x3_wino_p<true, false> : &k_conv3x3_wino_p<false, false>;
     }
-    if (c.ups) k_conv3x3_wino<true><<<(unsigned)grid, 256, shmem, st>>>(c, bh, bw, nimg);
-    else k_conv3x3_wino<false><<<(unsigned)grid, 256, shmem, st>>>(c, bh, bw, nimg);
+#ifdef DLPM_WINO_ABLATIONS
+    if (!c.ups) {
+        switch (abl) {
+            case 1: fn = &k_conv3x3_wino<false, 1>; break;
+            case 2: fn = &k_conv3x3_wino<false, 2>; break;
+            case 4: fn = &k_conv3x3_wino<false, 4>; break;
+            case 6: fn = &k_conv3x3_wino<false, 6>; break;
+            case 8: fn = &k_conv3x3_wino<false, 8>; break;
+            case 16: fn = &k_conv3x3_wino<false, 16>; break;
+            case 14: fn = &k_conv3x3_wino<false, 14>; break;
+            case 15: fn = &k_conv3x3_wino<false, 15>; break;
+            default: break;
+        }
+    }
+#endif
+    static const void *configured[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // (not during graph capture: the first
+    bool seen = false;                                                          //  launch of each kernel is eager)
+    for (const void *q : configured) seen = seen || q == reinterpret_cast<const void *>(fn);
+    if (!seen) {
+        DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (auto &q : configured)
+            if (!q) { q = reinterpret_cast<const void *>(fn); break; }
+    }
+    fn<<<(unsigned)grid, 256, piped ? shmem_p : shmem, st>>>(c, bh, bw, nimg);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }
@@ -403,7 +843,8 @@ int64_t wino_weight_floats(int Cout, int Cin) {
 int relayout_weight_wino(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st) {
     const int64_t n = (int64_t)(Cout / 32) * (Cin / WKC) * WGRP * 256;
     DLPM_HIP(hipMemsetAsync(dst_dev + n, 0, (size_t)(WRING - 1) * 256 * sizeof(float), st));
-    k_relayout_weight_wino<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
+    if (wino_pipelined()) k_relayout_weight_wino_p<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
+    else k_relayout_weight_wino<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }
