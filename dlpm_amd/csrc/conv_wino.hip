@@ -341,8 +341,10 @@ constexpr int PRING = 8;      // weight ring: 7 slots (1792 MFMA cycles) of pref
 
 // ACT: fused GroupNorm affine + SiLU on the input (the ResBlock convs) or a plain input (the Upsample conv); other
 // combinations take the phase-separated kernel.  Compile-time so that the phase has no branches at all.
-template <bool UPS, bool ACT>
+template <bool UPS, bool ACT, int ABL = 0>
 __global__ void __launch_bounds__(256, 1) k_conv3x3_wino_p(ConvLaunch p, int bh, int bw, int nimg) {
+    // ABL (timing experiments, DLPM_WINO_ABLATIONS builds): 1 no S pieces, 2 no X pieces, 4 no raw loads, 8 no barrier,
+    // 16 no weight loads, 32 no MFMA
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float *V = wsm;                                  // [2][16][WT][PVLD]
     float *raw = wsm + 2 * 16 * WT * PVLD;           // [2][PRAW_ROWS][PRLD]
@@ -433,20 +435,41 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_wino_p(ConvLaunch p, int bh,
             ncb[it] = *reinterpret_cast<const float4 *>(Cf + slot * 256 + cfo[it] + 8);
         }
     };
-    auto store_raw_piece = [&](int slot, int it, int j) {
-        if (j == 0) {
-            sx = xr[it];
-            if (ACT) { sca = nca[it]; scb = ncb[it]; }
+    // One staging item in six stages, each a handful of INDEPENDENT instructions that fits an MFMA's 64-cycle shadow
+    // (v_exp / v_rcp are quarter rate: 16 cycles each, two per stage):
+    //   0: t = x*ca + cb, m = -t*log2(e)   1: e.xy = exp2(m.xy)   2: e.zw = exp2(m.zw)
+    //   3: d = 1 + e, r.xy = rcp(d.xy)     4: r.zw = rcp(d.zw), y = t*r            5: zero padding, LDS store
+    float4 st, sm;
+    auto store_raw_stage = [&](int slot, int it, int stg) {
+        if (!ACT) {
+            if (stg == 5) {
+                float4 x = xr[it];
+                if (off[it] < 0) x = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(raw + slot * PRAW_ROWS * PRLD + (it * 128 + (tid >> 1)) * PRLD + squad * 4) = x;
+            }
+            return;
         }
-        if (ACT) {
-            if (j == 0) sx.x = silu_f(fmaf(sx.x, sca.x, scb.x));
-            if (j == 1) sx.y = silu_f(fmaf(sx.y, sca.y, scb.y));
-            if (j == 2) sx.z = silu_f(fmaf(sx.z, sca.z, scb.z));
-            if (j == 3) sx.w = silu_f(fmaf(sx.w, sca.w, scb.w));
+        if (stg == 0) {
+            const float4 x = xr[it], ca = nca[it], cb = ncb[it];
+            st = make_float4(fmaf(x.x, ca.x, cb.x), fmaf(x.y, ca.y, cb.y), fmaf(x.z, ca.z, cb.z), fmaf(x.w, ca.w, cb.w));
+            const float k = -1.4426950408889634f;
+            sm = make_float4(st.x * k, st.y * k, st.z * k, st.w * k);
         }
-        if (j == 3) {
-            if (off[it] < 0) sx = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(raw + slot * PRAW_ROWS * PRLD + (it * 128 + (tid >> 1)) * PRLD + squad * 4) = sx;
+        if (stg == 1) { sm.x = __builtin_amdgcn_exp2f(sm.x); sm.y = __builtin_amdgcn_exp2f(sm.y); }
+        if (stg == 2) { sm.z = __builtin_amdgcn_exp2f(sm.z); sm.w = __builtin_amdgcn_exp2f(sm.w); }
+        if (stg == 3) {
+            sm = make_float4(1.0f + sm.x, 1.0f + sm.y, 1.0f + sm.z, 1.0f + sm.w);
+            sm.x = __builtin_amdgcn_rcpf(sm.x);
+            sm.y = __builtin_amdgcn_rcpf(sm.y);
+        }
+        if (stg == 4) {
+            sm.z = __builtin_amdgcn_rcpf(sm.z);
+            sm.w = __builtin_amdgcn_rcpf(sm.w);
+            st = make_float4(st.x * sm.x, st.y * sm.y, st.z * sm.z, st.w * sm.w);
+        }
+        if (stg == 5) {
+            if (off[it] < 0) st = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(raw + slot * PRAW_ROWS * PRLD + (it * 128 + (tid >> 1)) * PRLD + squad * 4) = st;
         }
     };
 
@@ -506,12 +529,15 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_wino_p(ConvLaunch p, int bh,
         ne[c][1] = *reinterpret_cast<const float4 *>(rb + rowoff[1] + coloff[c]);
         ne[c][2] = *reinterpret_cast<const float4 *>(rb + rowoff[2] + coloff[c]);
     };
-    auto transform_col_piece = [&](int slot, int c, int j) {
-        if (j == 0) { te0 = ne[c][0]; te1 = ne[c][1]; te2 = ne[c][2]; }
-        if (j == 0) { ta[c].x = te0.x - te2.x; tb[c].x = fmaf(sg, half ? te0.x : te2.x, te1.x); }
-        if (j == 1) { ta[c].y = te0.y - te2.y; tb[c].y = fmaf(sg, half ? te0.y : te2.y, te1.y); }
-        if (j == 2) { ta[c].z = te0.z - te2.z; tb[c].z = fmaf(sg, half ? te0.z : te2.z, te1.z); }
-        if (j == 3) { ta[c].w = te0.w - te2.w; tb[c].w = fmaf(sg, half ? te0.w : te2.w, te1.w); }
+    auto transform_col_part = [&](int c, int part) {   // part 0: channels x,y   part 1: z,w
+        if (part == 0) {
+            te0 = ne[c][0]; te1 = ne[c][1]; te2 = ne[c][2];
+            ta[c].x = te0.x - te2.x; tb[c].x = fmaf(sg, half ? te0.x : te2.x, te1.x);
+            ta[c].y = te0.y - te2.y; tb[c].y = fmaf(sg, half ? te0.y : te2.y, te1.y);
+        } else {
+            ta[c].z = te0.z - te2.z; tb[c].z = fmaf(sg, half ? te0.z : te2.z, te1.z);
+            ta[c].w = te0.w - te2.w; tb[c].w = fmaf(sg, half ? te0.w : te2.w, te1.w);
+        }
     };
     auto transform = [&](int slot) {
 #pragma unroll
@@ -558,40 +584,45 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_wino_p(ConvLaunch p, int bh,
         load_coef(min(chunk + 3, last));
         const float *ab = asrc + cur * 16 * WT * PVLD;
         // One wave per SIMD: nothing hides a latency except this wave's own instruction stream, and the wave issues in
-        // order -- only what sits BETWEEN two MFMAs runs in an MFMA's 64-cycle shadow.  The phase is therefore laid out
-        // as 16 slots (one per position) x 4 MFMAs, each MFMA followed by a quarter of the slot's slice, the order
-        // pinned with sched_barrier; every LDS read is issued one slot (256 cycles) before its first use.
-        //   slot 1..5    S(chunk+2) item q-1 -> raw[cur]   (raw[cur] was read by X(chunk), a barrier ago)
-        //   slot 6       G(chunk+3): reload the staging registers
-        //   slot 7..10   X(chunk+1) column q-7: raw[nxt] -> registers
-        //   slot 11..14  X(chunk+1) outputs 2(q-11), 2(q-11)+1 -> V[nxt]
+        // order -- only what sits BETWEEN two MFMAs runs in an MFMA's 64-cycle shadow.  The phase is therefore a fixed
+        // program of 64 gaps g = 4*position + k-step, each MFMA followed by one small piece of the side work, the order
+        // pinned with sched_barrier; every LDS read is issued two or more gaps before its first use.
+        //   g  2..31   S(chunk+2): item (g-2)/6, stage (g-2)%6 -> raw[cur]  (raw[cur] was read by X(chunk), a barrier ago)
+        //   g 32       G(chunk+3): reload the staging registers
+        //   g 34..41   X(chunk+1): column (g-34)/2 of B^T d, half of the channels each
+        //   g 44..51   X(chunk+1): output g-44 of (.) B -> V[nxt]
         float4 afn = *reinterpret_cast<const float4 *>(ab);
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const float4 af = afn;
             if (q < 15) afn = *reinterpret_cast<const float4 *>(ab + (q + 1) * WT * PVLD);
-            if (q < PRAW_NIT) coef_prefetch(cur, q);             // for the item staged in slot q + 1
-            if (q >= 6 && q < 10) col_prefetch(nxt, q - 6);       // for the column transformed in slot q + 1
-            bq[(q + AHEAD) % PRING] = wbase[woff + AHEAD * 64];
+            if (!(ABL & 16)) bq[(q + AHEAD) % PRING] = wbase[woff + AHEAD * 64];
             woff += 64;
             const float4 b = bq[q % PRING];
-            if (q == 6) load_raw(min(chunk + 3, last));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
+                const int g = q * 4 + j;
                 const float av = j == 0 ? af.x : j == 1 ? af.y : j == 2 ? af.z : af.w;
                 const float bv = j == 0 ? b.x : j == 1 ? b.y : j == 2 ? b.z : b.w;
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[q], 0, 0, 0);
-                if (q >= 1 && q <= PRAW_NIT) store_raw_piece(cur, q - 1, j);
-                if (q >= 7 && q < 11) transform_col_piece(nxt, q - 7, j);
-                if (q >= 11 && q < 15 && j == 1) transform_out(nxt, 2 * (q - 11));
-                if (q >= 11 && q < 15 && j == 3) transform_out(nxt, 2 * (q - 11) + 1);
+                if (!(ABL & 32)) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[q], 0, 0, 0);
+                if (!(ABL & 1)) {
+                    if (g < 30 && g % 6 == 0) coef_prefetch(cur, g / 6);          // 2 gaps ahead of stage 0 of item g/6
+                    if (g >= 2 && g < 32) store_raw_stage(cur, (g - 2) / 6, (g - 2) % 6);
+                }
+                if (g == 32 && !(ABL & 4)) load_raw(min(chunk + 3, last));
+                if (!(ABL & 2)) {
+                    if (g >= 32 && g < 40 && g % 2 == 0) col_prefetch(nxt, (g - 32) / 2);   // 2 gaps ahead of its column
+                    if (g >= 34 && g < 42) transform_col_part((g - 34) / 2, (g - 34) % 2);
+                    if (g >= 44 && g < 52) transform_out(nxt, g - 44);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         store_coef(nxt);                        // coefficients of chunk+3 -> slot (chunk+3)&1
-        __syncthreads();
+        if (!(ABL & 8)) __syncthreads();
     }
+    if (ABL & 8) __syncthreads();
     // (the last barrier of the loop also fences V: the epilogue reuses it)
 
     const int c4 = tid & 15, rg = tid >> 4;
@@ -690,6 +721,348 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_wino_p(ConvLaunch p, int bh,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_conv3x3_wino_q: eight waves per workgroup, two per SIMD.
+// Measured on gfx950 (tools/mb/mfma_valu_overlap.hip): a wave's own VALU instructions do NOT run in the shadow of its
+// MFMAs (68 cycles per MFMA alone, 79 with four v_fma behind each one) -- only ANOTHER wave of the SIMD can use the
+// vector ALU while the matrix pipe is busy.  So the 256-KB accumulator block of the workgroup is split over 8 waves:
+// wave (ph, wm, wn) holds the 8 positions of transform rows a = 2ph, 2ph+1 for 32 tiles x 32 channels (128 AGPRs, two
+// waves per SIMD), and the staging / transform work of one wave overlaps the MFMAs of its SIMD neighbour.  The output
+// transform Y = A^T M A splits by rows: each wave reduces its 8 accumulators to 4 partial 2x2-output tiles in registers,
+// the ph = 1 waves pass theirs through LDS, the ph = 0 waves add them (fixed order: deterministic).
+// Phase structure as in k_conv3x3_wino_p: double-buffered raw / V, one barrier per 8-channel chunk.
+// ---------------------------------------------------------------------------------------------
+constexpr int QRAW_NIT = (RAW_MAXPIX * 2 + 511) / 512;   // 3 float4 per thread (512 threads)
+constexpr int QRING = 4;
+
+template <bool UPS>
+__global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh, int bw, int nimg) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float *V = wsm;                                  // [2][16][WT][PVLD]
+    float *raw = wsm + 2 * 16 * WT * PVLD;           // [2][RAW_MAXPIX][PRLD]
+    float *Cf = raw + 2 * RAW_MAXPIX * PRLD;         // [2 slots][16 images][2][8]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wn = wave & 1, wm = (wave >> 1) & 1, ph = wave >> 2;
+    const int W = p.Wout, H = p.Hout, TW = W >> 1, TH = H >> 1;
+    const int Ws = UPS ? (W >> 1) : W, Hs = UPS ? (H >> 1) : H;
+    const int Cin = p.C0 + p.C1, nch = Cin / PKC;
+    const int ntn = p.Cout / WN;
+    const int mb = blockIdx.x / ntn, n0 = (blockIdx.x % ntn) * WN;
+    int img0, ty0, tx0, blk_in_img = 0;
+    if (nimg == 1) {
+        const int bpr = TW / bw, bpi = (TH / bh) * bpr;
+        img0 = mb / bpi;
+        blk_in_img = mb - img0 * bpi;
+        ty0 = (blk_in_img / bpr) * bh;
+        tx0 = (blk_in_img % bpr) * bw;
+    } else {
+        img0 = mb * nimg;
+        ty0 = tx0 = 0;
+    }
+    const int RH = UPS ? bh + 2 : 2 * bh + 2, RW = UPS ? bw + 2 : 2 * bw + 2;
+    const int oy = UPS ? ty0 - 1 : 2 * ty0 - 1, ox = UPS ? tx0 - 1 : 2 * tx0 - 1;
+    const int rpi = RH * RW, npix = nimg * rpi;
+
+    // ---- raw staging: item = (pixel, channel quad of the 8-channel chunk)
+    const int squad = tid & 1;
+    int off[QRAW_NIT], cfo[QRAW_NIT];
+#pragma unroll
+    for (int it = 0; it < QRAW_NIT; it++) {
+        const int pix = it * 256 + (tid >> 1);
+        const int img = min(pix / rpi, nimg - 1), r = pix - img * rpi;
+        const int ry = r / RW, rx = r - ry * RW;
+        const int iy = oy + ry, ix = ox + rx;
+        const bool pad = iy < 0 || iy >= Hs || ix < 0 || ix >= Ws || (img0 + img) >= p.B;
+        off[it] = pix >= npix ? -2 : (pad ? -1 : (((img0 + img) * Hs + iy) * Ws + ix));
+        cfo[it] = img * 16 + squad * 4;
+    }
+    const bool has_coef = p.coefA != nullptr;
+    const int cf_img = tid >> 2, cf_isb = (tid >> 1) & 1;
+    const bool cf_mine = has_coef && tid < nimg * 4;
+    const float *cf_base = has_coef ? ((cf_isb ? p.coefB : p.coefA) + (int64_t)min(img0 + cf_img, p.B - 1) * Cin + squad * 4) : nullptr;
+    float4 xr[QRAW_NIT], cfr = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_raw = [&](int chunk) {
+        const int c = chunk * PKC + squad * 4;
+        const bool first = c < p.C0;
+        const float *sb = first ? p.src0 + c : p.src1 + (c - p.C0);
+        const int ld = first ? p.C0 : p.C1;
+#pragma unroll
+        for (int it = 0; it < QRAW_NIT; it++) xr[it] = *reinterpret_cast<const float4 *>(sb + (int64_t)max(off[it], 0) * ld);
+    };
+    auto load_coef = [&](int chunk) {
+        if (cf_mine) cfr = *reinterpret_cast<const float4 *>(cf_base + chunk * PKC);
+    };
+    auto store_coef = [&](int slot) {
+        if (cf_mine) *reinterpret_cast<float4 *>(Cf + slot * 256 + cf_img * 16 + cf_isb * 8 + squad * 4) = cfr;
+    };
+    auto store_raw = [&](int slot) {
+        float *rb = raw + slot * RAW_MAXPIX * PRLD;
+#pragma unroll
+        for (int it = 0; it < QRAW_NIT; it++) {
+            if (off[it] == -2) continue;
+            float4 x = xr[it];
+            if (has_coef) {
+                const float4 ca = *reinterpret_cast<const float4 *>(Cf + slot * 256 + cfo[it]);
+                const float4 cb = *reinterpret_cast<const float4 *>(Cf + slot * 256 + cfo[it] + 8);
+                x.x = fmaf(x.x, ca.x, cb.x);
+                x.y = fmaf(x.y, ca.y, cb.y);
+                x.z = fmaf(x.z, ca.z, cb.z);
+                x.w = fmaf(x.w, ca.w, cb.w);
+            }
+            if (p.act_silu) {
+                x.x = silu_f(x.x);
+                x.y = silu_f(x.y);
+                x.z = silu_f(x.z);
+                x.w = silu_f(x.w);
+            }
+            if (off[it] < 0) x = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding applies AFTER the activation
+            *reinterpret_cast<float4 *>(rb + (it * 256 + (tid >> 1)) * PRLD + squad * 4) = x;
+        }
+    };
+
+    // ---- input transform: thread = (tile, quad) over lanes x one row r of V (wave-uniform): V[r][.] = (B^T d)[r] B
+    //   row 0: d0 - d2   row 1: d1 + d2   row 2: d2 - d1   row 3: d1 - d3
+    const int trow = wave & 3;
+    const int rA = trow == 0 ? 0 : trow == 2 ? 2 : 1, rB = trow == 0 ? 2 : trow == 1 ? 2 : trow == 2 ? 1 : 3;
+    const float tsg = trow == 1 ? 1.f : -1.f;
+    int roA, roB, coloff[4], vofs;
+    {
+        const int pair = (wave >> 2) * 64 + lane;
+        const int tile = pair >> 1, tquad = pair & 1;
+        const int timg = tile / (bh * bw), r = tile - timg * (bh * bw);
+        const int ty = r / bw, tx = r - ty * bw;
+#pragma unroll
+        for (int k = 0; k < 4; k++) coloff[k] = (UPS ? tx + ((k + 1) >> 1) : 2 * tx + k) * PRLD;
+        const int rrA = UPS ? ty + ((rA + 1) >> 1) : 2 * ty + rA, rrB = UPS ? ty + ((rB + 1) >> 1) : 2 * ty + rB;
+        roA = (timg * rpi + rrA * RW) * PRLD + tquad * 4;
+        roB = (timg * rpi + rrB * RW) * PRLD + tquad * 4;
+        vofs = (trow * 4) * WT * PVLD + tile * PVLD + tquad * 4;
+    }
+    auto transform = [&](int slot) {
+        const float *rb = raw + slot * RAW_MAXPIX * PRLD;
+        float *vb = V + slot * 16 * WT * PVLD + vofs;
+        float4 t[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const float4 a = *reinterpret_cast<const float4 *>(rb + roA + coloff[c]);
+            const float4 b = *reinterpret_cast<const float4 *>(rb + roB + coloff[c]);
+            t[c] = make_float4(fmaf(tsg, b.x, a.x), fmaf(tsg, b.y, a.y), fmaf(tsg, b.z, a.z), fmaf(tsg, b.w, a.w));
+        }
+        *reinterpret_cast<float4 *>(vb + 0 * WT * PVLD) = make_float4(t[0].x - t[2].x, t[0].y - t[2].y, t[0].z - t[2].z, t[0].w - t[2].w);
+        *reinterpret_cast<float4 *>(vb + 1 * WT * PVLD) = make_float4(t[1].x + t[2].x, t[1].y + t[2].y, t[1].z + t[2].z, t[1].w + t[2].w);
+        *reinterpret_cast<float4 *>(vb + 2 * WT * PVLD) = make_float4(t[2].x - t[1].x, t[2].y - t[1].y, t[2].z - t[1].z, t[2].w - t[1].w);
+        *reinterpret_cast<float4 *>(vb + 3 * WT * PVLD) = make_float4(t[1].x - t[3].x, t[1].y - t[3].y, t[1].z - t[3].z, t[1].w - t[3].w);
+    };
+
+    // ---- weight stream of this wave: Wf[nb][ph][chunk][8 positions][lane][4]
+    const float4 *__restrict__ wbase = reinterpret_cast<const float4 *>(p.w_wino) + lane;
+    int64_t woff = (int64_t)(((n0 >> 5) + wn) * 2 + ph) * nch * 8 * 64;
+    constexpr int AHEAD = QRING - 1;
+    float4 bq[QRING];
+    const float *asrc = V + (ph * 8) * WT * PVLD + (wm * 32 + l31) * PVLD + kh * 4;
+
+    floatx16 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
+
+    // ---- prologue: S(0), S(1), X(0), G(2) and the coefficient slots (see k_conv3x3_wino_p)
+    const int last = nch - 1;
+    load_raw(0);
+    load_coef(0);
+#pragma unroll
+    for (int a = 0; a < AHEAD; a++) bq[a] = wbase[woff + a * 64];
+    store_coef(0);
+    load_coef(min(1, last));
+    __syncthreads();
+    store_raw(0);
+    load_raw(min(1, last));
+    store_coef(1);
+    load_coef(min(2, last));
+    __syncthreads();
+    transform(0);
+    store_raw(1);
+    load_raw(min(2, last));
+    store_coef(0);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < nch; chunk++) {
+        const int cur = chunk & 1, nxt = cur ^ 1;
+        const float *ab = asrc + cur * 16 * WT * PVLD;
+        load_coef(min(chunk + 3, last));
+        // first half of the MFMAs, then this wave's side work (its SIMD neighbour is typically in the other part),
+        // then the second half
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            bq[(q + AHEAD) % QRING] = wbase[woff + AHEAD * 64];
+            woff += 64;
+            const float4 af = *reinterpret_cast<const float4 *>(ab + q * WT * PVLD);
+            const float4 b = bq[q % QRING];
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, b.x, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, b.y, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, b.z, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, b.w, acc[q], 0, 0, 0);
+        }
+        store_raw(cur);                         // S(chunk+2): raw[cur] was read by X(chunk), a barrier ago
+        load_raw(min(chunk + 3, last));         // G(chunk+3)
+        transform(nxt);                         // X(chunk+1): raw[nxt] -> V[nxt]
+#pragma unroll
+        for (int q = 4; q < 8; q++) {
+            bq[(q + AHEAD) % QRING] = wbase[woff + AHEAD * 64];
+            woff += 64;
+            const float4 af = *reinterpret_cast<const float4 *>(ab + q * WT * PVLD);
+            const float4 b = bq[q % QRING];
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, b.x, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, b.y, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, b.z, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, b.w, acc[q], 0, 0, 0);
+        }
+        store_coef(nxt);
+        __syncthreads();
+    }
+
+    // ---- epilogue addressing + residual prefetch (8 rows per thread)
+    const int c4 = tid & 15, rg = tid >> 4;   // 32 row groups
+    const int n = n0 + c4 * 4;
+    const int R1 = p.Cout - p.R0;
+    int64_t mrow[8];
+    float4 resq[8];
+#pragma unroll
+    for (int pass = 0; pass < 8; pass++) {
+        const int row = pass * 32 + rg;
+        const int tile = row >> 2, i = (row >> 1) & 1, j = row & 1;
+        const int timg = tile / (bh * bw), r = tile - timg * (bh * bw);
+        const int ty = r / bw, tx = r - ty * bw;
+        const bool ok = img0 + timg < p.B;
+        const int64_t m = ((int64_t)min(img0 + timg, p.B - 1) * H + 2 * (ty0 + ty) + i) * W + 2 * (tx0 + tx) + j;
+        mrow[pass] = ok ? m : -1;
+        if (p.res0)
+            resq[pass] = (n < p.R0) ? *reinterpret_cast<const float4 *>(p.res0 + m * p.R0 + n)
+                                    : *reinterpret_cast<const float4 *>(p.res1 + m * R1 + (n - p.R0));
+    }
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bias = *reinterpret_cast<const float4 *>(p.bias + n);
+
+    // ---- partial output transform in registers: this wave holds M[a][b] for a = 2ph, 2ph+1 (acc[(a - 2ph)*4 + b])
+    //   s0[a] = M[a][0] + M[a][1] + M[a][2],  s1[a] = M[a][1] - M[a][2] - M[a][3]
+    //   ph 0: P[0][j] = sj[0] + sj[1], P[1][j] = sj[1]        ph 1: P[0][j] = sj[2], P[1][j] = -sj[2] - sj[3]
+    floatx16 P[4];   // index i*2 + j
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const float s0a = acc[0][r] + acc[1][r] + acc[2][r], s1a = acc[1][r] - acc[2][r] - acc[3][r];
+        const float s0b = acc[4][r] + acc[5][r] + acc[6][r], s1b = acc[5][r] - acc[6][r] - acc[7][r];
+        if (ph == 0) {
+            P[0][r] = s0a + s0b; P[1][r] = s1a + s1b; P[2][r] = s0b; P[3][r] = s1b;
+        } else {
+            P[0][r] = s0a; P[1][r] = s1a; P[2][r] = -s0a - s0b; P[3][r] = -s1a - s1b;
+        }
+    }
+    // exchange: ph = 1 waves -> LDS [wm][wn][ij][r][lane]; ph = 0 waves add (Y = P0 + P1, fixed order)
+    float *xch = wsm;                                   // 4 waves x 4 x 16 x 64 floats = 64 KB
+    constexpr int ELD = WN + 4;
+    float *img = wsm + 4 * 4 * 16 * 64;                 // row image [256][ELD] behind it (69.6 KB)
+    if (ph == 1) {
+        float *dst = xch + ((wm * 2 + wn) * 64) * 64 + lane;
+#pragma unroll
+        for (int ij = 0; ij < 4; ij++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) dst[(ij * 16 + r) * 64] = P[ij][r];
+    }
+    __syncthreads();
+    if (ph == 0) {
+        const float *src = xch + ((wm * 2 + wn) * 64) * 64 + lane;
+#pragma unroll
+        for (int ij = 0; ij < 4; ij++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int tile = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                img[(tile * 4 + ij) * ELD + wn * 32 + l31] = P[ij][r] + src[(ij * 16 + r) * 64];
+            }
+    }
+    __syncthreads();
+    const bool do_stats = p.stats_out != nullptr && nimg == 1;
+    float4 K = make_float4(0.f, 0.f, 0.f, 0.f), s1 = K, s2 = K;
+    int cnt = 0;
+#pragma unroll
+    for (int pass = 0; pass < 8; pass++) {
+        const int row = pass * 32 + rg;
+        const int64_t m = mrow[pass];
+        if (m < 0) continue;
+        float4 v = *reinterpret_cast<const float4 *>(img + row * ELD + c4 * 4);
+        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+        if (p.res0) {
+            const float4 q = resq[pass];
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        if (do_stats) {
+            if (cnt == 0) K = v;
+            float d;
+            d = v.x - K.x; s1.x += d; s2.x = fmaf(d, d, s2.x);
+            d = v.y - K.y; s1.y += d; s2.y = fmaf(d, d, s2.y);
+            d = v.z - K.z; s1.z += d; s2.z = fmaf(d, d, s2.z);
+            d = v.w - K.w; s1.w += d; s2.w = fmaf(d, d, s2.w);
+            cnt++;
+        }
+        *reinterpret_cast<float4 *>(p.out + m * p.Cout + n) = v;
+    }
+    if (do_stats) {
+        __syncthreads();
+        float2 *part = reinterpret_cast<float2 *>(wsm);
+        const float fc = (float)(cnt > 0 ? cnt : 1);
+        const float mx = s1.x / fc, my = s1.y / fc, mz = s1.z / fc, mw = s1.w / fc;
+        part[rg * WN + c4 * 4 + 0] = make_float2(K.x + mx, fmaxf(s2.x - s1.x * mx, 0.f));
+        part[rg * WN + c4 * 4 + 1] = make_float2(K.y + my, fmaxf(s2.y - s1.y * my, 0.f));
+        part[rg * WN + c4 * 4 + 2] = make_float2(K.z + mz, fmaxf(s2.z - s1.z * mz, 0.f));
+        part[rg * WN + c4 * 4 + 3] = make_float2(K.w + mw, fmaxf(s2.w - s1.w * mw, 0.f));
+        __syncthreads();
+        if (tid < WN) {
+            const float npart = 8.0f;   // rows behind each partial
+            float mean = part[tid].x, M2 = part[tid].y, na = npart;
+            for (int g = 1; g < 32; g++) {
+                const float2 q = part[g * WN + tid];
+                const float d = q.x - mean, N = na + npart;
+                mean += d * (npart / N);
+                M2 += q.y + d * d * (na * npart / N);
+                na = N;
+            }
+            const int nt = (H * W) / 256;
+            p.stats_out[((int64_t)img0 * nt + blk_in_img) * p.Cout + n0 + tid] = make_float2(mean, M2);
+        }
+    }
+}
+
+// OIHW (3x3) -> U = G g G^T in k_conv3x3_wino_q's fragment order  Wf[nb][ph][chunk8][pos8][lane][4]:
+// lane = h*32 + n holds U_pos[cin = chunk*8 + h*4 + e][cout = nb*32 + n], pos = ph*8 + pos8.
+__global__ void k_relayout_weight_wino_q(const float *oihw, float *dst, int Cout, int Cin) {
+    const int nbk = Cout / 32, nch = Cin / PKC;
+    const int64_t total = (int64_t)nbk * 2 * nch * 8 * 64 * 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int e = (int)(i & 3);
+    const int lane = (int)((i >> 2) & 63);
+    int64_t r = i >> 8;
+    const int pos8 = (int)(r & 7); r >>= 3;
+    const int chunk = (int)(r % nch); r /= nch;
+    const int ph = (int)(r & 1);
+    const int nb = (int)(r >> 1);
+    const int pos = ph * 8 + pos8;
+    const int h = lane >> 5, nn = lane & 31;
+    const int cin = chunk * PKC + h * 4 + e, cout = nb * 32 + nn;
+    const float *g = oihw + ((int64_t)cout * Cin + cin) * 9;
+    const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+    const int a = pos >> 2, b = pos & 3;
+    float u = 0.f;
+    for (int ii = 0; ii < 3; ii++) {
+        float row = 0.f;
+        for (int jj = 0; jj < 3; jj++) row += g[ii * 3 + jj] * G[b][jj];
+        u += G[a][ii] * row;
+    }
+    dst[i] = u;
+}
+
 // OIHW (3x3) -> U = G g G^T in the pipelined kernel's fragment order  Wf[nb][chunk8][pos][lane][4]:
 // lane = h*32 + n holds U_pos[cin = chunk*8 + h*4 + e][cout = nb*32 + n].
 __global__ void k_relayout_weight_wino_p(const float *oihw, float *dst, int Cout, int Cin) {
@@ -747,11 +1120,12 @@ __global__ void k_relayout_weight_wino(const float *oihw, float *dst, int Cout, 
 
 }  // namespace
 
-static bool wino_pipelined() {   // DLPM_WINO_P=0 selects the phase-separated kernel (and its weight layout)
+static int wino_variant() {   // DLPM_WINO_P: 0 phase-separated 4-wave kernel, 1 pipelined 4-wave kernel, 2 (default) 8-wave kernel
     static int v = -1;
-    if (v < 0) { const char *e = getenv("DLPM_WINO_P"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v == 1;
+    if (v < 0) { const char *e = getenv("DLPM_WINO_P"); v = e ? atoi(e) : 2; }
+    return v;
 }
+static bool wino_pipelined() { return wino_variant() == 1; }
 
 static bool wino_disabled() {
     static int v = -1;
@@ -808,7 +1182,21 @@ int launch_conv_wino(const ConvLaunch &c, hipStream_t st) {
         else fn = c.ups ? &k_conv3x3_wino_p<true, false> : &k_conv3x3_wino_p<false, false>;
     }
 #ifdef DLPM_WINO_ABLATIONS
-    if (!c.ups) {
+    if (piped && act && !c.ups) {
+        switch (abl) {
+            case 1: fn = &k_conv3x3_wino_p<false, true, 1>; break;
+            case 2: fn = &k_conv3x3_wino_p<false, true, 2>; break;
+            case 3: fn = &k_conv3x3_wino_p<false, true, 3>; break;
+            case 4: fn = &k_conv3x3_wino_p<false, true, 4>; break;
+            case 7: fn = &k_conv3x3_wino_p<false, true, 7>; break;
+            case 8: fn = &k_conv3x3_wino_p<false, true, 8>; break;
+            case 15: fn = &k_conv3x3_wino_p<false, true, 15>; break;
+            case 16: fn = &k_conv3x3_wino_p<false, true, 16>; break;
+            case 31: fn = &k_conv3x3_wino_p<false, true, 31>; break;
+            case 32: fn = &k_conv3x3_wino_p<false, true, 32>; break;
+            default: break;
+        }
+    } else if (!c.ups) {
         switch (abl) {
             case 1: fn = &k_conv3x3_wino<false, 1>; break;
             case 2: fn = &k_conv3x3_wino<false, 2>; break;
@@ -822,13 +1210,27 @@ int launch_conv_wino(const ConvLaunch &c, hipStream_t st) {
         }
     }
 #endif
-    static const void *configured[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // (not during graph capture: the first
+    static const void *configured[24] = {nullptr};   // (not during graph capture: the first
     bool seen = false;                                                          //  launch of each kernel is eager)
     for (const void *q : configured) seen = seen || q == reinterpret_cast<const void *>(fn);
     if (!seen) {
         DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         for (auto &q : configured)
             if (!q) { q = reinterpret_cast<const void *>(fn); break; }
+    }
+    if (wino_variant() == 2) {
+        fn = c.ups ? &k_conv3x3_wino_q<true> : &k_conv3x3_wino_q<false>;
+        bool seen2 = false;
+        for (const void *q : configured) seen2 = seen2 || q == reinterpret_cast<const void *>(fn);
+        if (!seen2) {
+            DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            for (auto &q : configured)
+                if (!q) { q = reinterpret_cast<const void *>(fn); break; }
+        }
+        const size_t shmem_q = (size_t)(2 * 16 * WT * PVLD + 2 * RAW_MAXPIX * PRLD + 512) * sizeof(float);
+        fn<<<(unsigned)grid, 512, shmem_q, st>>>(c, bh, bw, nimg);
+        DLPM_LAUNCH_CHECK();
+        return DLPM_OK;
     }
     fn<<<(unsigned)grid, 256, piped ? shmem_p : shmem, st>>>(c, bh, bw, nimg);
     DLPM_LAUNCH_CHECK();
@@ -843,7 +1245,8 @@ int64_t wino_weight_floats(int Cout, int Cin) {
 int relayout_weight_wino(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st) {
     const int64_t n = (int64_t)(Cout / 32) * (Cin / WKC) * WGRP * 256;
     DLPM_HIP(hipMemsetAsync(dst_dev + n, 0, (size_t)(WRING - 1) * 256 * sizeof(float), st));
-    if (wino_pipelined()) k_relayout_weight_wino_p<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
+    if (wino_variant() == 2) k_relayout_weight_wino_q<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
+    else if (wino_pipelined()) k_relayout_weight_wino_p<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
     else k_relayout_weight_wino<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
