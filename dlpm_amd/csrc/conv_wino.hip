@@ -735,7 +735,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_wino_p(ConvLaunch p, int bh,
 constexpr int QRAW_NIT = (RAW_MAXPIX * 2 + 511) / 512;   // 3 float4 per thread (512 threads)
 constexpr int QRING = 4;
 
-template <bool UPS>
+template <bool UPS, int ABL = 0>   // ABL (DLPM_WINO_ABLATIONS builds): 1 no S, 2 no X, 4 no raw loads, 8 no barrier, 16 no weight loads, 32 no MFMA
 __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh, int bw, int nimg) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float *V = wsm;                                  // [2][16][WT][PVLD]
@@ -893,36 +893,33 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
         const int cur = chunk & 1, nxt = cur ^ 1;
         const float *ab = asrc + cur * 16 * WT * PVLD;
         load_coef(min(chunk + 3, last));
-        // first half of the MFMAs, then this wave's side work (its SIMD neighbour is typically in the other part),
-        // then the second half
+        // Half of the MFMAs, the side work, the other half.  (Measured, tools/mb/mfma_valu_2waves.hip: on gfx950 VALU
+        // instructions do not overlap MFMAs of the SAME SIMD even from another wave -- 3460 cycles for 2048 cycles of MFMA
+        // in one wave next to 1233 cycles of v_fma in the other -- so the side work's VALU time is simply added; what the
+        // second wave does hide is latency: LDS, global loads, barriers.  Running the two waves of a SIMD in opposite
+        // order measured 4 % slower.)
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            bq[(q + AHEAD) % QRING] = wbase[woff + AHEAD * 64];
+        for (int q = 0; q < 8; q++) {
+            if (q == 4) {
+                if (!(ABL & 1)) store_raw(cur);                         // S(chunk+2): raw[cur] was read by X(chunk), a barrier ago
+                if (!(ABL & 4)) load_raw(min(chunk + 3, last));         // G(chunk+3)
+                if (!(ABL & 2)) transform(nxt);                         // X(chunk+1): raw[nxt] -> V[nxt]
+            }
+            if (!(ABL & 16)) bq[(q + AHEAD) % QRING] = wbase[woff + AHEAD * 64];
             woff += 64;
             const float4 af = *reinterpret_cast<const float4 *>(ab + q * WT * PVLD);
             const float4 b = bq[q % QRING];
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, b.x, acc[q], 0, 0, 0);
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, b.y, acc[q], 0, 0, 0);
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, b.z, acc[q], 0, 0, 0);
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, b.w, acc[q], 0, 0, 0);
-        }
-        store_raw(cur);                         // S(chunk+2): raw[cur] was read by X(chunk), a barrier ago
-        load_raw(min(chunk + 3, last));         // G(chunk+3)
-        transform(nxt);                         // X(chunk+1): raw[nxt] -> V[nxt]
-#pragma unroll
-        for (int q = 4; q < 8; q++) {
-            bq[(q + AHEAD) % QRING] = wbase[woff + AHEAD * 64];
-            woff += 64;
-            const float4 af = *reinterpret_cast<const float4 *>(ab + q * WT * PVLD);
-            const float4 b = bq[q % QRING];
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, b.x, acc[q], 0, 0, 0);
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, b.y, acc[q], 0, 0, 0);
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, b.z, acc[q], 0, 0, 0);
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, b.w, acc[q], 0, 0, 0);
+            if (!(ABL & 32)) {
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, b.x, acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, b.y, acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, b.z, acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, b.w, acc[q], 0, 0, 0);
+            }
         }
         store_coef(nxt);
-        __syncthreads();
+        if (!(ABL & 8)) __syncthreads();
     }
+    if (ABL & 8) __syncthreads();
 
     // ---- epilogue addressing + residual prefetch (8 rows per thread)
     const int c4 = tid & 15, rg = tid >> 4;   // 32 row groups
@@ -1220,6 +1217,21 @@ int launch_conv_wino(const ConvLaunch &c, hipStream_t st) {
     }
     if (wino_variant() == 2) {
         fn = c.ups ? &k_conv3x3_wino_q<true> : &k_conv3x3_wino_q<false>;
+#ifdef DLPM_WINO_ABLATIONS
+        if (!c.ups) {
+            switch (abl) {
+                case 1: fn = &k_conv3x3_wino_q<false, 1>; break;
+                case 2: fn = &k_conv3x3_wino_q<false, 2>; break;
+                case 3: fn = &k_conv3x3_wino_q<false, 3>; break;
+                case 4: fn = &k_conv3x3_wino_q<false, 4>; break;
+                case 8: fn = &k_conv3x3_wino_q<false, 8>; break;
+                case 16: fn = &k_conv3x3_wino_q<false, 16>; break;
+                case 31: fn = &k_conv3x3_wino_q<false, 31>; break;
+                case 32: fn = &k_conv3x3_wino_q<false, 32>; break;
+                default: break;
+            }
+        }
+#endif
         bool seen2 = false;
         for (const void *q : configured) seen2 = seen2 || q == reinterpret_cast<const void *>(fn);
         if (!seen2) {
