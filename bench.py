@@ -40,7 +40,9 @@ METRIC = {
 }
 # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc runs,
 # FETCH_SIZE doubled per the gfx950 guide): profiles/r01/pmc_hbm_traffic_*.txt
-PMC_TRAFFIC_BYTES_PER_LAUNCH = {'k_conv3x3_halo_ws<128,2,2,2,2,2>': (0.6663 + 0.2194) * 1e9}  # fetch + write, mean over all three instantiations
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {'k_conv3x3_halo_ws<128,2,2,2,2,2>': (0.6663 + 0.2194) * 1e9,  # fetch + write, mean over all three instantiations
+                                'k_conv3x3_wino_q': (0.9743 + 0.2221) * 1e9}   # fetch + write, mean over both instantiations (47 launches/step)
+PMC_TRAFFIC_FILE = 'profiles/r01/pmc_hbm_traffic_v10.txt'
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 PEAK_HBM_GBS = 8000.0
 
@@ -184,19 +186,37 @@ def main():
         _lib.check(L.dlpm_prof_enable(0))
         prof = parse_prof(buf.value.decode())
         breakdown = {k: round(v['ms'] / nprof, 4) for k, v in prof.items()}
-        c = prof.get('conv3x3_halo') or prof.get('conv3x3_igemm')
+        wino = prof.get('conv3x3_wino')
+        c = wino or prof.get('conv3x3_halo') or prof.get('conv3x3_igemm')
         if c:
             ach = c['flops'] / (c['ms'] * 1e-3) / 1e12
-            roofline = dict(kernel='k_conv3x3_halo_ws<128,2,2,2,2,2> (3x3 stride-1 conv, fp32 MFMA 32x32x2, LDS halo tile + register-streamed weights, fused GN+SiLU/bias/residual/GN-stats)',
+            if wino:
+                kname = 'k_conv3x3_wino_q'
+                kdesc = ('k_conv3x3_wino_q (3x3 stride-1 conv as Winograd F(2x2,3x3) on the fp32 MFMA 32x32x2: 16 instead of 36 '
+                         'multiplies per 2x2 output tile and channel pair; fused GN+SiLU staging, in-register output transform, '
+                         'bias/residual/GN-stats epilogue)')
+            else:
+                kname = 'k_conv3x3_halo_ws<128,2,2,2,2,2>'
+                kdesc = ('k_conv3x3_halo_ws<128,2,2,2,2,2> (3x3 stride-1 conv, fp32 MFMA 32x32x2, LDS halo tile + register-streamed '
+                         'weights, fused GN+SiLU/bias/residual/GN-stats)')
+            roofline = dict(kernel=kdesc,
                             bound='mfma', achieved=round(ach, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
                             frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                            traffic=(PMC_TRAFFIC_BYTES_PER_LAUNCH['k_conv3x3_halo_ws<128,2,2,2,2,2>'] if cfg_name == 'cifar10' and B == 1024 else None),
-                            traffic_note='HBM bytes per launch (mean over the 48 launches of a step) from committed rocprofv3 PMC passes, profiles/r01/pmc_hbm_traffic_v9.txt; algorithmic bytes per launch = %.4g' % (c['bytes'] / c['launches']),
+                            traffic=(PMC_TRAFFIC_BYTES_PER_LAUNCH.get(kname) if cfg_name == 'cifar10' and B == 1024 else None),
+                            traffic_note='HBM bytes per launch (mean over the launches of a step) from committed rocprofv3 PMC passes, %s; algorithmic bytes per launch = %.4g' % (PMC_TRAFFIC_FILE, c['bytes'] / c['launches']),
                             launches_per_step=c['launches'] // nprof, avg_launch_ms=round(c['ms'] / c['launches'], 5),
                             flops_per_launch_avg=c['flops'] / c['launches'],
                             share_of_step_ms=round(c['ms'] / nprof, 3),
                             all_mfma_conv_classes_tflops=round(sum(v['flops'] for k, v in prof.items() if k.startswith('conv') and 'stem' not in k and 'direct' not in k)
                                                                / (sum(v['ms'] for k, v in prof.items() if k.startswith('conv') and 'stem' not in k and 'direct' not in k) * 1e-3) / 1e12, 3))
+            if wino:
+                # `achieved` counts ALGORITHMIC flops (2*9*Cin*Cout per output pixel, the direct-convolution count of
+                # SURVEY 8d); the Winograd kernel executes 16/36 of them on the matrix pipe, so `frac` can exceed 1:
+                # the MFMA pipe's own utilisation is reported next to it
+                roofline['mfma_executed_tflops'] = round(ach * 16.0 / 36.0, 3)
+                roofline['mfma_utilisation'] = round(ach * 16.0 / 36.0 / PEAK_FP32_MFMA_TFLOPS, 4)
+                roofline['note'] = ('achieved = algorithmic (direct-convolution) FLOP/s; F(2x2,3x3) executes 16/36 of them, '
+                                    'mfma_utilisation = executed MFMA FLOP/s over the fp32 MFMA peak')
         u = prof.get('update')
         if u:
             gbs = u['bytes'] / (u['ms'] * 1e-3) / 1e9
