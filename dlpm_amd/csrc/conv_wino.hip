@@ -869,23 +869,38 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
 
-    // ---- prologue: S(0), S(1), X(0), G(2) and the coefficient slots (see k_conv3x3_wino_p)
+    // ---- prologue: S(0), S(1), X(0), G(2) and the coefficient slots.  One workgroup per CU: nothing hides these
+    // latencies, so everything the first two chunks need is requested at once (one exposed round trip instead of three).
     const int last = nch - 1;
+    float4 xr1[QRAW_NIT], cfr1 = make_float4(0.f, 0.f, 0.f, 0.f), cfr2 = cfr1;
     load_raw(0);
+    {
+        const int c = min(1, last) * PKC + squad * 4;
+        const bool first = c < p.C0;
+        const float *sb = first ? p.src0 + c : p.src1 + (c - p.C0);
+        const int ld = first ? p.C0 : p.C1;
+#pragma unroll
+        for (int it = 0; it < QRAW_NIT; it++) xr1[it] = *reinterpret_cast<const float4 *>(sb + (int64_t)max(off[it], 0) * ld);
+    }
     load_coef(0);
+    if (cf_mine) {
+        cfr1 = *reinterpret_cast<const float4 *>(cf_base + min(1, last) * PKC);
+        cfr2 = *reinterpret_cast<const float4 *>(cf_base + min(2, last) * PKC);
+    }
 #pragma unroll
     for (int a = 0; a < AHEAD; a++) bq[a] = wbase[woff + a * 64];
     store_coef(0);
-    load_coef(min(1, last));
+    cfr = cfr1;
+    store_coef(1);
     __syncthreads();
     store_raw(0);
-    load_raw(min(1, last));
-    store_coef(1);
-    load_coef(min(2, last));
-    __syncthreads();
-    transform(0);
+#pragma unroll
+    for (int it = 0; it < QRAW_NIT; it++) xr[it] = xr1[it];
     store_raw(1);
     load_raw(min(2, last));
+    __syncthreads();
+    transform(0);
+    cfr = cfr2;
     store_coef(0);
     __syncthreads();
 
