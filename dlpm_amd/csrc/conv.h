@@ -38,6 +38,7 @@ int launch_conv_direct(const ConvLaunch &c, hipStream_t st);
 int launch_conv_stem(const ConvLaunch &c, hipStream_t st);
 // Winograd F(2x2,3x3) path (conv_wino.hip)
 bool wino_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg);
+int wino_tiles(const ConvLaunch &c);   // 2x2 output tiles per workgroup (64 or 32)
 int launch_conv_wino(const ConvLaunch &c, hipStream_t st);
 int64_t wino_weight_floats(int Cout, int Cin);
 int relayout_weight_wino(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st);

@@ -876,7 +876,7 @@ int launch_conv_stem(const ConvLaunch &c, hipStream_t st) {
 
 int conv_stats_pixels(const ConvLaunch &c) {
     int a, b, n;
-    if (wino_geometry(c, &a, &b, &n)) return n == 1 ? 256 : 0;
+    if (wino_geometry(c, &a, &b, &n)) return n == 1 ? 4 * wino_tiles(c) : 0;
     if (c.out_nchw || (c.Cout & 3) || (c.R0 & 3)) return 0;
     return ((int64_t)c.Hout * c.Wout) % BM == 0 ? BM : 0;
 }

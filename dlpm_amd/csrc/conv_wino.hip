@@ -735,21 +735,29 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_wino_p(ConvLaunch p, int bh,
 constexpr int QRAW_NIT = (RAW_MAXPIX * 2 + 511) / 512;   // 3 float4 per thread (512 threads)
 constexpr int QRING = 4;
 
-template <bool UPS, int ABL = 0>   // ABL (DLPM_WINO_ABLATIONS builds): 1 no S, 2 no X, 4 no raw loads, 8 no barrier, 16 no weight loads, 32 no MFMA
+// MT = tiles per workgroup: 64 (x 64 output channels) or 32 (x 128 channels).  The accumulator block is 256 KB either
+// way; the 32-tile shape stages a smaller halo patch per MFMA (180-288 instead of 324-576 pixels, for twice the
+// channels) and transforms half as many tiles, i.e. ~40 % less VALU work per MFMA -- which matters because VALU time
+// is added to MFMA time on this chip -- at the price of streaming every weight fragment for one MFMA tile only.
+template <bool UPS, int MT, int ABL = 0>   // ABL (DLPM_WINO_ABLATIONS builds): 1 no S, 2 no X, 4 no raw loads, 8 no barrier, 16 no weight loads, 32 no MFMA
 __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh, int bw, int nimg) {
+    constexpr int NQ = 4096 / MT;                    // output channels per workgroup
+    constexpr int RAWPIX = MT == 64 ? RAW_MAXPIX : RAW_MAXPIX / 2;
+    constexpr int QNIT = (RAWPIX * 2 + 511) / 512;   // staging items per thread
     extern __shared__ __attribute__((aligned(16))) float wsm[];
-    float *V = wsm;                                  // [2][16][WT][PVLD]
-    float *raw = wsm + 2 * 16 * WT * PVLD;           // [2][RAW_MAXPIX][PRLD]
-    float *Cf = raw + 2 * RAW_MAXPIX * PRLD;         // [2 slots][16 images][2][8]
+    float *V = wsm;                                  // [2][16][MT][PVLD]
+    float *raw = wsm + 2 * 16 * MT * PVLD;           // [2][RAWPIX][PRLD]
+    float *Cf = raw + 2 * RAWPIX * PRLD;             // [2 slots][16 images][2][8]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int wn = wave & 1, wm = (wave >> 1) & 1, ph = wave >> 2;
+    const int ph = wave >> 2;
+    const int wn = MT == 64 ? (wave & 1) : (wave & 3), wm = MT == 64 ? ((wave >> 1) & 1) : 0;
     const int W = p.Wout, H = p.Hout, TW = W >> 1, TH = H >> 1;
     const int Ws = UPS ? (W >> 1) : W, Hs = UPS ? (H >> 1) : H;
     const int Cin = p.C0 + p.C1, nch = Cin / PKC;
-    const int ntn = p.Cout / WN;
-    const int mb = blockIdx.x / ntn, n0 = (blockIdx.x % ntn) * WN;
+    const int ntn = p.Cout / NQ;
+    const int mb = blockIdx.x / ntn, n0 = (blockIdx.x % ntn) * NQ;
     int img0, ty0, tx0, blk_in_img = 0;
     if (nimg == 1) {
         const int bpr = TW / bw, bpi = (TH / bh) * bpr;
@@ -767,9 +775,9 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
 
     // ---- raw staging: item = (pixel, channel quad of the 8-channel chunk)
     const int squad = tid & 1;
-    int off[QRAW_NIT], cfo[QRAW_NIT];
+    int off[QNIT], cfo[QNIT];
 #pragma unroll
-    for (int it = 0; it < QRAW_NIT; it++) {
+    for (int it = 0; it < QNIT; it++) {
         const int pix = it * 256 + (tid >> 1);
         const int img = min(pix / rpi, nimg - 1), r = pix - img * rpi;
         const int ry = r / RW, rx = r - ry * RW;
@@ -782,14 +790,14 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
     const int cf_img = tid >> 2, cf_isb = (tid >> 1) & 1;
     const bool cf_mine = has_coef && tid < nimg * 4;
     const float *cf_base = has_coef ? ((cf_isb ? p.coefB : p.coefA) + (int64_t)min(img0 + cf_img, p.B - 1) * Cin + squad * 4) : nullptr;
-    float4 xr[QRAW_NIT], cfr = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 xr[QNIT], cfr = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_raw = [&](int chunk) {
         const int c = chunk * PKC + squad * 4;
         const bool first = c < p.C0;
         const float *sb = first ? p.src0 + c : p.src1 + (c - p.C0);
         const int ld = first ? p.C0 : p.C1;
 #pragma unroll
-        for (int it = 0; it < QRAW_NIT; it++) xr[it] = *reinterpret_cast<const float4 *>(sb + (int64_t)max(off[it], 0) * ld);
+        for (int it = 0; it < QNIT; it++) xr[it] = *reinterpret_cast<const float4 *>(sb + (int64_t)max(off[it], 0) * ld);
     };
     auto load_coef = [&](int chunk) {
         if (cf_mine) cfr = *reinterpret_cast<const float4 *>(cf_base + chunk * PKC);
@@ -798,9 +806,9 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
         if (cf_mine) *reinterpret_cast<float4 *>(Cf + slot * 256 + cf_img * 16 + cf_isb * 8 + squad * 4) = cfr;
     };
     auto store_raw = [&](int slot) {
-        float *rb = raw + slot * RAW_MAXPIX * PRLD;
+        float *rb = raw + slot * RAWPIX * PRLD;
 #pragma unroll
-        for (int it = 0; it < QRAW_NIT; it++) {
+        for (int it = 0; it < QNIT; it++) {
             if (off[it] == -2) continue;
             float4 x = xr[it];
             if (has_coef) {
@@ -825,11 +833,12 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
     // ---- input transform: thread = (tile, quad) over lanes x one row r of V (wave-uniform): V[r][.] = (B^T d)[r] B
     //   row 0: d0 - d2   row 1: d1 + d2   row 2: d2 - d1   row 3: d1 - d3
     const int trow = wave & 3;
+    const bool xform_mine = MT == 64 || wave < 4;     // 32 tiles x 2 quads x 4 rows = 256 items: the ph = 0 waves
     const int rA = trow == 0 ? 0 : trow == 2 ? 2 : 1, rB = trow == 0 ? 2 : trow == 1 ? 2 : trow == 2 ? 1 : 3;
     const float tsg = trow == 1 ? 1.f : -1.f;
     int roA, roB, coloff[4], vofs;
     {
-        const int pair = (wave >> 2) * 64 + lane;
+        const int pair = MT == 64 ? (wave >> 2) * 64 + lane : lane;
         const int tile = pair >> 1, tquad = pair & 1;
         const int timg = tile / (bh * bw), r = tile - timg * (bh * bw);
         const int ty = r / bw, tx = r - ty * bw;
@@ -838,11 +847,12 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
         const int rrA = UPS ? ty + ((rA + 1) >> 1) : 2 * ty + rA, rrB = UPS ? ty + ((rB + 1) >> 1) : 2 * ty + rB;
         roA = (timg * rpi + rrA * RW) * PRLD + tquad * 4;
         roB = (timg * rpi + rrB * RW) * PRLD + tquad * 4;
-        vofs = (trow * 4) * WT * PVLD + tile * PVLD + tquad * 4;
+        vofs = (trow * 4) * MT * PVLD + tile * PVLD + tquad * 4;
     }
     auto transform = [&](int slot) {
-        const float *rb = raw + slot * RAW_MAXPIX * PRLD;
-        float *vb = V + slot * 16 * WT * PVLD + vofs;
+        if (!xform_mine) return;
+        const float *rb = raw + slot * RAWPIX * PRLD;
+        float *vb = V + slot * 16 * MT * PVLD + vofs;
         float4 t[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
@@ -850,10 +860,10 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
             const float4 b = *reinterpret_cast<const float4 *>(rb + roB + coloff[c]);
             t[c] = make_float4(fmaf(tsg, b.x, a.x), fmaf(tsg, b.y, a.y), fmaf(tsg, b.z, a.z), fmaf(tsg, b.w, a.w));
         }
-        *reinterpret_cast<float4 *>(vb + 0 * WT * PVLD) = make_float4(t[0].x - t[2].x, t[0].y - t[2].y, t[0].z - t[2].z, t[0].w - t[2].w);
-        *reinterpret_cast<float4 *>(vb + 1 * WT * PVLD) = make_float4(t[1].x + t[2].x, t[1].y + t[2].y, t[1].z + t[2].z, t[1].w + t[2].w);
-        *reinterpret_cast<float4 *>(vb + 2 * WT * PVLD) = make_float4(t[2].x - t[1].x, t[2].y - t[1].y, t[2].z - t[1].z, t[2].w - t[1].w);
-        *reinterpret_cast<float4 *>(vb + 3 * WT * PVLD) = make_float4(t[1].x - t[3].x, t[1].y - t[3].y, t[1].z - t[3].z, t[1].w - t[3].w);
+        *reinterpret_cast<float4 *>(vb + 0 * MT * PVLD) = make_float4(t[0].x - t[2].x, t[0].y - t[2].y, t[0].z - t[2].z, t[0].w - t[2].w);
+        *reinterpret_cast<float4 *>(vb + 1 * MT * PVLD) = make_float4(t[1].x + t[2].x, t[1].y + t[2].y, t[1].z + t[2].z, t[1].w + t[2].w);
+        *reinterpret_cast<float4 *>(vb + 2 * MT * PVLD) = make_float4(t[2].x - t[1].x, t[2].y - t[1].y, t[2].z - t[1].z, t[2].w - t[1].w);
+        *reinterpret_cast<float4 *>(vb + 3 * MT * PVLD) = make_float4(t[1].x - t[3].x, t[1].y - t[3].y, t[1].z - t[3].z, t[1].w - t[3].w);
     };
 
     // ---- weight stream of this wave: Wf[nb][ph][chunk][8 positions][lane][4]
@@ -861,7 +871,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
     int64_t woff = (int64_t)(((n0 >> 5) + wn) * 2 + ph) * nch * 8 * 64;
     constexpr int AHEAD = QRING - 1;
     float4 bq[QRING];
-    const float *asrc = V + (ph * 8) * WT * PVLD + (wm * 32 + l31) * PVLD + kh * 4;
+    const float *asrc = V + (ph * 8) * MT * PVLD + (wm * 32 + l31) * PVLD + kh * 4;
 
     floatx16 acc[8];
 #pragma unroll
@@ -872,7 +882,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
     // ---- prologue: S(0), S(1), X(0), G(2) and the coefficient slots.  One workgroup per CU: nothing hides these
     // latencies, so everything the first two chunks need is requested at once (one exposed round trip instead of three).
     const int last = nch - 1;
-    float4 xr1[QRAW_NIT], cfr1 = make_float4(0.f, 0.f, 0.f, 0.f), cfr2 = cfr1;
+    float4 xr1[QNIT], cfr1 = make_float4(0.f, 0.f, 0.f, 0.f), cfr2 = cfr1;
     load_raw(0);
     {
         const int c = min(1, last) * PKC + squad * 4;
@@ -880,7 +890,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
         const float *sb = first ? p.src0 + c : p.src1 + (c - p.C0);
         const int ld = first ? p.C0 : p.C1;
 #pragma unroll
-        for (int it = 0; it < QRAW_NIT; it++) xr1[it] = *reinterpret_cast<const float4 *>(sb + (int64_t)max(off[it], 0) * ld);
+        for (int it = 0; it < QNIT; it++) xr1[it] = *reinterpret_cast<const float4 *>(sb + (int64_t)max(off[it], 0) * ld);
     }
     load_coef(0);
     if (cf_mine) {
@@ -895,7 +905,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
     __syncthreads();
     store_raw(0);
 #pragma unroll
-    for (int it = 0; it < QRAW_NIT; it++) xr[it] = xr1[it];
+    for (int it = 0; it < QNIT; it++) xr[it] = xr1[it];
     store_raw(1);
     load_raw(min(2, last));
     __syncthreads();
@@ -906,7 +916,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
 
     for (int chunk = 0; chunk < nch; chunk++) {
         const int cur = chunk & 1, nxt = cur ^ 1;
-        const float *ab = asrc + cur * 16 * WT * PVLD;
+        const float *ab = asrc + cur * 16 * MT * PVLD;
         load_coef(min(chunk + 3, last));
         // Half of the MFMAs, the side work, the other half.  (Measured, tools/mb/mfma_valu_2waves.hip: on gfx950 VALU
         // instructions do not overlap MFMAs of the SAME SIMD even from another wave -- 3460 cycles for 2048 cycles of MFMA
@@ -922,7 +932,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
             }
             if (!(ABL & 16)) bq[(q + AHEAD) % QRING] = wbase[woff + AHEAD * 64];
             woff += 64;
-            const float4 af = *reinterpret_cast<const float4 *>(ab + q * WT * PVLD);
+            const float4 af = *reinterpret_cast<const float4 *>(ab + q * MT * PVLD);
             const float4 b = bq[q % QRING];
             if (!(ABL & 32)) {
                 acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, b.x, acc[q], 0, 0, 0);
@@ -937,14 +947,15 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
     if (ABL & 8) __syncthreads();
 
     // ---- epilogue addressing + residual prefetch (8 rows per thread)
-    const int c4 = tid & 15, rg = tid >> 4;   // 32 row groups
+    constexpr int C4N = NQ / 4, NRG = 512 / C4N;   // float4 columns per row, row groups (32 or 16)
+    const int c4 = tid % C4N, rg = tid / C4N;
     const int n = n0 + c4 * 4;
     const int R1 = p.Cout - p.R0;
     int64_t mrow[8];
     float4 resq[8];
 #pragma unroll
     for (int pass = 0; pass < 8; pass++) {
-        const int row = pass * 32 + rg;
+        const int row = pass * NRG + rg;
         const int tile = row >> 2, i = (row >> 1) & 1, j = row & 1;
         const int timg = tile / (bh * bw), r = tile - timg * (bh * bw);
         const int ty = r / bw, tx = r - ty * bw;
@@ -974,10 +985,10 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
     }
     // exchange: ph = 1 waves -> LDS [wm][wn][ij][r][lane]; ph = 0 waves add (Y = P0 + P1, fixed order)
     float *xch = wsm;                                   // 4 waves x 4 x 16 x 64 floats = 64 KB
-    constexpr int ELD = WN + 4;
-    float *img = wsm + 4 * 4 * 16 * 64;                 // row image [256][ELD] behind it (69.6 KB)
+    constexpr int ELD = NQ + 4;
+    float *img = wsm + 4 * 4 * 16 * 64;                 // row image [4 MT][ELD] behind it (<= 69.6 KB)
     if (ph == 1) {
-        float *dst = xch + ((wm * 2 + wn) * 64) * 64 + lane;
+        float *dst = xch + ((wave & 3) * 64) * 64 + lane;
 #pragma unroll
         for (int ij = 0; ij < 4; ij++)
 #pragma unroll
@@ -985,7 +996,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
     }
     __syncthreads();
     if (ph == 0) {
-        const float *src = xch + ((wm * 2 + wn) * 64) * 64 + lane;
+        const float *src = xch + ((wave & 3) * 64) * 64 + lane;
 #pragma unroll
         for (int ij = 0; ij < 4; ij++)
 #pragma unroll
@@ -1000,7 +1011,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
     int cnt = 0;
 #pragma unroll
     for (int pass = 0; pass < 8; pass++) {
-        const int row = pass * 32 + rg;
+        const int row = pass * NRG + rg;
         const int64_t m = mrow[pass];
         if (m < 0) continue;
         float4 v = *reinterpret_cast<const float4 *>(img + row * ELD + c4 * 4);
@@ -1025,22 +1036,22 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
         float2 *part = reinterpret_cast<float2 *>(wsm);
         const float fc = (float)(cnt > 0 ? cnt : 1);
         const float mx = s1.x / fc, my = s1.y / fc, mz = s1.z / fc, mw = s1.w / fc;
-        part[rg * WN + c4 * 4 + 0] = make_float2(K.x + mx, fmaxf(s2.x - s1.x * mx, 0.f));
-        part[rg * WN + c4 * 4 + 1] = make_float2(K.y + my, fmaxf(s2.y - s1.y * my, 0.f));
-        part[rg * WN + c4 * 4 + 2] = make_float2(K.z + mz, fmaxf(s2.z - s1.z * mz, 0.f));
-        part[rg * WN + c4 * 4 + 3] = make_float2(K.w + mw, fmaxf(s2.w - s1.w * mw, 0.f));
+        part[rg * NQ + c4 * 4 + 0] = make_float2(K.x + mx, fmaxf(s2.x - s1.x * mx, 0.f));
+        part[rg * NQ + c4 * 4 + 1] = make_float2(K.y + my, fmaxf(s2.y - s1.y * my, 0.f));
+        part[rg * NQ + c4 * 4 + 2] = make_float2(K.z + mz, fmaxf(s2.z - s1.z * mz, 0.f));
+        part[rg * NQ + c4 * 4 + 3] = make_float2(K.w + mw, fmaxf(s2.w - s1.w * mw, 0.f));
         __syncthreads();
-        if (tid < WN) {
+        if (tid < NQ) {
             const float npart = 8.0f;   // rows behind each partial
             float mean = part[tid].x, M2 = part[tid].y, na = npart;
-            for (int g = 1; g < 32; g++) {
-                const float2 q = part[g * WN + tid];
+            for (int g = 1; g < NRG; g++) {
+                const float2 q = part[g * NQ + tid];
                 const float d = q.x - mean, N = na + npart;
                 mean += d * (npart / N);
                 M2 += q.y + d * d * (na * npart / N);
                 na = N;
             }
-            const int nt = (H * W) / 256;
+            const int nt = (H * W) / (4 * MT);
             p.stats_out[((int64_t)img0 * nt + blk_in_img) * p.Cout + n0 + tid] = make_float2(mean, M2);
         }
     }
@@ -1145,32 +1156,38 @@ static bool wino_disabled() {
     return v == 1;
 }
 
+// tiles per workgroup: 32 (x 128 output channels) for the 8-wave kernel when Cout allows it, else 64 (x 64 channels)
+int wino_tiles(const ConvLaunch &c) {
+    static int pref = -1;
+    if (pref < 0) { const char *e = getenv("DLPM_WINO_MT"); pref = e ? atoi(e) : 32; }
+    return (wino_variant() == 2 && pref == 32 && c.Cout % 128 == 0) ? 32 : 64;
+}
+
 bool wino_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
     if (wino_disabled() || !c.w_wino || c.ks != 3 || c.stride != 1 || c.in_nchw || c.out_nchw || c.abl) return false;
     if ((c.Hout & 1) || (c.Wout & 1) || c.Cout % WN != 0 || (c.C0 + c.C1) % WKC != 0 || c.C0 % WKC != 0) return false;
     if ((c.R0 & 3) != 0) return false;
     if (c.ups && ((c.Hout & 3) || (c.Wout & 3))) return false;
     const int TH = c.Hout / 2, TW = c.Wout / 2;
+    const int T = wino_tiles(c);
     int h, w, n;
-    if (TH * TW >= WT) {           // a block inside one image
+    if (TH * TW >= T) {            // a block inside one image
         w = TW < 8 ? TW : 8;
-        if (WT % w != 0) return false;
-        h = WT / w;
+        if (T % w != 0) return false;
+        h = T / w;
         if (TW % w != 0 || TH % h != 0) return false;
         n = 1;
     } else {                       // several whole small images per block
-        if (WT % (TH * TW) != 0) return false;
-        h = TH; w = TW; n = WT / (TH * TW);
+        if (T % (TH * TW) != 0) return false;
+        h = TH; w = TW; n = T / (TH * TW);
         if (n > 16) return false;
     }
     const int RH = c.ups ? h + 2 : 2 * h + 2, RW = c.ups ? w + 2 : 2 * w + 2;
     if (c.ups && ((h & 1) || (w & 1))) return false;   // source-resolution halo needs even block origins
-    if (n * RH * RW > RAW_MAXPIX) return false;
+    if (n * RH * RW > (T == 64 ? RAW_MAXPIX : RAW_MAXPIX / 2)) return false;
     *bh = h; *bw = w; *nimg = n;
     return true;
 }
-
-int wino_stats_pixels() { return 256; }
 
 int launch_conv_wino(const ConvLaunch &c, hipStream_t st) {
     int bh, bw, nimg;
@@ -1231,18 +1248,19 @@ int launch_conv_wino(const ConvLaunch &c, hipStream_t st) {
             if (!q) { q = reinterpret_cast<const void *>(fn); break; }
     }
     if (wino_variant() == 2) {
-        fn = c.ups ? &k_conv3x3_wino_q<true> : &k_conv3x3_wino_q<false>;
+        const int mt = wino_tiles(c);
+        if (mt == 32) fn = c.ups ? &k_conv3x3_wino_q<true, 32> : &k_conv3x3_wino_q<false, 32>;
+        else fn = c.ups ? &k_conv3x3_wino_q<true, 64> : &k_conv3x3_wino_q<false, 64>;
 #ifdef DLPM_WINO_ABLATIONS
-        if (!c.ups) {
+        if (!c.ups && mt == 32) {
             switch (abl) {
-                case 1: fn = &k_conv3x3_wino_q<false, 1>; break;
-                case 2: fn = &k_conv3x3_wino_q<false, 2>; break;
-                case 3: fn = &k_conv3x3_wino_q<false, 3>; break;
-                case 4: fn = &k_conv3x3_wino_q<false, 4>; break;
-                case 8: fn = &k_conv3x3_wino_q<false, 8>; break;
-                case 16: fn = &k_conv3x3_wino_q<false, 16>; break;
-                case 31: fn = &k_conv3x3_wino_q<false, 31>; break;
-                case 32: fn = &k_conv3x3_wino_q<false, 32>; break;
+                case 1: fn = &k_conv3x3_wino_q<false, 32, 1>; break;
+                case 2: fn = &k_conv3x3_wino_q<false, 32, 2>; break;
+                case 3: fn = &k_conv3x3_wino_q<false, 32, 3>; break;
+                case 8: fn = &k_conv3x3_wino_q<false, 32, 8>; break;
+                case 16: fn = &k_conv3x3_wino_q<false, 32, 16>; break;
+                case 31: fn = &k_conv3x3_wino_q<false, 32, 31>; break;
+                case 32: fn = &k_conv3x3_wino_q<false, 32, 32>; break;
                 default: break;
             }
         }
@@ -1254,8 +1272,12 @@ int launch_conv_wino(const ConvLaunch &c, hipStream_t st) {
             for (auto &q : configured)
                 if (!q) { q = reinterpret_cast<const void *>(fn); break; }
         }
-        const size_t shmem_q = (size_t)(2 * 16 * WT * PVLD + 2 * RAW_MAXPIX * PRLD + 512) * sizeof(float);
-        fn<<<(unsigned)grid, 512, shmem_q, st>>>(c, bh, bw, nimg);
+        size_t shmem_q = (size_t)(2 * 16 * mt * PVLD + 2 * (mt == 64 ? RAW_MAXPIX : RAW_MAXPIX / 2) * PRLD + 512) * sizeof(float);
+        const size_t epi_q = (size_t)(4 * 4 * 16 * 64 + 4 * mt * (4096 / mt + 4)) * sizeof(float);   // exchange + row image
+        if (shmem_q < epi_q) shmem_q = epi_q;
+        const int64_t tiles_q = (int64_t)c.B * (c.Hout / 2) * (c.Wout / 2);
+        const int64_t mblocks_q = nimg == 1 ? tiles_q / mt : ceil_div(c.B, nimg);
+        fn<<<(unsigned)(mblocks_q * (c.Cout / (4096 / mt))), 512, shmem_q, st>>>(c, bh, bw, nimg);
         DLPM_LAUNCH_CHECK();
         return DLPM_OK;
     }
