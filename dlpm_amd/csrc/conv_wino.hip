@@ -733,7 +733,7 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_wino_p(ConvLaunch p, int bh,
 // Phase structure as in k_conv3x3_wino_p: double-buffered raw / V, one barrier per 8-channel chunk.
 // ---------------------------------------------------------------------------------------------
 constexpr int QRAW_NIT = (RAW_MAXPIX * 2 + 511) / 512;   // 3 float4 per thread (512 threads)
-constexpr int QRING = 4;
+constexpr int QRING = 8;      // weight prefetch ring of the 8-wave kernel (groups of 4 MFMAs); must divide the 8 groups of a phase
 
 // MT = tiles per workgroup: 64 (x 64 output channels) or 32 (x 128 channels).  The accumulator block is 256 KB either
 // way; the 32-tile shape stages a smaller halo patch per MFMA (180-288 instead of 324-576 pixels, for twice the
@@ -756,8 +756,11 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
     const int W = p.Wout, H = p.Hout, TW = W >> 1, TH = H >> 1;
     const int Ws = UPS ? (W >> 1) : W, Hs = UPS ? (H >> 1) : H;
     const int Cin = p.C0 + p.C1, nch = Cin / PKC;
+    // n-tile-major grid: all workgroups in flight stream the SAME half of the Winograd-domain weights (2.1 MB for a
+    // 256 x 256 layer: fits the 4-MB L2 of an XCD; both halves together do not)
     const int ntn = p.Cout / NQ;
-    const int mb = blockIdx.x / ntn, n0 = (blockIdx.x % ntn) * NQ;
+    const int nmb = gridDim.x / ntn;
+    const int mb = blockIdx.x % nmb, n0 = (blockIdx.x / nmb) * NQ;
     int img0, ty0, tx0, blk_in_img = 0;
     if (nimg == 1) {
         const int bpr = TW / bw, bpi = (TH / bh) * bpr;
@@ -1288,12 +1291,12 @@ int launch_conv_wino(const ConvLaunch &c, hipStream_t st) {
 
 int64_t wino_weight_floats(int Cout, int Cin) {
     // + AHEAD groups of padding: the prefetch ring reads past the last group
-    return ((int64_t)(Cout / 32) * (Cin / WKC) * WGRP + (WRING - 1)) * 256;
+    return ((int64_t)(Cout / 32) * (Cin / WKC) * WGRP + 8) * 256;   // 8 >= every kernel's ring depth - 1
 }
 
 int relayout_weight_wino(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st) {
     const int64_t n = (int64_t)(Cout / 32) * (Cin / WKC) * WGRP * 256;
-    DLPM_HIP(hipMemsetAsync(dst_dev + n, 0, (size_t)(WRING - 1) * 256 * sizeof(float), st));
+    DLPM_HIP(hipMemsetAsync(dst_dev + n, 0, (size_t)8 * 256 * sizeof(float), st));
     if (wino_variant() == 2) k_relayout_weight_wino_q<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
     else if (wino_pipelined()) k_relayout_weight_wino_p<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
     else k_relayout_weight_wino<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
