@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libdlpm_amd.so')
 
 vp, i32, i64, u32, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
 
+ABI_VERSION = 2   # must equal dlpm_abi_version(): struct layouts below mirror include/dlpm_amd.h at this version
 UPD_DLIM, UPD_CLIP, UPD_ADVANCE, SMP_NO_FUSED_MLP, UPD_ELEMENTWISE, SMP_LIM = 1, 2, 4, 8, 16, 32
 
 
@@ -136,6 +137,10 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        got = handle.dlpm_abi_version()
+        if got != ABI_VERSION:
+            raise DlpmError('libdlpm_amd.so has ABI version %d, the Python mirror expects %d -- rebuild with '
+                            '`python -m dlpm_amd.build`' % (got, ABI_VERSION))
         _lib = handle
     return _lib
 
