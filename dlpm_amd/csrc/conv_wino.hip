@@ -739,11 +739,15 @@ constexpr int QRING = 8;      // weight prefetch ring of the 8-wave kernel (grou
 // way; the 32-tile shape stages a smaller halo patch per MFMA (180-288 instead of 324-576 pixels, for twice the
 // channels) and transforms half as many tiles, i.e. ~40 % less VALU work per MFMA -- which matters because VALU time
 // is added to MFMA time on this chip -- at the price of streaming every weight fragment for one MFMA tile only.
-template <bool UPS, int MT, int ABL = 0>   // ABL (DLPM_WINO_ABLATIONS builds): 1 no S, 2 no X, 4 no raw loads, 8 no barrier, 16 no weight loads, 32 no MFMA
-__global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh, int bw, int nimg) {
-    constexpr int NQ = 4096 / MT;                    // output channels per workgroup
+// NW = waves per workgroup: 8 (one workgroup per CU, 256-KB accumulator block) or 4 (MT = 32 only: 32 tiles x 64
+// channels, 128-KB block, TWO workgroups per CU, so that one's prologue / epilogue / barriers overlap the other's MFMAs).
+template <bool UPS, int MT, int NW = 8, int ABL = 0>   // ABL (DLPM_WINO_ABLATIONS builds): 1 no S, 2 no X, 4 no raw loads, 8 no barrier, 16 no weight loads, 32 no MFMA
+__global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(ConvLaunch p, int bh, int bw, int nimg) {
+    static_assert(NW == 8 || (NW == 4 && MT == 32), "wave layout");
+    constexpr int NT = NW * 64;                      // threads
+    constexpr int NQ = NW == 8 ? 4096 / MT : 64;     // output channels per workgroup
     constexpr int RAWPIX = MT == 64 ? RAW_MAXPIX : RAW_MAXPIX / 2;
-    constexpr int QNIT = (RAWPIX * 2 + 511) / 512;   // staging items per thread
+    constexpr int QNIT = (RAWPIX * 2 + NT - 1) / NT; // staging items per thread
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float *V = wsm;                                  // [2][16][MT][PVLD]
     float *raw = wsm + 2 * 16 * MT * PVLD;           // [2][RAWPIX][PRLD]
@@ -751,8 +755,8 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int ph = wave >> 2;
-    const int wn = MT == 64 ? (wave & 1) : (wave & 3), wm = MT == 64 ? ((wave >> 1) & 1) : 0;
+    const int ph = NW == 8 ? wave >> 2 : wave >> 1;
+    const int wn = MT == 64 ? (wave & 1) : (NW == 8 ? (wave & 3) : (wave & 1)), wm = MT == 64 ? ((wave >> 1) & 1) : 0;
     const int W = p.Wout, H = p.Hout, TW = W >> 1, TH = H >> 1;
     const int Ws = UPS ? (W >> 1) : W, Hs = UPS ? (H >> 1) : H;
     const int Cin = p.C0 + p.C1, nch = Cin / PKC;
@@ -781,7 +785,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
     int off[QNIT], cfo[QNIT];
 #pragma unroll
     for (int it = 0; it < QNIT; it++) {
-        const int pix = it * 256 + (tid >> 1);
+        const int pix = it * (NT / 2) + (tid >> 1);
         const int img = min(pix / rpi, nimg - 1), r = pix - img * rpi;
         const int ry = r / RW, rx = r - ry * RW;
         const int iy = oy + ry, ix = ox + rx;
@@ -829,14 +833,14 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
                 x.w = silu_f(x.w);
             }
             if (off[it] < 0) x = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding applies AFTER the activation
-            *reinterpret_cast<float4 *>(rb + (it * 256 + (tid >> 1)) * PRLD + squad * 4) = x;
+            *reinterpret_cast<float4 *>(rb + (it * (NT / 2) + (tid >> 1)) * PRLD + squad * 4) = x;
         }
     };
 
     // ---- input transform: thread = (tile, quad) over lanes x one row r of V (wave-uniform): V[r][.] = (B^T d)[r] B
     //   row 0: d0 - d2   row 1: d1 + d2   row 2: d2 - d1   row 3: d1 - d3
     const int trow = wave & 3;
-    const bool xform_mine = MT == 64 || wave < 4;     // 32 tiles x 2 quads x 4 rows = 256 items: the ph = 0 waves
+    const bool xform_mine = MT == 64 || wave < 4;     // 32 tiles x 2 quads x 4 rows = 256 items: waves 0..3
     const int rA = trow == 0 ? 0 : trow == 2 ? 2 : 1, rB = trow == 0 ? 2 : trow == 1 ? 2 : trow == 2 ? 1 : 3;
     const float tsg = trow == 1 ? 1.f : -1.f;
     int roA, roB, coloff[4], vofs;
@@ -950,14 +954,15 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
     if (ABL & 8) __syncthreads();
 
     // ---- epilogue addressing + residual prefetch (8 rows per thread)
-    constexpr int C4N = NQ / 4, NRG = 512 / C4N;   // float4 columns per row, row groups (32 or 16)
+    constexpr int C4N = NQ / 4, NRG = NT / C4N;    // float4 columns per row, row groups
+    constexpr int NPASS = 4 * MT / NRG;             // rows per thread (8)
     const int c4 = tid % C4N, rg = tid / C4N;
     const int n = n0 + c4 * 4;
     const int R1 = p.Cout - p.R0;
-    int64_t mrow[8];
-    float4 resq[8];
+    int64_t mrow[NPASS];
+    float4 resq[NPASS];
 #pragma unroll
-    for (int pass = 0; pass < 8; pass++) {
+    for (int pass = 0; pass < NPASS; pass++) {
         const int row = pass * NRG + rg;
         const int tile = row >> 2, i = (row >> 1) & 1, j = row & 1;
         const int timg = tile / (bh * bw), r = tile - timg * (bh * bw);
@@ -987,11 +992,11 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
         }
     }
     // exchange: ph = 1 waves -> LDS [wm][wn][ij][r][lane]; ph = 0 waves add (Y = P0 + P1, fixed order)
-    float *xch = wsm;                                   // 4 waves x 4 x 16 x 64 floats = 64 KB
+    float *xch = wsm;                                   // NW/2 waves x 4 x 16 x 64 floats (64 or 32 KB)
     constexpr int ELD = NQ + 4;
-    float *img = wsm + 4 * 4 * 16 * 64;                 // row image [4 MT][ELD] behind it (<= 69.6 KB)
+    float *img = wsm + (NW / 2) * 4 * 16 * 64;          // row image [4 MT][ELD] behind it (<= 69.6 KB)
     if (ph == 1) {
-        float *dst = xch + ((wave & 3) * 64) * 64 + lane;
+        float *dst = xch + ((wave & (NW / 2 - 1)) * 64) * 64 + lane;
 #pragma unroll
         for (int ij = 0; ij < 4; ij++)
 #pragma unroll
@@ -999,7 +1004,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
     }
     __syncthreads();
     if (ph == 0) {
-        const float *src = xch + ((wave & 3) * 64) * 64 + lane;
+        const float *src = xch + ((wave & (NW / 2 - 1)) * 64) * 64 + lane;
 #pragma unroll
         for (int ij = 0; ij < 4; ij++)
 #pragma unroll
@@ -1013,7 +1018,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
     float4 K = make_float4(0.f, 0.f, 0.f, 0.f), s1 = K, s2 = K;
     int cnt = 0;
 #pragma unroll
-    for (int pass = 0; pass < 8; pass++) {
+    for (int pass = 0; pass < NPASS; pass++) {
         const int row = pass * NRG + rg;
         const int64_t m = mrow[pass];
         if (m < 0) continue;
@@ -1045,7 +1050,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_wino_q(ConvLaunch p, int bh,
         part[rg * NQ + c4 * 4 + 3] = make_float2(K.w + mw, fmaxf(s2.w - s1.w * mw, 0.f));
         __syncthreads();
         if (tid < NQ) {
-            const float npart = 8.0f;   // rows behind each partial
+            const float npart = (float)NPASS;   // rows behind each partial
             float mean = part[tid].x, M2 = part[tid].y, na = npart;
             for (int g = 1; g < NRG; g++) {
                 const float2 q = part[g * NQ + tid];
@@ -1159,11 +1164,20 @@ static bool wino_disabled() {
     return v == 1;
 }
 
+int wino_waves(const ConvLaunch &c);
 // tiles per workgroup: 32 (x 128 output channels) for the 8-wave kernel when Cout allows it, else 64 (x 64 channels)
 int wino_tiles(const ConvLaunch &c) {
     static int pref = -1;
     if (pref < 0) { const char *e = getenv("DLPM_WINO_MT"); pref = e ? atoi(e) : 32; }
+    if (wino_variant() == 2 && wino_waves(c) == 4) return 32;
     return (wino_variant() == 2 && pref == 32 && c.Cout % 128 == 0) ? 32 : 64;
+}
+
+// waves per workgroup of the 8-wave kernel family: DLPM_WINO_NW=4 selects the two-workgroups-per-CU shape (32 x 64 blocks)
+int wino_waves(const ConvLaunch &c) {
+    static int pref = -1;
+    if (pref < 0) { const char *e = getenv("DLPM_WINO_NW"); pref = e ? atoi(e) : 8; }
+    return (pref == 4 && wino_variant() == 2) ? 4 : 8;
 }
 
 bool wino_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
@@ -1252,18 +1266,20 @@ int launch_conv_wino(const ConvLaunch &c, hipStream_t st) {
     }
     if (wino_variant() == 2) {
         const int mt = wino_tiles(c);
-        if (mt == 32) fn = c.ups ? &k_conv3x3_wino_q<true, 32> : &k_conv3x3_wino_q<false, 32>;
+        const int nw = wino_waves(c);
+        if (mt == 32 && nw == 4) fn = c.ups ? &k_conv3x3_wino_q<true, 32, 4> : &k_conv3x3_wino_q<false, 32, 4>;
+        else if (mt == 32) fn = c.ups ? &k_conv3x3_wino_q<true, 32> : &k_conv3x3_wino_q<false, 32>;
         else fn = c.ups ? &k_conv3x3_wino_q<true, 64> : &k_conv3x3_wino_q<false, 64>;
 #ifdef DLPM_WINO_ABLATIONS
-        if (!c.ups && mt == 32) {
+        if (!c.ups && mt == 32 && nw == 8) {
             switch (abl) {
-                case 1: fn = &k_conv3x3_wino_q<false, 32, 1>; break;
-                case 2: fn = &k_conv3x3_wino_q<false, 32, 2>; break;
-                case 3: fn = &k_conv3x3_wino_q<false, 32, 3>; break;
-                case 8: fn = &k_conv3x3_wino_q<false, 32, 8>; break;
-                case 16: fn = &k_conv3x3_wino_q<false, 32, 16>; break;
-                case 31: fn = &k_conv3x3_wino_q<false, 32, 31>; break;
-                case 32: fn = &k_conv3x3_wino_q<false, 32, 32>; break;
+                case 1: fn = &k_conv3x3_wino_q<false, 32, 8, 1>; break;
+                case 2: fn = &k_conv3x3_wino_q<false, 32, 8, 2>; break;
+                case 3: fn = &k_conv3x3_wino_q<false, 32, 8, 3>; break;
+                case 8: fn = &k_conv3x3_wino_q<false, 32, 8, 8>; break;
+                case 16: fn = &k_conv3x3_wino_q<false, 32, 8, 16>; break;
+                case 31: fn = &k_conv3x3_wino_q<false, 32, 8, 31>; break;
+                case 32: fn = &k_conv3x3_wino_q<false, 32, 8, 32>; break;
                 default: break;
             }
         }
@@ -1275,12 +1291,13 @@ int launch_conv_wino(const ConvLaunch &c, hipStream_t st) {
             for (auto &q : configured)
                 if (!q) { q = reinterpret_cast<const void *>(fn); break; }
         }
+        const int nq = nw == 8 ? 4096 / mt : 64;
         size_t shmem_q = (size_t)(2 * 16 * mt * PVLD + 2 * (mt == 64 ? RAW_MAXPIX : RAW_MAXPIX / 2) * PRLD + 512) * sizeof(float);
-        const size_t epi_q = (size_t)(4 * 4 * 16 * 64 + 4 * mt * (4096 / mt + 4)) * sizeof(float);   // exchange + row image
+        const size_t epi_q = (size_t)((nw / 2) * 4 * 16 * 64 + 4 * mt * (nq + 4)) * sizeof(float);   // exchange + row image
         if (shmem_q < epi_q) shmem_q = epi_q;
         const int64_t tiles_q = (int64_t)c.B * (c.Hout / 2) * (c.Wout / 2);
         const int64_t mblocks_q = nimg == 1 ? tiles_q / mt : ceil_div(c.B, nimg);
-        fn<<<(unsigned)(mblocks_q * (c.Cout / (4096 / mt))), 512, shmem_q, st>>>(c, bh, bw, nimg);
+        fn<<<(unsigned)(mblocks_q * (c.Cout / nq)), nw * 64, shmem_q, st>>>(c, bh, bw, nimg);
         DLPM_LAUNCH_CHECK();
         return DLPM_OK;
     }
