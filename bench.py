@@ -108,12 +108,19 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert world == args.gpus, 'WORLD_SIZE=%d but --gpus %d (use torch.distributed.run for N > 1)' % (world, args.gpus)
+    # test hooks (not used by the driver): run the N-rank control flow on a 1-GPU box -- every rank on cuda:0 with gloo
+    if os.environ.get('DLPM_BENCH_SINGLE_DEVICE') == '1':
+        local = 0
+    backend = os.environ.get('DLPM_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import dlpm_amd
     from dlpm_amd import _lib
