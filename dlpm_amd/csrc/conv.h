@@ -23,6 +23,7 @@ struct ConvLaunch {
     float *out = nullptr;
     int Cout = 0;
     int in_nchw = 0, out_nchw = 0;  // boundary layouts
+    int ws_gemm = 0;                // 1x1 only: use the weight-streaming kernel (TAPS = 1) instead of k_conv_igemm
     int abl = 0;                    // timing-only ablation bits (DLPM_ABL env; results are wrong when set)
     // Optional fused GroupNorm statistics of the OUTPUT: per (image, pixel tile, channel) the
     // pair (mean, centred sum of squares) over the tile's pixels, written by the MFMA kernels'
@@ -55,8 +56,8 @@ inline int launch_conv_fallback(const ConvLaunch &L, hipStream_t st) {
 // weight re-layout kernels: OIHW -> [tap][Cout][Cin] (igemm) or [tap][Cin][Cout] (direct)
 int relayout_weight(const float *oihw_dev, float *dst_dev, int Cout, int Cin, int ks, bool for_igemm, hipStream_t st);
 // OIHW 3x3 -> fragment order for k_conv3x3_halo_ws; dst holds frag_weight_floats(Cout, Cin) floats
-int64_t frag_weight_floats(int Cout, int Cin);
-int relayout_weight_frag(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st);
+int64_t frag_weight_floats(int Cout, int Cin, int taps = 9);
+int relayout_weight_frag(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st, int taps = 9);
 
 int launch_gn_coeffs(const float *src0, const float *src1, int C0, int C1, int B, int HW, int groups,
                      const float *gamma, const float *beta, const float *ss, int64_t ss_stride, int64_t ss_offset,

@@ -506,18 +506,22 @@ __global__ void __launch_bounds__(256) k_conv3x3_halo(ConvLaunch p, int th, int 
 // micro-benchmark tools/mb/mfma_loop.hip): the LDS weight staging + per-tap barrier cost ~8 % of the
 // kernel.
 // ---------------------------------------------------------------------------------------------
-template <int BN, int WAVES_M, int WAVES_N, int RM, int RN, int RING, bool UPS>
+// TAPS = 9: the 3x3 convolution.  TAPS = 1: the same kernel as a plain GEMM over pixels for 1x1 convolutions / conv1d /
+// Linear (no halo, 4 fragment groups per chunk) -- weights from registers instead of through LDS.
+template <int BN, int WAVES_M, int WAVES_N, int RM, int RN, int RING, bool UPS, int TAPS = 9>
 __global__ void __launch_bounds__(256, 2) k_conv3x3_halo_ws(ConvLaunch p, int th, int nimg) {
     // UPS: the conv runs on the nearest-x2 upsampled input (Upsample, unet.py:73-75).  The halo tile then holds
     // the SOURCE-resolution patch ((th/2+2) x (W/2+2) pixels) and each lane's tap address is
     // row_offset[ky] + col_offset[kx], which depend on the parity of its output pixel.
     static_assert(WAVES_M * WAVES_N == 4 && WAVES_M * RM * 32 == BM && WAVES_N * RN * 32 == BN, "tile shape");
-    constexpr int NG = 36;  // fragment groups per chunk: 9 taps x 4 k-groups
+    static_assert(TAPS == 9 || (TAPS == 1 && !UPS), "taps");
+    constexpr int NG = TAPS * 4;  // fragment groups per chunk: taps x 4 k-groups
+    constexpr int PADW = TAPS == 9 ? 1 : 0;
     extern __shared__ __attribute__((aligned(16))) float hsm[];
     const int W = p.Wout, H = p.Hout;
     const int Ws = UPS ? (W >> 1) : W, Hs = UPS ? (H >> 1) : H;   // source (staged) resolution
-    const int Wp = Ws + 2;
-    const int hpi = ((UPS ? (th >> 1) : th) + 2) * Wp;
+    const int Wp = Ws + 2 * PADW;
+    const int hpi = ((UPS ? (th >> 1) : th) + 2 * PADW) * Wp;
     const int hp = nimg * hpi;
     float *Ah = hsm;
     float *Cf = hsm + ((hp + 3) & ~3) * LDS_LD;
@@ -544,7 +548,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_halo_ws(ConvLaunch p, int th
         const int hpix = it * 32 + (tid >> 3);
         const int img = hpix / hpi, hr = hpix - img * hpi;
         const int hy = hr / Wp, hx = hr - hy * Wp;
-        const int iy = (UPS ? (y0 >> 1) : y0) + hy - 1, ix = hx - 1;
+        const int iy = (UPS ? (y0 >> 1) : y0) + hy - PADW, ix = hx - PADW;
         const bool pad = iy < 0 || iy >= Hs || ix < 0 || ix >= Ws || (pb + img) >= p.B;
         off[it] = (it >= nit || hpix >= hp) ? -2 : (pad ? -1 : (((pb + img) * Hs + iy) * Ws + ix));
     }
@@ -653,7 +657,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_halo_ws(ConvLaunch p, int th
                 bq[(g + AHEAD) % RING][j] = wbase[woff[j] + AHEAD * 64];
                 woff[j] += 64;
             }
-            if (g == 24 && more) load_halo(chunk + 1);  // tap 6: two taps of MFMAs cover its latency
+            if (g == (TAPS == 9 ? 24 : 0) && more) load_halo(chunk + 1);  // 3x3: at tap 6, two taps of MFMAs cover its latency
             // pin the prefetch HERE: left alone, the scheduler sinks each load to just before its first
             // use (two groups later) to save registers and then waits for it with vmcnt(0)
             __builtin_amdgcn_sched_barrier(0);
@@ -715,9 +719,9 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_halo_ws(ConvLaunch p, int th
 
 // OIHW (3x3) -> Wf[nb][chunk][tap][kk][lane][4]:  lane = kh*32 + l31 holds
 // W[cout = nb*32 + l31][cin = chunk*32 + kk*8 + kh*4 + e][tap], zero beyond Cout.
-__global__ void k_relayout_weight_frag(const float *oihw, float *dst, int Cout, int Cin) {
+__global__ void k_relayout_weight_frag(const float *oihw, float *dst, int Cout, int Cin, int taps) {
     const int nbk = (Cout + 31) / 32, nch = Cin / 32;
-    const int64_t n = (int64_t)nbk * nch * 36 * 64 * 4;
+    const int64_t n = (int64_t)nbk * nch * taps * 4 * 64 * 4;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int e = (int)(i & 3);
@@ -725,12 +729,12 @@ __global__ void k_relayout_weight_frag(const float *oihw, float *dst, int Cout, 
     int64_t r = i >> 8;
     const int kk = (int)(r & 3);
     r >>= 2;
-    const int tap = (int)(r % 9);
-    r /= 9;
+    const int tap = (int)(r % taps);
+    r /= taps;
     const int chunk = (int)(r % nch);
     const int nb = (int)(r / nch);
     const int co = nb * 32 + (lane & 31), ci = chunk * 32 + kk * 8 + (lane >> 5) * 4 + e;
-    dst[i] = (co < Cout) ? oihw[((int64_t)co * Cin + ci) * 9 + tap] : 0.f;
+    dst[i] = (co < Cout) ? oihw[((int64_t)co * Cin + ci) * taps + tap] : 0.f;
 }
 
 // stem: Cin = image channels read from the caller's NCHW state, 3x3 stride 1, writes NHWC.
@@ -825,9 +829,10 @@ static bool halo_ok(const ConvLaunch &c, int *th, int *nimg) {
     return *nimg * (*th + 2) * (W + 2) * 8 <= HALO_NIT * 256;
 }
 
-template <int BN, int WAVES_M, int WAVES_N, int RM, int RN, int RING, bool UPS>
+template <int BN, int WAVES_M, int WAVES_N, int RM, int RN, int RING, bool UPS, int TAPS = 9>
 static int launch_halo_ws_r(const ConvLaunch &c, int th, int nimg, int64_t grid, hipStream_t st) {
-    const int hp = nimg * ((UPS ? th / 2 : th) + 2) * ((UPS ? c.Wout / 2 : c.Wout) + 2);
+    constexpr int PADW = TAPS == 9 ? 1 : 0;
+    const int hp = nimg * ((UPS ? th / 2 : th) + 2 * PADW) * ((UPS ? c.Wout / 2 : c.Wout) + 2 * PADW);
     size_t shmem = (size_t)((hp + 3) & ~3) * LDS_LD * sizeof(float) + (size_t)nimg * 64 * sizeof(float);
     const size_t epi = (size_t)(RM * 32) * (BN + 4) * sizeof(float);   // epilogue_rows' row image
     const size_t stats = (size_t)(256 / (BN / 4)) * BN * 2 * sizeof(float);
@@ -835,11 +840,11 @@ static int launch_halo_ws_r(const ConvLaunch &c, int th, int nimg, int64_t grid,
     if (shmem < stats) shmem = stats;
     static bool attr = false;
     if (!attr) {
-        DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo_ws<BN, WAVES_M, WAVES_N, RM, RN, RING, UPS>),
+        DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo_ws<BN, WAVES_M, WAVES_N, RM, RN, RING, UPS, TAPS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         attr = true;
     }
-    k_conv3x3_halo_ws<BN, WAVES_M, WAVES_N, RM, RN, RING, UPS><<<(unsigned)grid, 256, shmem, st>>>(c, th, nimg);
+    k_conv3x3_halo_ws<BN, WAVES_M, WAVES_N, RM, RN, RING, UPS, TAPS><<<(unsigned)grid, 256, shmem, st>>>(c, th, nimg);
     return DLPM_OK;
 }
 
@@ -848,6 +853,32 @@ static int launch_halo_ws(const ConvLaunch &c, int th, int nimg, int64_t grid, h
     // ring depth 2 = one fragment group (16 MFMAs = 1024 cycles) of prefetch distance; 3 measured equal
     if (c.ups) return launch_halo_ws_r<BN, WAVES_M, WAVES_N, RM, RN, 2, true>(c, th, nimg, grid, st);
     return launch_halo_ws_r<BN, WAVES_M, WAVES_N, RM, RN, 2, false>(c, th, nimg, grid, st);
+}
+
+// 1x1 / Linear through the weight-streaming kernel (TAPS = 1): geometry of the 128-pixel tile
+static bool gemm_ws_ok(const ConvLaunch &c, int *th, int *nimg) {
+    // opt-in (ConvLaunch::ws_gemm): measured on the CIFAR net it is 1-10 % SLOWER than k_conv_igemm for every 1x1 shape
+    // (91 vs 101 TFLOP/s at H32, 128+128 -> 128): with one tap there are only 64 MFMAs per wave between two barriers,
+    // and the LDS weight staging it removes was not what limits these launches
+    if (!c.ws_gemm || ws_disabled() || !c.w_frag || c.ks != 1 || c.stride != 1 || c.ups || c.in_nchw || c.abl) return false;
+    if ((c.C0 + c.C1) % KC != 0 || (c.C0 & 3) || c.Hin != c.Hout || c.Win != c.Wout) return false;
+    const int W = c.Wout, HW = c.Hout * c.Wout;
+    if (HW >= BM) {
+        if (HW % BM != 0 || BM % W != 0) return false;
+        *th = BM / W;
+        *nimg = 1;
+    } else {
+        if (BM % HW != 0) return false;
+        *th = c.Hout;
+        *nimg = BM / HW;
+        if (c.coefA && *nimg > 16) return false;   // 16 threads per image load the GroupNorm coefficients
+    }
+    return true;
+}
+
+template <int BN, int WAVES_M, int WAVES_N, int RM, int RN>
+static int launch_gemm_ws(const ConvLaunch &c, int th, int nimg, int64_t grid, hipStream_t st) {
+    return launch_halo_ws_r<BN, WAVES_M, WAVES_N, RM, RN, 2, false, 1>(c, th, nimg, grid, st);
 }
 
 template <int BN, int WAVES_M, int WAVES_N, int RM, int RN>
@@ -909,6 +940,15 @@ int launch_conv_igemm(const ConvLaunch &c, hipStream_t st) {
     static int abl = -1;
     if (abl < 0) { const char *e = getenv("DLPM_ABL"); abl = e ? atoi(e) : 0; }
     if (abl) const_cast<ConvLaunch &>(c).abl = abl;
+    if (gemm_ws_ok(c, &th, &nimg)) {
+        int r;
+        if (c.Cout > 64) r = launch_gemm_ws<128, 2, 2, 2, 2>(c, th, nimg, mt * ceil_div(c.Cout, 128), st);
+        else if (c.Cout > 32) r = launch_gemm_ws<64, 2, 2, 2, 1>(c, th, nimg, mt * ceil_div(c.Cout, 64), st);
+        else r = launch_gemm_ws<32, 4, 1, 1, 1>(c, th, nimg, mt * ceil_div(c.Cout, 32), st);
+        if (r != DLPM_OK) return r;
+        DLPM_LAUNCH_CHECK();
+        return DLPM_OK;
+    }
     if (halo_ok(c, &th, &nimg)) {
         int r;
         if (c.w_frag && !ws_disabled() && !c.abl && (c.C0 + c.C1) % KC == 0) {
@@ -940,15 +980,15 @@ int launch_conv_igemm(const ConvLaunch &c, hipStream_t st) {
     return DLPM_OK;
 }
 
-int64_t frag_weight_floats(int Cout, int Cin) {
+int64_t frag_weight_floats(int Cout, int Cin, int taps) {
     // + 2 groups of padding at the end: the 2-ahead prefetch of the last groups reads past the data
-    return ((int64_t)((Cout + 31) / 32) * (Cin / 32) * 36 + 2) * 256;
+    return ((int64_t)((Cout + 31) / 32) * (Cin / 32) * taps * 4 + 2) * 256;
 }
 
-int relayout_weight_frag(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st) {
-    const int64_t n = (int64_t)((Cout + 31) / 32) * (Cin / 32) * 36 * 256;
+int relayout_weight_frag(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st, int taps) {
+    const int64_t n = (int64_t)((Cout + 31) / 32) * (Cin / 32) * taps * 4 * 256;
     DLPM_HIP(hipMemsetAsync(dst_dev + n, 0, 2 * 256 * sizeof(float), st));
-    k_relayout_weight_frag<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
+    k_relayout_weight_frag<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin, taps);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }

@@ -239,6 +239,12 @@ void build_arch(dlpm_unet *u) {
     u->head = u->conv("out.2.", c.out_channels, mc, 3);
 }
 
+bool ws_gemm_enabled() {   // DLPM_WS1X1=1: route the UNet's 1x1 convolutions through the weight-streaming kernel (experiment)
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DLPM_WS1X1"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 none, 1 NCHW input (stem), 2 NCHW output (head)
     ConvLaunch probe;
     probe.C0 = C0; probe.C1 = c.cin - C0; probe.Cout = c.cout; probe.ks = c.ks;
@@ -247,6 +253,10 @@ int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 no
     const float *src = u->params[c.p_w].dev;
     if (c.use_igemm && c.ks == 1) {  // [O][I] row-major is already the igemm layout
         c.w_dev = const_cast<float *>(src);
+        if (ws_gemm_enabled() && c.cin % 32 == 0 && boundary == 0) {   // fragment order for the weight-streaming GEMM (TAPS = 1)
+            DLPM_HIP(hipMalloc(&c.w_frag, (size_t)frag_weight_floats(c.cout, c.cin, 1) * sizeof(float)));
+            return relayout_weight_frag(src, c.w_frag, c.cout, c.cin, nullptr, 1);
+        }
         return DLPM_OK;
     }
     DLPM_HIP(hipMalloc(&c.w_dev, (size_t)c.cout * c.cin * c.ks * c.ks * sizeof(float)));
@@ -268,6 +278,7 @@ int run_conv(const ConvW &c, ConvLaunch L, hipStream_t st) {
     L.w = c.w_dev;
     L.w_frag = c.w_frag;
     L.w_wino = c.w_wino;
+    L.ws_gemm = (c.ks == 1 && c.w_frag) ? 1 : 0;
     L.ks = c.ks;
     L.Cout = c.cout;
     return c.use_igemm ? launch_conv_igemm(L, st) : launch_conv_fallback(L, st);
@@ -710,6 +721,13 @@ extern "C" int dlpm_conv2d_f32(const dlpm_conv_args *a, float *scratch_dev, dlpm
     hipStream_t st = as_stream(stream);
     TRY(relayout_weight(a->weight, scratch_dev, a->Cout, a->C0 + a->C1, a->ksize, ig, st));
     L.w = scratch_dev;
+    if (ig && a->ksize == 1 && (a->C0 + a->C1) % 32 == 0 && (a->force_direct & 4) &&
+        a->scratch_floats >= (int64_t)a->Cout * (a->C0 + a->C1) + frag_weight_floats(a->Cout, a->C0 + a->C1, 1)) {
+        float *wf = scratch_dev + (int64_t)a->Cout * (a->C0 + a->C1);
+        TRY(relayout_weight_frag(a->weight, wf, a->Cout, a->C0 + a->C1, st, 1));
+        L.w_frag = wf;
+        L.ws_gemm = 1;
+    }
     if (ig && a->ksize == 3 && (a->C0 + a->C1) % 32 == 0 &&
         a->scratch_floats >= (int64_t)a->Cout * (a->C0 + a->C1) * 9 + frag_weight_floats(a->Cout, a->C0 + a->C1)) {
         float *wf = scratch_dev + (int64_t)a->Cout * (a->C0 + a->C1) * 9;

@@ -101,6 +101,10 @@ CONV_CASES = [
     ('igemm_3x3_upsample', 2, 64, 0, 4, 64, 3, 1, 1, False, False, False),
     ('igemm_cout_256_tail', 1, 128, 0, 4, 256, 3, 1, 0, False, False, True),
     ('igemm_cout_96', 2, 32, 0, 8, 96, 1, 1, 0, True, False, False),
+    ('igemm_1x1_qkv_16x16', 3, 64, 0, 16, 192, 1, 1, 0, True, False, False),
+    ('igemm_1x1_proj_res_4x4', 5, 64, 0, 4, 64, 1, 1, 0, False, False, True),
+    ('igemm_1x1_skip_concat_32x32', 1, 64, 64, 32, 128, 1, 1, 0, False, False, False),
+    ('igemm_linear_silu', 37, 128, 0, 1, 96, 1, 1, 0, False, True, False),
     ('igemm_ragged_m', 3, 32, 0, 4, 32, 3, 1, 0, False, True, False),     # M = 48 < one 128-pixel tile
     ('igemm_32x32_rows', 1, 32, 0, 32, 64, 3, 1, 0, True, True, True),
     ('igemm_halo_32x32_concat_res', 2, 64, 32, 32, 128, 3, 1, 0, True, True, True),
@@ -140,6 +144,10 @@ def test_conv(case):
         assert (got_h - want).abs().max().item() < conv_tol(w, Cin), name + ' (implicit GEMM)'
         print('%s: winograd/auto err %.2e, implicit-GEMM err %.2e, tol %.2e' % (
             name, (got - want).abs().max().item(), (got_h - want).abs().max().item(), conv_tol(w, Cin)))
+    if 'igemm' in name and ks == 1:
+        # force_direct bit 2: the same 1x1 shape through the weight-streaming kernel (TAPS = 1; opt-in, see gemm_ws_ok)
+        got_l = run_conv(x0, w, bias, x1, stride, ups, coef, silu, res, force_direct=4)
+        assert (got_l - want).abs().max().item() < conv_tol(w, Cin), name + ' (weight-streaming GEMM)'
     if 'igemm' in name:  # same shape through the direct kernel: the two kernels agree with each other
         got_d = run_conv(x0, w, bias, x1, stride, ups, coef, silu, res, force_direct=True)
         assert (got_d - want).abs().max().item() < conv_tol(w, Cin), name + ' (direct)'
