@@ -15,6 +15,7 @@ struct ConvLaunch {
                                    // (see k_conv3x3_halo_ws): each wave streams it straight into registers
     const float *w_wino = nullptr; // optional, 3x3 s1 only: Winograd-domain weights U = G g G^T in fragment order
                                    // (see conv_wino.hip); when the shape qualifies the F(2x2,3x3) kernel runs
+    const float *w_small = nullptr;// optional, 3x3 with Cout <= 4 (the head): [tap][Cin][4] for k_conv3x3_head
     const float *bias = nullptr;   // [Cout] or null
     const float *coefA = nullptr, *coefB = nullptr;  // [B, Cin] fused GroupNorm affine, or null
     int act_silu = 0;
@@ -37,6 +38,10 @@ bool igemm_supported(const ConvLaunch &c);
 int launch_conv_igemm(const ConvLaunch &c, hipStream_t st);
 int launch_conv_direct(const ConvLaunch &c, hipStream_t st);
 int launch_conv_stem(const ConvLaunch &c, hipStream_t st);
+// head convolution (Cout <= 4) as a VALU kernel (conv_direct.hip)
+bool head_conv_ok(const ConvLaunch &c);
+int launch_conv_head(const ConvLaunch &c, hipStream_t st);
+int relayout_weight_head(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st);
 // Winograd F(2x2,3x3) path (conv_wino.hip)
 bool wino_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg);
 int wino_tiles(const ConvLaunch &c);   // 2x2 output tiles per workgroup (64 or 32)

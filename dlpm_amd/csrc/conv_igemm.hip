@@ -779,6 +779,54 @@ __global__ void __launch_bounds__(256) k_conv_stem(ConvLaunch p) {
     reinterpret_cast<float4 *>(p.out + m * p.Cout)[nq] = acc;
 }
 
+// Stem with the weights held in registers: a thread owns 4 output channels (9*CIN float4 of weights + bias, loaded once)
+// and walks over pixels; the 9*CIN inputs of a pixel are the same address for all threads of that pixel (broadcast).
+// The first version re-read its 27 weight float4 per output: 0.53 ms for [1024,3,32,32] -> 128 channels, where the
+// 537-MB output write alone is 0.1 ms.
+template <int CIN>
+__global__ void __launch_bounds__(256) k_conv_stem_regw(ConvLaunch p, int ppb) {
+    const int Cq = p.Cout >> 2;                 // channel quads: a power of two <= 256
+    const int pl_n = 256 / Cq;                  // pixels in flight per block
+    const int nq = threadIdx.x & (Cq - 1), pl = threadIdx.x / Cq;
+    const int HWo = p.Hout * p.Wout;
+    const int64_t M = (int64_t)p.B * HWo;
+    float4 w[9 * CIN];
+#pragma unroll
+    for (int k = 0; k < 9 * CIN; k++) w[k] = reinterpret_cast<const float4 *>(p.w + (int64_t)k * p.Cout)[nq];
+    const float4 bias = reinterpret_cast<const float4 *>(p.bias)[nq];
+    const int64_t m_lo = (int64_t)blockIdx.x * ppb;
+    for (int it = 0; it < ppb / pl_n; it++) {
+        const int64_t m = m_lo + it * pl_n + pl;
+        if (m >= M) break;
+        const int b = (int)(m / HWo);
+        const int rem = (int)(m - (int64_t)b * HWo);
+        const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+        float v[9 * CIN];
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                const int iy = oy + ky - 1, ix = ox + kx - 1;
+                const bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+                const int cy = min(max(iy, 0), p.Hin - 1), cx = min(max(ix, 0), p.Win - 1);
+#pragma unroll
+                for (int c = 0; c < CIN; c++) {
+                    const float x = p.src0[(((int64_t)b * CIN + c) * p.Hin + cy) * p.Win + cx];
+                    v[(ky * 3 + kx) * CIN + c] = ok ? x : 0.f;
+                }
+            }
+        float4 acc = bias;
+#pragma unroll
+        for (int k = 0; k < 9 * CIN; k++) {
+            acc.x = fmaf(v[k], w[k].x, acc.x);
+            acc.y = fmaf(v[k], w[k].y, acc.y);
+            acc.z = fmaf(v[k], w[k].z, acc.z);
+            acc.w = fmaf(v[k], w[k].w, acc.w);
+        }
+        reinterpret_cast<float4 *>(p.out + m * p.Cout)[nq] = acc;
+    }
+}
+
 __global__ void k_relayout_weight(const float *oihw, float *dst, int Cout, int Cin, int ks, int for_igemm) {
     const int64_t n = (int64_t)Cout * Cin * ks * ks;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -898,7 +946,13 @@ static int launch_halo(const ConvLaunch &c, int th, int nimg, int64_t grid, hipS
 int launch_conv_stem(const ConvLaunch &c, hipStream_t st) {
     const int64_t total = (int64_t)c.B * c.Hout * c.Wout * (c.Cout / 4);
     ProfScope ps("conv_stem", 2.0 * total * 4 * c.C0 * 9, 4.0 * ((double)c.B * c.Hin * c.Win * c.C0 + total * 4.0), st);
-    if (c.C0 == 3) k_conv_stem<3><<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(c);
+    const int Cq = c.Cout / 4;
+    const bool regw = Cq >= 1 && Cq <= 256 && (Cq & (Cq - 1)) == 0;   // power-of-two channel quads
+    const int64_t Mpix = (int64_t)c.B * c.Hout * c.Wout;
+    const int ppb = 1024;                                              // pixels per block
+    if (c.C0 == 3 && regw) k_conv_stem_regw<3><<<(unsigned)ceil_div(Mpix, ppb), 256, 0, st>>>(c, ppb);
+    else if (c.C0 == 1 && regw) k_conv_stem_regw<1><<<(unsigned)ceil_div(Mpix, ppb), 256, 0, st>>>(c, ppb);
+    else if (c.C0 == 3) k_conv_stem<3><<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(c);
     else if (c.C0 == 1) k_conv_stem<1><<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(c);
     else return launch_conv_direct(c, st);
     DLPM_LAUNCH_CHECK();

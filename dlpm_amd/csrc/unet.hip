@@ -41,6 +41,7 @@ struct ConvW {            // one convolution's weights
     float *w_dev = nullptr;  // re-laid-out copy (or the original for 1x1 igemm)
     float *w_frag = nullptr; // 3x3 only: MFMA fragment order for the weight-streaming halo kernel
     float *w_wino = nullptr; // 3x3 only: Winograd-domain weights in fragment order (conv_wino.hip)
+    float *w_small = nullptr;// 3x3 with cout <= 4 (head): [tap][cin][4]
     bool owns = false;
 };
 
@@ -261,6 +262,11 @@ int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 no
     }
     DLPM_HIP(hipMalloc(&c.w_dev, (size_t)c.cout * c.cin * c.ks * c.ks * sizeof(float)));
     c.owns = true;
+    if (c.ks == 3 && c.cout <= 4 && c.cin % 32 == 0) {
+        DLPM_HIP(hipMalloc(&c.w_small, (size_t)9 * c.cin * 4 * sizeof(float)));
+        int r = relayout_weight_head(src, c.w_small, c.cout, c.cin, nullptr);
+        if (r != DLPM_OK) return r;
+    }
     if (c.use_igemm && c.ks == 3 && c.cin % 32 == 0) {
         DLPM_HIP(hipMalloc(&c.w_frag, (size_t)frag_weight_floats(c.cout, c.cin) * sizeof(float)));
         int r = relayout_weight_frag(src, c.w_frag, c.cout, c.cin, nullptr);
@@ -278,9 +284,11 @@ int run_conv(const ConvW &c, ConvLaunch L, hipStream_t st) {
     L.w = c.w_dev;
     L.w_frag = c.w_frag;
     L.w_wino = c.w_wino;
+    L.w_small = c.w_small;
     L.ws_gemm = (c.ks == 1 && c.w_frag) ? 1 : 0;
     L.ks = c.ks;
     L.Cout = c.cout;
+    if (head_conv_ok(L)) return launch_conv_head(L, st);
     return c.use_igemm ? launch_conv_igemm(L, st) : launch_conv_fallback(L, st);
 }
 
@@ -540,6 +548,8 @@ static void free_conv(ConvW &c) {
     c.w_frag = nullptr;
     if (c.w_wino) (void)hipFree(c.w_wino);
     c.w_wino = nullptr;
+    if (c.w_small) (void)hipFree(c.w_small);
+    c.w_small = nullptr;
     c.w_dev = nullptr;
     c.owns = false;
 }
@@ -739,6 +749,17 @@ extern "C" int dlpm_conv2d_f32(const dlpm_conv_args *a, float *scratch_dev, dlpm
             float *ww = scratch_dev + used;
             TRY(relayout_weight_wino(a->weight, ww, a->Cout, a->C0 + a->C1, st));
             L.w_wino = ww;
+        }
+    }
+    if (!a->force_direct && a->ksize == 3 && a->Cout <= 4 && a->C0 % 32 == 0 && a->C1 == 0) {
+        // [tap][cin][4] copy at the END of the scratch buffer (the front holds the layouts built above)
+        const int64_t front = (int64_t)a->Cout * a->C0 * 9 + frag_weight_floats(a->Cout, a->C0);
+        const int64_t wsz = (int64_t)9 * a->C0 * 4;
+        if (a->scratch_floats >= front + wsz) {
+            float *ws = scratch_dev + (a->scratch_floats - wsz);
+            TRY(relayout_weight_head(a->weight, ws, a->Cout, a->C0, st));
+            L.w_small = ws;
+            if (head_conv_ok(L)) return launch_conv_head(L, st);
         }
     }
     if (ig) return launch_conv_igemm(L, st);

@@ -172,6 +172,24 @@ def test_conv_boundary_layouts():
     assert (got - ref_conv(x, w, b)).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize('B,C,H,Cout,nchw', [(3, 64, 16, 3, True), (2, 32, 32, 3, True), (2, 128, 32, 1, True), (1, 32, 64, 4, False)])
+def test_head_conv_kernel(B, C, H, Cout, nchw):
+    """The dedicated head kernel (Cout <= 4, fused GN affine + SiLU, NCHW out) against the fp64 reference and against
+    the MFMA path it replaces (force_direct bit 1 keeps the launch on the old path)."""
+    g = torch.Generator().manual_seed(B * 100 + C + H)
+    h = torch.randn(B, C, H, H, generator=g)
+    w = torch.randn(Cout, C, 3, 3, generator=g) / math.sqrt(9 * C)
+    b = torch.randn(Cout, generator=g)
+    coef = (1 + 0.3 * torch.randn(B, C, generator=g), 0.3 * torch.randn(B, C, generator=g))
+    want = ref_conv(h, w, b, coef=coef, silu=True)
+    got = run_conv(h, w, b, coef=coef, silu=True, out_nchw=nchw)
+    old = run_conv(h, w, b, coef=coef, silu=True, out_nchw=nchw, force_direct=2)
+    assert (got - want).abs().max().item() < conv_tol(w, C)
+    assert (old - want).abs().max().item() < conv_tol(w, C)
+    got2 = run_conv(h, w, b, out_nchw=nchw)                     # no activation
+    assert (got2 - ref_conv(h, w, b)).abs().max().item() < conv_tol(w, C)
+
+
 def test_linear_as_conv():
     g = torch.Generator().manual_seed(5)
     x = torch.randn(37, 128, generator=g)
