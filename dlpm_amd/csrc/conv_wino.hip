@@ -741,13 +741,20 @@ constexpr int QRING = 8;      // weight prefetch ring of the 8-wave kernel (grou
 // is added to MFMA time on this chip -- at the price of streaming every weight fragment for one MFMA tile only.
 // NW = waves per workgroup: 8 (one workgroup per CU, 256-KB accumulator block) or 4 (MT = 32 only: 32 tiles x 64
 // channels, 128-KB block, TWO workgroups per CU, so that one's prologue / epilogue / barriers overlap the other's MFMAs).
-template <bool UPS, int MT, int NW = 8, int ABL = 0>   // ABL (DLPM_WINO_ABLATIONS builds): 1 no S, 2 no X, 4 no raw loads, 8 no barrier, 16 no weight loads, 32 no MFMA
+// KC = input channels per phase: 8, or 16 (MT = 32, NW = 8 only: the smaller V / raw tiles leave room for it): half as many
+// barriers and phase start-ups per MFMA.
+template <bool UPS, int MT, int NW = 8, int ABL = 0, int KC = 8>   // ABL (DLPM_WINO_ABLATIONS builds): 1 no S, 2 no X, 4 no raw loads, 8 no barrier, 16 no weight loads, 32 no MFMA
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(ConvLaunch p, int bh, int bw, int nimg) {
     static_assert(NW == 8 || (NW == 4 && MT == 32), "wave layout");
+    static_assert(KC == 8 || (KC == 16 && MT == 32 && NW == 8), "chunk");
     constexpr int NT = NW * 64;                      // threads
     constexpr int NQ = NW == 8 ? 4096 / MT : 64;     // output channels per workgroup
     constexpr int RAWPIX = MT == 64 ? RAW_MAXPIX : RAW_MAXPIX / 2;
-    constexpr int QNIT = (RAWPIX * 2 + NT - 1) / NT; // staging items per thread
+    constexpr int NQD = KC / 4;                      // channel quads per pixel and chunk
+    constexpr int QNIT = (RAWPIX * NQD + NT - 1) / NT; // staging items per thread
+    constexpr int PVLD = KC + 4, PRLD = KC + 4;      // padded V / raw rows (shadow the 8-channel constants)
+    constexpr int CFS = 16 * 2 * KC;                 // floats per coefficient slot: [16 images][2][KC]
+    constexpr int NJQ = KC / 8;                      // float4 fragments per position and lane
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float *V = wsm;                                  // [2][16][MT][PVLD]
     float *raw = wsm + 2 * 16 * MT * PVLD;           // [2][RAWPIX][PRLD]
@@ -759,7 +766,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
     const int wn = MT == 64 ? (wave & 1) : (NW == 8 ? (wave & 3) : (wave & 1)), wm = MT == 64 ? ((wave >> 1) & 1) : 0;
     const int W = p.Wout, H = p.Hout, TW = W >> 1, TH = H >> 1;
     const int Ws = UPS ? (W >> 1) : W, Hs = UPS ? (H >> 1) : H;
-    const int Cin = p.C0 + p.C1, nch = Cin / PKC;
+    const int Cin = p.C0 + p.C1, nch = Cin / KC;
     // n-tile-major grid: all workgroups in flight stream the SAME half of the Winograd-domain weights (2.1 MB for a
     // 256 x 256 layer: fits the 4-MB L2 of an XCD; both halves together do not)
     const int ntn = p.Cout / NQ;
@@ -780,26 +787,26 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
     const int oy = UPS ? ty0 - 1 : 2 * ty0 - 1, ox = UPS ? tx0 - 1 : 2 * tx0 - 1;
     const int rpi = RH * RW, npix = nimg * rpi;
 
-    // ---- raw staging: item = (pixel, channel quad of the 8-channel chunk)
-    const int squad = tid & 1;
+    // ---- raw staging: item = (pixel, channel quad of the chunk)
+    const int squad = tid & (NQD - 1);
     int off[QNIT], cfo[QNIT];
 #pragma unroll
     for (int it = 0; it < QNIT; it++) {
-        const int pix = it * (NT / 2) + (tid >> 1);
+        const int pix = it * (NT / NQD) + (tid / NQD);
         const int img = min(pix / rpi, nimg - 1), r = pix - img * rpi;
         const int ry = r / RW, rx = r - ry * RW;
         const int iy = oy + ry, ix = ox + rx;
         const bool pad = iy < 0 || iy >= Hs || ix < 0 || ix >= Ws || (img0 + img) >= p.B;
         off[it] = pix >= npix ? -2 : (pad ? -1 : (((img0 + img) * Hs + iy) * Ws + ix));
-        cfo[it] = img * 16 + squad * 4;
+        cfo[it] = img * 2 * KC + squad * 4;
     }
     const bool has_coef = p.coefA != nullptr;
-    const int cf_img = tid >> 2, cf_isb = (tid >> 1) & 1;
-    const bool cf_mine = has_coef && tid < nimg * 4;
+    const int cf_img = tid / (2 * NQD), cf_isb = (tid / NQD) & 1;
+    const bool cf_mine = has_coef && tid < nimg * 2 * NQD;
     const float *cf_base = has_coef ? ((cf_isb ? p.coefB : p.coefA) + (int64_t)min(img0 + cf_img, p.B - 1) * Cin + squad * 4) : nullptr;
     float4 xr[QNIT], cfr = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_raw = [&](int chunk) {
-        const int c = chunk * PKC + squad * 4;
+        const int c = chunk * KC + squad * 4;
         const bool first = c < p.C0;
         const float *sb = first ? p.src0 + c : p.src1 + (c - p.C0);
         const int ld = first ? p.C0 : p.C1;
@@ -807,10 +814,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
         for (int it = 0; it < QNIT; it++) xr[it] = *reinterpret_cast<const float4 *>(sb + (int64_t)max(off[it], 0) * ld);
     };
     auto load_coef = [&](int chunk) {
-        if (cf_mine) cfr = *reinterpret_cast<const float4 *>(cf_base + chunk * PKC);
+        if (cf_mine) cfr = *reinterpret_cast<const float4 *>(cf_base + chunk * KC);
     };
     auto store_coef = [&](int slot) {
-        if (cf_mine) *reinterpret_cast<float4 *>(Cf + slot * 256 + cf_img * 16 + cf_isb * 8 + squad * 4) = cfr;
+        if (cf_mine) *reinterpret_cast<float4 *>(Cf + slot * CFS + cf_img * 2 * KC + cf_isb * KC + squad * 4) = cfr;
     };
     auto store_raw = [&](int slot) {
         float *rb = raw + slot * RAWPIX * PRLD;
@@ -819,8 +826,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
             if (off[it] == -2) continue;
             float4 x = xr[it];
             if (has_coef) {
-                const float4 ca = *reinterpret_cast<const float4 *>(Cf + slot * 256 + cfo[it]);
-                const float4 cb = *reinterpret_cast<const float4 *>(Cf + slot * 256 + cfo[it] + 8);
+                const float4 ca = *reinterpret_cast<const float4 *>(Cf + slot * CFS + cfo[it]);
+                const float4 cb = *reinterpret_cast<const float4 *>(Cf + slot * CFS + cfo[it] + KC);
                 x.x = fmaf(x.x, ca.x, cb.x);
                 x.y = fmaf(x.y, ca.y, cb.y);
                 x.z = fmaf(x.z, ca.z, cb.z);
@@ -833,20 +840,20 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
                 x.w = silu_f(x.w);
             }
             if (off[it] < 0) x = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding applies AFTER the activation
-            *reinterpret_cast<float4 *>(rb + (it * (NT / 2) + (tid >> 1)) * PRLD + squad * 4) = x;
+            *reinterpret_cast<float4 *>(rb + (it * (NT / NQD) + (tid / NQD)) * PRLD + squad * 4) = x;
         }
     };
 
     // ---- input transform: thread = (tile, quad) over lanes x one row r of V (wave-uniform): V[r][.] = (B^T d)[r] B
     //   row 0: d0 - d2   row 1: d1 + d2   row 2: d2 - d1   row 3: d1 - d3
     const int trow = wave & 3;
-    const bool xform_mine = MT == 64 || wave < 4;     // 32 tiles x 2 quads x 4 rows = 256 items: waves 0..3
+    const bool xform_mine = MT * NQD * 4 >= NT || wave < 4;   // MT tiles x NQD quads x 4 rows items (256: waves 0..3 only)
     const int rA = trow == 0 ? 0 : trow == 2 ? 2 : 1, rB = trow == 0 ? 2 : trow == 1 ? 2 : trow == 2 ? 1 : 3;
     const float tsg = trow == 1 ? 1.f : -1.f;
     int roA, roB, coloff[4], vofs;
     {
-        const int pair = MT == 64 ? (wave >> 2) * 64 + lane : lane;
-        const int tile = pair >> 1, tquad = pair & 1;
+        const int pair = MT * NQD > 64 ? (wave >> 2) * 64 + lane : lane;
+        const int tile = pair / NQD, tquad = pair & (NQD - 1);
         const int timg = tile / (bh * bw), r = tile - timg * (bh * bw);
         const int ty = r / bw, tx = r - ty * bw;
 #pragma unroll
@@ -875,10 +882,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
 
     // ---- weight stream of this wave: Wf[nb][ph][chunk][8 positions][lane][4]
     const float4 *__restrict__ wbase = reinterpret_cast<const float4 *>(p.w_wino) + lane;
-    int64_t woff = (int64_t)(((n0 >> 5) + wn) * 2 + ph) * nch * 8 * 64;
+    int64_t woff = (int64_t)(((n0 >> 5) + wn) * 2 + ph) * nch * 8 * NJQ * 64;
     constexpr int AHEAD = QRING - 1;
     float4 bq[QRING];
-    const float *asrc = V + (ph * 8) * MT * PVLD + (wm * 32 + l31) * PVLD + kh * 4;
+    const float *asrc = V + (ph * 8) * MT * PVLD + (wm * 32 + l31) * PVLD + kh * (KC / 2);
 
     floatx16 acc[8];
 #pragma unroll
@@ -892,7 +899,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
     float4 xr1[QNIT], cfr1 = make_float4(0.f, 0.f, 0.f, 0.f), cfr2 = cfr1;
     load_raw(0);
     {
-        const int c = min(1, last) * PKC + squad * 4;
+        const int c = min(1, last) * KC + squad * 4;
         const bool first = c < p.C0;
         const float *sb = first ? p.src0 + c : p.src1 + (c - p.C0);
         const int ld = first ? p.C0 : p.C1;
@@ -901,8 +908,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
     }
     load_coef(0);
     if (cf_mine) {
-        cfr1 = *reinterpret_cast<const float4 *>(cf_base + min(1, last) * PKC);
-        cfr2 = *reinterpret_cast<const float4 *>(cf_base + min(2, last) * PKC);
+        cfr1 = *reinterpret_cast<const float4 *>(cf_base + min(1, last) * KC);
+        cfr2 = *reinterpret_cast<const float4 *>(cf_base + min(2, last) * KC);
     }
 #pragma unroll
     for (int a = 0; a < AHEAD; a++) bq[a] = wbase[woff + a * 64];
@@ -931,16 +938,17 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
         // second wave does hide is latency: LDS, global loads, barriers.  Running the two waves of a SIMD in opposite
         // order measured 4 % slower.)
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            if (q == 4) {
+        for (int g = 0; g < 8 * NJQ; g++) {
+            const int q = g / NJQ, jq = g % NJQ;
+            if (g == 4 * NJQ) {
                 if (!(ABL & 1)) store_raw(cur);                         // S(chunk+2): raw[cur] was read by X(chunk), a barrier ago
                 if (!(ABL & 4)) load_raw(min(chunk + 3, last));         // G(chunk+3)
                 if (!(ABL & 2)) transform(nxt);                         // X(chunk+1): raw[nxt] -> V[nxt]
             }
-            if (!(ABL & 16)) bq[(q + AHEAD) % QRING] = wbase[woff + AHEAD * 64];
+            if (!(ABL & 16)) bq[(g + AHEAD) % QRING] = wbase[woff + AHEAD * 64];
             woff += 64;
-            const float4 af = *reinterpret_cast<const float4 *>(ab + q * MT * PVLD);
-            const float4 b = bq[q % QRING];
+            const float4 af = *reinterpret_cast<const float4 *>(ab + q * MT * PVLD + jq * 4);
+            const float4 b = bq[g % QRING];
             if (!(ABL & 32)) {
                 acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, b.x, acc[q], 0, 0, 0);
                 acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, b.y, acc[q], 0, 0, 0);
@@ -1067,21 +1075,24 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
 
 // OIHW (3x3) -> U = G g G^T in k_conv3x3_wino_q's fragment order  Wf[nb][ph][chunk8][pos8][lane][4]:
 // lane = h*32 + n holds U_pos[cin = chunk*8 + h*4 + e][cout = nb*32 + n], pos = ph*8 + pos8.
-__global__ void k_relayout_weight_wino_q(const float *oihw, float *dst, int Cout, int Cin) {
-    const int nbk = Cout / 32, nch = Cin / PKC;
-    const int64_t total = (int64_t)nbk * 2 * nch * 8 * 64 * 4;
+__global__ void k_relayout_weight_wino_q(const float *oihw, float *dst, int Cout, int Cin, int kc) {
+    // kc = 8: Wf[nb][ph][chunk][pos8][lane][4], cin = chunk*8 + h*4 + e
+    // kc = 16: Wf[nb][ph][chunk][pos8][jq][lane][4], cin = chunk*16 + h*8 + jq*4 + e
+    const int nbk = Cout / 32, nch = Cin / kc, njq = kc / 8;
+    const int64_t total = (int64_t)nbk * 2 * nch * 8 * njq * 64 * 4;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int e = (int)(i & 3);
     const int lane = (int)((i >> 2) & 63);
     int64_t r = i >> 8;
+    const int jq = (int)(r % njq); r /= njq;
     const int pos8 = (int)(r & 7); r >>= 3;
     const int chunk = (int)(r % nch); r /= nch;
     const int ph = (int)(r & 1);
     const int nb = (int)(r >> 1);
     const int pos = ph * 8 + pos8;
     const int h = lane >> 5, nn = lane & 31;
-    const int cin = chunk * PKC + h * 4 + e, cout = nb * 32 + nn;
+    const int cin = chunk * kc + h * (kc / 2) + jq * 4 + e, cout = nb * 32 + nn;
     const float *g = oihw + ((int64_t)cout * Cin + cin) * 9;
     const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
     const int a = pos >> 2, b = pos & 3;
@@ -1165,6 +1176,18 @@ static bool wino_disabled() {
 }
 
 int wino_waves(const ConvLaunch &c);
+// input channels per phase of the 8-wave kernel for a layer with Cout output channels: 8; DLPM_WINO_KC=16 selects 16 for
+// the 32-tile x 128-channel shape (half the barriers per MFMA -- measured 2 % SLOWER: 61.3 vs 60.1 ms/step).  It fixes the
+// Winograd-domain weight layout, so it depends on Cout only
+static int wino_kc_for(int Cout) {
+    static int pref = -1, nw = -1, mtp = -1;
+    if (pref < 0) {
+        const char *e = getenv("DLPM_WINO_KC"); pref = e ? atoi(e) : 8;
+        const char *f = getenv("DLPM_WINO_NW"); nw = f ? atoi(f) : 8;
+        const char *g = getenv("DLPM_WINO_MT"); mtp = g ? atoi(g) : 32;
+    }
+    return (pref == 16 && nw != 4 && mtp == 32 && Cout % 128 == 0) ? 16 : 8;
+}
 // tiles per workgroup: 32 (x 128 output channels) for the 8-wave kernel when Cout allows it, else 64 (x 64 channels)
 int wino_tiles(const ConvLaunch &c) {
     static int pref = -1;
@@ -1267,11 +1290,13 @@ int launch_conv_wino(const ConvLaunch &c, hipStream_t st) {
     if (wino_variant() == 2) {
         const int mt = wino_tiles(c);
         const int nw = wino_waves(c);
+        const int kc = wino_kc_for(c.Cout);
         if (mt == 32 && nw == 4) fn = c.ups ? &k_conv3x3_wino_q<true, 32, 4> : &k_conv3x3_wino_q<false, 32, 4>;
+        else if (mt == 32 && kc == 16) fn = c.ups ? &k_conv3x3_wino_q<true, 32, 8, 0, 16> : &k_conv3x3_wino_q<false, 32, 8, 0, 16>;
         else if (mt == 32) fn = c.ups ? &k_conv3x3_wino_q<true, 32> : &k_conv3x3_wino_q<false, 32>;
         else fn = c.ups ? &k_conv3x3_wino_q<true, 64> : &k_conv3x3_wino_q<false, 64>;
 #ifdef DLPM_WINO_ABLATIONS
-        if (!c.ups && mt == 32 && nw == 8) {
+        if (!c.ups && mt == 32 && nw == 8 && kc == 8) {
             switch (abl) {
                 case 1: fn = &k_conv3x3_wino_q<false, 32, 8, 1>; break;
                 case 2: fn = &k_conv3x3_wino_q<false, 32, 8, 2>; break;
@@ -1292,7 +1317,7 @@ int launch_conv_wino(const ConvLaunch &c, hipStream_t st) {
                 if (!q) { q = reinterpret_cast<const void *>(fn); break; }
         }
         const int nq = nw == 8 ? 4096 / mt : 64;
-        size_t shmem_q = (size_t)(2 * 16 * mt * PVLD + 2 * (mt == 64 ? RAW_MAXPIX : RAW_MAXPIX / 2) * PRLD + 512) * sizeof(float);
+        size_t shmem_q = (size_t)(2 * 16 * mt * (kc + 4) + 2 * (mt == 64 ? RAW_MAXPIX : RAW_MAXPIX / 2) * (kc + 4) + 2 * 16 * 2 * kc) * sizeof(float);
         const size_t epi_q = (size_t)((nw / 2) * 4 * 16 * 64 + 4 * mt * (nq + 4)) * sizeof(float);   // exchange + row image
         if (shmem_q < epi_q) shmem_q = epi_q;
         const int64_t tiles_q = (int64_t)c.B * (c.Hout / 2) * (c.Wout / 2);
@@ -1314,7 +1339,7 @@ int64_t wino_weight_floats(int Cout, int Cin) {
 int relayout_weight_wino(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st) {
     const int64_t n = (int64_t)(Cout / 32) * (Cin / WKC) * WGRP * 256;
     DLPM_HIP(hipMemsetAsync(dst_dev + n, 0, (size_t)8 * 256 * sizeof(float), st));
-    if (wino_variant() == 2) k_relayout_weight_wino_q<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
+    if (wino_variant() == 2) k_relayout_weight_wino_q<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin, wino_kc_for(Cout));
     else if (wino_pipelined()) k_relayout_weight_wino_p<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
     else k_relayout_weight_wino<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
     DLPM_LAUNCH_CHECK();
