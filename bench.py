@@ -182,7 +182,7 @@ def main():
     total_s = init_s + nsteps * ms_per_step / 1e3 + gather_s
     value = B * world / total_s
 
-    roofline, upd, breakdown = None, None, None
+    roofline, upd, breakdown, att = None, None, None, None
     if not args.no_prof and rank == 0:
         # instrumented eager pass on the same stream: HIP events around every launch, by kernel class
         _lib.check(L.dlpm_prof_enable(1))
@@ -224,6 +224,13 @@ def main():
                 roofline['mfma_utilisation'] = round(ach * 16.0 / 36.0 / PEAK_FP32_MFMA_TFLOPS, 4)
                 roofline['note'] = ('achieved = algorithmic (direct-convolution) FLOP/s; F(2x2,3x3) executes 16/36 of them, '
                                     'mfma_utilisation = executed MFMA FLOP/s over the fp32 MFMA peak')
+        at = prof.get('attention')
+        if at and at['ms'] > 0:
+            tf = at['flops'] / (at['ms'] * 1e-3) / 1e12
+            att = dict(kernel='k_attention<64,NT> (QK^T / softmax / AV on the fp32 MFMA 16x16x4, one workgroup per head)', bound='mfma',
+                       achieved=round(tf, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s', frac=round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                       launches_per_step=at['launches'] // nprof, avg_launch_ms=round(at['ms'] / at['launches'], 5),
+                       note='T <= 256 tokens per head: latency-bound (0.2 % of the step FLOPs)')
         u = prof.get('update')
         if u:
             gbs = u['bytes'] / (u['ms'] * 1e-3) / 1e9
@@ -252,7 +259,7 @@ def main():
             'whole_step_tflops': round(step_tflops, 3),
             'whole_step_frac_of_fp32_peak': round(step_tflops / (PEAK_FP32_MFMA_TFLOPS * world), 4),
             'samples_finite': finite,
-            'roofline': roofline, 'update_kernel': upd, 'ms_per_step_by_kernel_class': breakdown, 'cpu_baseline': cpu,
+            'roofline': roofline, 'update_kernel': upd, 'attention_kernel': att, 'ms_per_step_by_kernel_class': breakdown, 'cpu_baseline': cpu,
         }
         print(json.dumps(out))
     if world > 1:
