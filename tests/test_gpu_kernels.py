@@ -353,6 +353,54 @@ def test_update_against_reference_single_step():
         np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-6, atol=2e-6)
 
 
+@pytest.mark.parametrize('shape', [(3, 2, 4, 4), (2, 1, 1, 3)])       # D % 4 == 0 (vector path) and D = 3 (scalar path)
+def test_update_elementwise_tables_all_variants(shape):
+    """DLPM_UPD_ELEMENTWISE (non-isotropic noise): per-element [T,B,D] tables through the update kernel, every variant
+    (stochastic, clip, DLIM eta = 0, DLIM eta > 0 with noise, history row) against the oracle's formulas."""
+    T, alpha = 12, 1.7
+    g_, bg_, s_, bs_ = P.schedule(T, alpha)
+    gen = torch.Generator().manual_seed(sum(shape))
+    B, D = shape[0], int(np.prod(shape[1:]))
+    A = torch.rand((T,) + shape, generator=gen) * 3 + 0.2
+    x, eps, z = (torch.randn(shape, generator=gen) for _ in range(3))
+    Sig = P.sigma_table(A, g_, s_)
+    Ad = A.reshape(T, B * D).to(DEV).contiguous()
+    g, bg, s, bs = (v.to(DEV) for v in (g_, bg_, s_, bs_))
+    ce, cn = torch.empty_like(Ad), torch.empty_like(Ad)
+    _lib.check(L().dlpm_coeff_tables_f32(Ad.data_ptr(), g.data_ptr(), s.data_ptr(), bs.data_ptr(), T, B * D, ce.data_ptr(),
+                                        cn.data_ptr(), None, st()))
+
+    def run(t, flags, eta=0.0, hist=None):
+        a = _lib.UpdateArgs()
+        xd, ed, zd = x.to(DEV).contiguous(), eps.to(DEV).contiguous(), z.to(DEV).contiguous()
+        td = torch.tensor([t], dtype=torch.int32, device=DEV)
+        a.x_dev, a.eps_dev, a.z_dev, a.t_dev = xd.data_ptr(), ed.data_ptr(), zd.data_ptr(), td.data_ptr()
+        a.g_dev, a.bg_dev, a.bs_dev = g.data_ptr(), bg.data_ptr(), bs.data_ptr()
+        a.c_eps_dev, a.c_noise_dev, a.A_dev = ce.data_ptr(), cn.data_ptr(), Ad.data_ptr()
+        a.B, a.D, a.T, a.flags, a.dlim_eta, a.alpha = B, D, T, flags | _lib.UPD_ELEMENTWISE, eta, alpha
+        cell = None
+        if hist is not None:
+            cell = torch.tensor([hist.data_ptr()], dtype=torch.int64, device=DEV)
+            a.hist_pp = cell.data_ptr()
+        _lib.check(L().dlpm_update_f32(C.byref(a), st()))
+        torch.cuda.synchronize()
+        return xd.cpu()
+
+    for t in (1, 2, 7, 11):
+        want, _, _ = P.dlpm_step(x, eps, t, Sig, g_, bs_, z)
+        np.testing.assert_allclose(run(t, 0).numpy(), want.numpy(), rtol=2e-6, atol=2e-6)
+        e2 = P.clipped_eps(x, eps, t, bg_, bs_)
+        want, _, _ = P.dlpm_step(x, e2, t, Sig, g_, bs_, z)
+        np.testing.assert_allclose(run(t, _lib.UPD_CLIP).numpy(), want.numpy(), rtol=3e-6, atol=3e-6)
+        want = P.dlim_step(x, eps, t, g_, bs_, eta=0.0)
+        np.testing.assert_allclose(run(t, _lib.UPD_DLIM).numpy(), want.numpy(), rtol=2e-6, atol=2e-6)
+        want = P.dlim_step(x, eps, t, g_, bs_, eta=0.5, alpha=alpha, A=A, z=z)
+        np.testing.assert_allclose(run(t, _lib.UPD_DLIM, eta=0.5).numpy(), want.numpy(), rtol=5e-6, atol=5e-6)
+    hist = torch.zeros((T,) + shape, device=DEV)
+    got = run(5, 0, hist=hist)
+    assert torch.equal(hist[T - 5].cpu(), got) and float(hist.abs().sum()) == float(got.abs().sum())
+
+
 def test_update_scalar_path_toy_shape():
     """D = 2 (toy data) takes the non-vectorised path."""
     f = golden('f5_traj_synth_toy')
