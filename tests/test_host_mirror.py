@@ -191,6 +191,29 @@ def test_exploding_schedule_mirror_exact_native_close(T, alpha):
     assert dlpm_amd.GenerativeLevyProcess(alpha, 'cpu', T, input_scaling=True)._input_scale() is None
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/dlpm_amd.h is the drop-in boundary: it must be consumable by a C compiler (C99, no C++-isms) and by a
+    C++ one, and a C program must link against the library with it."""
+    import subprocess
+    src = tmp_path / 'use.c'
+    src.write_text('#include "dlpm_amd.h"\n#include <stdio.h>\n'
+                   'int main(void) { dlpm_update_args a; dlpm_sampler_config c; (void)a; (void)c;\n'
+                   '  float g[8], bg[8], s[8], bs[8];\n'
+                   '  if (dlpm_schedule_f32(8, 1.7, g, bg, s, bs) != DLPM_OK) return 2;\n'
+                   '  printf("%d %.6f\\n", dlpm_abi_version(), bg[7]); return 0; }\n')
+    inc = os.path.join(ROOT, 'include')
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-fsyntax-only', '-I', inc, str(src)])
+    subprocess.check_call(['g++', '-std=c++17', '-Wall', '-fsyntax-only', '-x', 'c++', '-I', inc, str(src)])
+    exe = tmp_path / 'use'
+    libdir = os.path.join(ROOT, 'dlpm_amd', 'lib')
+    subprocess.check_call(['gcc', '-std=c99', '-I', inc, str(src), '-o', str(exe), '-L', libdir, '-ldlpm_amd',
+                           '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib'])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert int(out[0]) == _lib.ABI_VERSION
+    d = dlpm_amd.DLPM(1.7, 'cpu', 8)
+    assert abs(float(out[1]) - float(d.host_schedule[1][7])) < 1e-6
+
+
 def test_product_never_imports_oracle():
     import subprocess, sys
     code = ("import sys; import dlpm_amd; "
