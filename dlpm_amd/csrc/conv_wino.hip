@@ -819,11 +819,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
     auto store_coef = [&](int slot) {
         if (cf_mine) *reinterpret_cast<float4 *>(Cf + slot * CFS + cf_img * 2 * KC + cf_isb * KC + squad * 4) = cfr;
     };
-    auto store_raw = [&](int slot) {
+    auto store_raw_item = [&](int slot, int it) {
         float *rb = raw + slot * RAWPIX * PRLD;
-#pragma unroll
-        for (int it = 0; it < QNIT; it++) {
-            if (off[it] == -2) continue;
+        {
+            if (off[it] == -2) return;
             float4 x = xr[it];
             if (has_coef) {
                 const float4 ca = *reinterpret_cast<const float4 *>(Cf + slot * CFS + cfo[it]);
@@ -842,6 +841,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
             if (off[it] < 0) x = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding applies AFTER the activation
             *reinterpret_cast<float4 *>(rb + (it * (NT / NQD) + (tid / NQD)) * PRLD + squad * 4) = x;
         }
+    };
+    auto store_raw = [&](int slot) {
+#pragma unroll
+        for (int it = 0; it < QNIT; it++) store_raw_item(slot, it);
     };
 
     // ---- input transform: thread = (tile, quad) over lanes x one row r of V (wave-uniform): V[r][.] = (B^T d)[r] B
@@ -940,11 +943,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
 #pragma unroll
         for (int g = 0; g < 8 * NJQ; g++) {
             const int q = g / NJQ, jq = g % NJQ;
-            if (g == 4 * NJQ) {
-                if (!(ABL & 1)) store_raw(cur);                         // S(chunk+2): raw[cur] was read by X(chunk), a barrier ago
-                if (!(ABL & 4)) load_raw(min(chunk + 3, last));         // G(chunk+3)
-                if (!(ABL & 2)) transform(nxt);                         // X(chunk+1): raw[nxt] -> V[nxt]
-            }
+            // the side work is spread over the phase (one piece behind each of the first positions): bunched in the
+            // middle of the phase it measured 2.5 % slower (both waves of a SIMD reach it together and the matrix pipe idles)
+            if (!(ABL & 1) && g % NJQ == 0 && g / NJQ >= 1 && g / NJQ <= QNIT)
+                store_raw_item(cur, g / NJQ - 1);                       // S(chunk+2): raw[cur] was read by X(chunk), a barrier ago
+            if (g == (QNIT + 1) * NJQ && !(ABL & 4)) load_raw(min(chunk + 3, last));   // G(chunk+3)
+            if (g == 4 * NJQ && !(ABL & 2)) transform(nxt);             // X(chunk+1): raw[nxt] -> V[nxt]
             if (!(ABL & 16)) bq[(g + AHEAD) % QRING] = wbase[woff + AHEAD * 64];
             woff += 64;
             const float4 af = *reinterpret_cast<const float4 *>(ab + q * MT * PVLD + jq * 4);
