@@ -945,10 +945,18 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
             const int q = g / NJQ, jq = g % NJQ;
             // the side work is spread over the phase (one piece behind each of the first positions): bunched in the
             // middle of the phase it measured 2.5 % slower (both waves of a SIMD reach it together and the matrix pipe idles)
-            if (!(ABL & 1) && g % NJQ == 0 && g / NJQ >= 1 && g / NJQ <= QNIT)
-                store_raw_item(cur, g / NJQ - 1);                       // S(chunk+2): raw[cur] was read by X(chunk), a barrier ago
-            if (g == (QNIT + 1) * NJQ && !(ABL & 4)) load_raw(min(chunk + 3, last));   // G(chunk+3)
-            if (g == 4 * NJQ && !(ABL & 2)) transform(nxt);             // X(chunk+1): raw[nxt] -> V[nxt]
+            // placement sweep (DLPM_BUILD_DEFS="WQ_S0=.. WQ_X=.."): staging from an odd position on is 3-6 % faster than
+            // from an even one (the compiler pairs the MFMAs of positions 2k, 2k+1); X position does not matter
+#ifndef WQ_S0
+#define WQ_S0 3
+#endif
+#ifndef WQ_X
+#define WQ_X 6
+#endif
+            if (!(ABL & 1) && g % NJQ == 0 && g / NJQ >= WQ_S0 && g / NJQ < WQ_S0 + QNIT)
+                store_raw_item(cur, g / NJQ - WQ_S0);                   // S(chunk+2): raw[cur] was read by X(chunk), a barrier ago
+            if (g == (WQ_S0 + QNIT) * NJQ && !(ABL & 4)) load_raw(min(chunk + 3, last));   // G(chunk+3)
+            if (g == WQ_X * NJQ && !(ABL & 2)) transform(nxt);          // X(chunk+1): raw[nxt] -> V[nxt]
             if (!(ABL & 16)) bq[(g + AHEAD) % QRING] = wbase[woff + AHEAD * 64];
             woff += 64;
             const float4 af = *reinterpret_cast<const float4 *>(ab + q * MT * PVLD + jq * 4);
