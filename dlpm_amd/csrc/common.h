@@ -48,4 +48,23 @@ struct ProfScope {
     ~ProfScope();
 };
 
+
+// Developer instrumentation, compiled in only with -DDLPM_PHASE_TIMING (DLPM_BUILD_DEFS): kernels that carry a
+// ConvLaunch add clock64() deltas of their phases (thread 0 of every workgroup) into this device buffer.
+#ifdef DLPM_PHASE_TIMING
+unsigned long long *phase_buffer();   // 32 counters, zero-initialised device memory (allocated on first use)
+#define DLPM_PHASE_DECL long long _pt = clock64()
+#define DLPM_PHASE(p, i)                                                                              \
+    do {                                                                                              \
+        if ((p).phase && threadIdx.x == 0) {                                                          \
+            const long long _n = clock64();                                                           \
+            atomicAdd((p).phase + (i), (unsigned long long)(_n - _pt));                               \
+            _pt = _n;                                                                                 \
+        }                                                                                             \
+    } while (0)
+#else
+#define DLPM_PHASE_DECL
+#define DLPM_PHASE(p, i)
+#endif
+
 }  // namespace dlpm

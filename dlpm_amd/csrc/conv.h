@@ -31,6 +31,9 @@ struct ConvLaunch {
     // epilogue when the tile lies inside one image.  [B][HW/tile][Cout] float2 with tile =
     // conv_stats_pixels(launch): 128 for the implicit-GEMM kernels, 256 for the Winograd kernel.
     float2 *stats_out = nullptr;
+#ifdef DLPM_PHASE_TIMING
+    unsigned long long *phase = nullptr;
+#endif
 };
 
 // true when the MFMA implicit-GEMM kernel covers this shape

@@ -113,7 +113,93 @@ __device__ __forceinline__ void epilogue_rows(const ConvLaunch &p, floatx16 (&ac
     }
 }
 
+// Full-tile form of epilogue_rows (M % 128 == 0, Cout % BN == 0: no bounds tests).  The co-resident workgroup's MFMAs
+// share this SIMD's issue port, so every VALU instruction here is paid for in matrix-pipe time (phase counters: the
+// generic epilogue took 30 % of a 1x1 workgroup's life): thread -> (channel quad, row group) is fixed, rows advance by
+// pointer increments, bias is loaded once and the residual rows of a phase are fetched before its barrier.
 template <int BN, int WAVES_M, int WAVES_N, int RM, int RN>
+__device__ __forceinline__ void epilogue_rows_full(const ConvLaunch &p, floatx16 (&acc)[RM][RN], float *lds, int64_t m0, int n0,
+                                                   int tid, int wm, int wn, int l31, int kh) {
+    constexpr int LD = BN + 4, PR = RM * 32, C4 = BN / 4, RG = 256 / C4, NP = PR / RG;
+    static_assert(PR % RG == 0, "row groups must tile a phase");
+    const int c4 = tid % C4, rg = tid / C4;
+    const int n = n0 + c4 * 4;
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bias = *reinterpret_cast<const float4 *>(p.bias + n);
+    const bool has_res = p.res0 != nullptr;
+    const int R1 = p.Cout - p.R0;
+    const int rs = (n < p.R0) ? p.R0 : R1;                       // residual row stride of this thread's source
+    const float *rp = has_res ? ((n < p.R0) ? p.res0 + (m0 + rg) * p.R0 + n : p.res1 + (m0 + rg) * R1 + (n - p.R0)) : p.out;
+    float *op = p.out + (m0 + rg) * p.Cout + n;
+    const float *lp = lds + rg * LD + c4 * 4;
+    const bool do_stats = p.stats_out != nullptr;
+    float4 K = make_float4(0.f, 0.f, 0.f, 0.f), s1 = K, s2 = K;
+#pragma unroll
+    for (int ph = 0; ph < WAVES_M; ph++) {
+        float4 q[NP];
+        if (has_res) {
+#pragma unroll
+            for (int k = 0; k < NP; k++) q[k] = *reinterpret_cast<const float4 *>(rp + (int64_t)(ph * PR + k * RG) * rs);
+        }
+        if (wm == ph) {
+#pragma unroll
+            for (int i = 0; i < RM; i++)
+#pragma unroll
+                for (int j = 0; j < RN; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        lds[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * LD + (wn * RN + j) * 32 + l31] = acc[i][j][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            float4 v = *reinterpret_cast<const float4 *>(lp + k * RG * LD);
+            v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+            if (has_res) { v.x += q[k].x; v.y += q[k].y; v.z += q[k].z; v.w += q[k].w; }
+            if (do_stats) {
+                if (ph == 0 && k == 0) K = v;  // pivot = this thread's first value per channel
+                float d;
+                d = v.x - K.x; s1.x += d; s2.x = fmaf(d, d, s2.x);
+                d = v.y - K.y; s1.y += d; s2.y = fmaf(d, d, s2.y);
+                d = v.z - K.z; s1.z += d; s2.z = fmaf(d, d, s2.z);
+                d = v.w - K.w; s1.w += d; s2.w = fmaf(d, d, s2.w);
+            }
+            *reinterpret_cast<float4 *>(op + (int64_t)(ph * PR + k * RG) * p.Cout) = v;
+        }
+        __syncthreads();
+    }
+    if (do_stats) {
+        float2 *part = reinterpret_cast<float2 *>(lds);  // the row image is dead now
+        const float fc = (float)(NP * WAVES_M);
+        const float mx = s1.x / fc, my = s1.y / fc, mz = s1.z / fc, mw = s1.w / fc;
+        part[rg * BN + c4 * 4 + 0] = make_float2(K.x + mx, fmaxf(s2.x - s1.x * mx, 0.f));
+        part[rg * BN + c4 * 4 + 1] = make_float2(K.y + my, fmaxf(s2.y - s1.y * my, 0.f));
+        part[rg * BN + c4 * 4 + 2] = make_float2(K.z + mz, fmaxf(s2.z - s1.z * mz, 0.f));
+        part[rg * BN + c4 * 4 + 3] = make_float2(K.w + mw, fmaxf(s2.w - s1.w * mw, 0.f));
+        __syncthreads();
+        if (tid < BN) {
+            const float npart = (float)(BM / RG);
+            float mean = part[tid].x, M2 = part[tid].y, na = npart;
+            for (int g = 1; g < RG; g++) {
+                const float2 qq = part[g * BN + tid];
+                const float d = qq.x - mean, N = na + npart;
+                mean += d * (npart / N);
+                M2 += qq.y + d * d * (na * npart / N);
+                na = N;
+            }
+            p.stats_out[(m0 / BM) * p.Cout + n0 + tid] = make_float2(mean, M2);
+        }
+    }
+}
+
+// MODE 0: any shape.  MODE 1: full tiles (M % 128 == 0, Cout % BN == 0, NHWC out): epilogue_rows_full.
+// MODE 2: MODE 1 and a 1x1 / stride 1 / NHWC convolution with C0 % 32 == 0 (the skip, qkv and proj convolutions):
+// the A gather is a row pointer that advances 32 channels per step (no tap / padding / clamp arithmetic in the loop).
+// (A persistent variant of MODE 2 -- one software pipeline over (tile, K step), the next tile's operands in LDS before
+// the epilogue -- measured 10 % SLOWER: with both workgroups of a CU always inside the MFMA loop the two waves of a
+// SIMD run at 78 % of the pipe (LDS / VMEM / VALU issue shares the port), whereas here a workgroup has the pipe to
+// itself while its neighbour is in its prologue or epilogue.)
+template <int BN, int WAVES_M, int WAVES_N, int RM, int RN, int MODE = 0>
 __global__ void __launch_bounds__(256) k_conv_igemm(ConvLaunch p) {
     static_assert(WAVES_M * WAVES_N == 4 && WAVES_M * RM * 32 == BM && WAVES_N * RN * 32 == BN, "tile shape");
     constexpr int NBF = BN / 8;          // floats of the W tile staged per thread (BN*32/256)
@@ -122,6 +208,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvLaunch p) {
     constexpr int BUF = (BM + BN) * LDS_LD;
     __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
 
+    DLPM_PHASE_DECL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -157,7 +244,30 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvLaunch p) {
     // time): a load inside a divergent branch makes hipcc copy its result at the join, which forces
     // s_waitcnt vmcnt(0) right there and serialises the prefetch with the MFMAs it should hide under.
     const int wrow = min(n0 + rb, p.Cout - 1);
+    // MODE 2 row pointers: channel c of this thread's pixel is a0[c] for c < C0 and a1[c] beyond (a1 is pre-biased)
+    const float *a0 = p.src0 + ma * p.C0 + sega;
+    const float *a1 = p.src1 ? p.src1 + ma * p.C1 + sega - p.C0 : a0;
+    const float *w0 = p.w + (int64_t)wrow * Cin + segb;
+    const float *ka = has_coef ? p.coefA + (int64_t)pb * Cin + sega : nullptr;
+    const float *kb = has_coef ? p.coefB + (int64_t)pb * Cin + sega : nullptr;
     auto load_step = [&](int s) {
+        if constexpr (MODE == 2) {
+            const int c0 = s * KC;
+            a_ok = true;
+            const float *src = (c0 < p.C0) ? a0 + c0 : a1 + c0;   // uniform: C0 % 32 == 0
+#pragma unroll
+            for (int v = 0; v < 4; v++) xa[v] = reinterpret_cast<const float4 *>(src)[v];
+            if (has_coef) {
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    ca[v] = reinterpret_cast<const float4 *>(ka + c0)[v];
+                    cb[v] = reinterpret_cast<const float4 *>(kb + c0)[v];
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < NBV; v++) wb[v] = reinterpret_cast<const float4 *>(w0 + c0)[v];
+            return;
+        }
         const int chunk = s / ntaps, tap = s - chunk * ntaps;
         const int c0 = chunk * KC;
         const int ky = tap / p.ks, kx = tap - ky * p.ks;
@@ -220,6 +330,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvLaunch p) {
     load_step(0);
     store_step(0);
     __syncthreads();
+    DLPM_PHASE(p, 0);
 
     for (int s = 0; s < nsteps; s++) {
         const int buf = s & 1;
@@ -249,8 +360,21 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvLaunch p) {
         __syncthreads();
     }
 
+    DLPM_PHASE(p, 1);
+    if constexpr (MODE >= 1) {
+        epilogue_rows_full<BN, WAVES_M, WAVES_N, RM, RN>(p, acc, smem, m0, n0, tid, wm, wn, l31, kh);
+        DLPM_PHASE(p, 2);
+#ifdef DLPM_PHASE_TIMING
+        if (p.phase && tid == 0) atomicAdd(p.phase + 3, 1ull);
+#endif
+        return;
+    }
     if (!p.out_nchw && (p.Cout & 3) == 0 && (p.R0 & 3) == 0) {
         epilogue_rows<BN, WAVES_M, WAVES_N, RM, RN>(p, acc, smem, m0, n0, M, tid, wm, wn, l31, kh);
+        DLPM_PHASE(p, 2);
+#ifdef DLPM_PHASE_TIMING
+        if (p.phase && tid == 0) atomicAdd(p.phase + 3, 1ull);
+#endif
         return;
     }
     // ---- scalar epilogue (NCHW head, odd channel counts): C/D layout of the 32x32 MFMA:
@@ -994,6 +1118,9 @@ int launch_conv_igemm(const ConvLaunch &c, hipStream_t st) {
     static int abl = -1;
     if (abl < 0) { const char *e = getenv("DLPM_ABL"); abl = e ? atoi(e) : 0; }
     if (abl) const_cast<ConvLaunch &>(c).abl = abl;
+#ifdef DLPM_PHASE_TIMING
+    const_cast<ConvLaunch &>(c).phase = phase_buffer();
+#endif
     if (gemm_ws_ok(c, &th, &nimg)) {
         int r;
         if (c.Cout > 64) r = launch_gemm_ws<128, 2, 2, 2, 2>(c, th, nimg, mt * ceil_div(c.Cout, 128), st);
@@ -1020,16 +1147,24 @@ int launch_conv_igemm(const ConvLaunch &c, hipStream_t st) {
         DLPM_LAUNCH_CHECK();
         return DLPM_OK;
     }
-    if (c.Cout > 64) {
-        const int64_t grid = mt * ceil_div(c.Cout, 128);
-        k_conv_igemm<128, 2, 2, 2, 2><<<(unsigned)grid, 256, 0, st>>>(c);
-    } else if (c.Cout > 32) {
-        const int64_t grid = mt * ceil_div(c.Cout, 64);
-        k_conv_igemm<64, 2, 2, 2, 1><<<(unsigned)grid, 256, 0, st>>>(c);
-    } else {
-        const int64_t grid = mt * ceil_div(c.Cout, 32);
-        k_conv_igemm<32, 4, 1, 1, 1><<<(unsigned)grid, 256, 0, st>>>(c);
-    }
+    // full tiles take the lean epilogue (MODE 1); 1x1 NHWC convolutions also the pointer-walking gather (MODE 2)
+    static int nofast = -1;
+    if (nofast < 0) { const char *e = getenv("DLPM_NO_FAST_IGEMM"); nofast = (e && e[0] == '1') ? 1 : 0; }
+    const int bn = c.Cout > 64 ? 128 : c.Cout > 32 ? 64 : 32;
+    const bool full = !nofast && !c.abl && M % BM == 0 && c.Cout % bn == 0 && !c.out_nchw && (c.R0 & 3) == 0;
+    const bool g1 = full && c.ks == 1 && c.stride == 1 && !c.ups && !c.in_nchw && c.C0 % KC == 0 && (c.C0 + c.C1) % KC == 0;
+    const int mode = g1 ? 2 : full ? 1 : 0;
+    const unsigned grid = (unsigned)(mt * ceil_div(c.Cout, bn));
+#define DLPM_IGEMM_LAUNCH(BN_, WM_, WN_, RM_, RN_)                                                   \
+    do {                                                                                             \
+        if (mode == 2) k_conv_igemm<BN_, WM_, WN_, RM_, RN_, 2><<<grid, 256, 0, st>>>(c);            \
+        else if (mode == 1) k_conv_igemm<BN_, WM_, WN_, RM_, RN_, 1><<<grid, 256, 0, st>>>(c);       \
+        else k_conv_igemm<BN_, WM_, WN_, RM_, RN_, 0><<<grid, 256, 0, st>>>(c);                      \
+    } while (0)
+    if (bn == 128) DLPM_IGEMM_LAUNCH(128, 2, 2, 2, 2);
+    else if (bn == 64) DLPM_IGEMM_LAUNCH(64, 2, 2, 2, 1);
+    else DLPM_IGEMM_LAUNCH(32, 4, 1, 1, 1);
+#undef DLPM_IGEMM_LAUNCH
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }

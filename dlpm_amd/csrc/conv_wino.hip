@@ -760,6 +760,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
     float *raw = wsm + 2 * 16 * MT * PVLD;           // [2][RAWPIX][PRLD]
     float *Cf = raw + 2 * RAWPIX * PRLD;             // [2 slots][16 images][2][8]
 
+    DLPM_PHASE_DECL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
     const int ph = NW == 8 ? wave >> 2 : wave >> 1;
@@ -930,6 +931,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
     cfr = cfr2;
     store_coef(0);
     __syncthreads();
+    DLPM_PHASE(p, 8);
 
     for (int chunk = 0; chunk < nch; chunk++) {
         const int cur = chunk & 1, nxt = cur ^ 1;
@@ -972,6 +974,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
         if (!(ABL & 8)) __syncthreads();
     }
     if (ABL & 8) __syncthreads();
+    DLPM_PHASE(p, 9);
 
     // ---- epilogue addressing + residual prefetch (8 rows per thread)
     constexpr int C4N = NQ / 4, NRG = NT / C4N;    // float4 columns per row, row groups
@@ -1083,6 +1086,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
             p.stats_out[((int64_t)img0 * nt + blk_in_img) * p.Cout + n0 + tid] = make_float2(mean, M2);
         }
     }
+    DLPM_PHASE(p, 10);
+#ifdef DLPM_PHASE_TIMING
+    if (p.phase && tid == 0) atomicAdd(p.phase + 11, 1ull);
+#endif
 }
 
 // OIHW (3x3) -> U = G g G^T in k_conv3x3_wino_q's fragment order  Wf[nb][ph][chunk8][pos8][lane][4]:
@@ -1247,6 +1254,9 @@ int launch_conv_wino(const ConvLaunch &c, hipStream_t st) {
         set_error("launch_conv_wino: unsupported shape");
         return DLPM_ERR_UNSUPPORTED;
     }
+#ifdef DLPM_PHASE_TIMING
+    const_cast<ConvLaunch &>(c).phase = phase_buffer();
+#endif
     const int64_t tiles = (int64_t)c.B * (c.Hout / 2) * (c.Wout / 2);
     const int64_t mblocks = nimg == 1 ? tiles / WT : ceil_div(c.B, nimg);
     const int64_t grid = mblocks * (c.Cout / WN);

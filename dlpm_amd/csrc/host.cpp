@@ -30,6 +30,13 @@ bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 }  // namespace
 bool prof_enabled() { return g_prof_on; }
+#ifdef DLPM_PHASE_TIMING
+unsigned long long *phase_buffer() {
+    static unsigned long long *buf = nullptr;
+    if (!buf && hipMalloc(&buf, 32 * sizeof(unsigned long long)) == hipSuccess) hipMemset(buf, 0, 32 * sizeof(unsigned long long));
+    return buf;
+}
+#endif
 bool prof_detail() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("DLPM_PROF_DETAIL"); v = (e && e[0] == '1') ? 1 : 0; }
@@ -304,3 +311,15 @@ extern "C" int dlpm_lim_tables_f32(double alpha, int32_t steps, int32_t ode, flo
     }
     return DLPM_OK;
 }
+
+#ifdef DLPM_PHASE_TIMING
+// developer builds only (not in include/dlpm_amd.h): read and clear the phase counters
+extern "C" int dlpm_debug_phases(unsigned long long *out32) {
+    unsigned long long *b = dlpm::phase_buffer();
+    if (!b) return DLPM_ERR_HIP;
+    DLPM_HIP(hipDeviceSynchronize());
+    DLPM_HIP(hipMemcpy(out32, b, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    DLPM_HIP(hipMemset(b, 0, 32 * sizeof(unsigned long long)));
+    return DLPM_OK;
+}
+#endif

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Where a convolution workgroup spends its cycles (developer tool).
+
+Needs a library built with the phase counters compiled in:
+
+    DLPM_BUILD_DEFS=-DDLPM_PHASE_TIMING python -m dlpm_amd.build
+    python tools/phase_conv.py
+
+Thread 0 of every workgroup adds clock64() deltas per phase (prologue / main loop / epilogue) into a device buffer;
+this prints the mean per workgroup for a list of the CIFAR net's launch shapes next to the launch time.
+"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch
+from dlpm_amd import _lib
+
+L = _lib.lib()
+if not hasattr(L, 'dlpm_debug_phases'):
+    sys.exit('library was built without -DDLPM_PHASE_TIMING')
+L.dlpm_debug_phases.restype = C.c_int
+L.dlpm_debug_phases.argtypes = [C.POINTER(C.c_ulonglong * 32)]
+DEV = 'cuda'
+
+# name, B, C0, C1, H, Cout, ks, coef+silu, res
+SHAPES = [
+    ('1x1 skip H32 128+128->128', 1024, 128, 128, 32, 128, 1, False, False),
+    ('1x1 skip H32 256+128->128', 1024, 256, 128, 32, 128, 1, False, False),
+    ('1x1 skip H16 256+256->256', 1024, 256, 256, 16, 256, 1, False, False),
+    ('1x1 qkv  H8  256->768', 1024, 256, 0, 8, 768, 1, True, False),
+    ('1x1 proj H8  256->256 +res', 1024, 256, 0, 8, 256, 1, False, True),
+    ('3x3 wino H32 128->128', 1024, 128, 0, 32, 128, 3, True, True),
+    ('3x3 wino H16 256->256', 1024, 256, 0, 16, 256, 3, True, True),
+    ('3x3 wino H32 128+128->128', 1024, 128, 128, 32, 128, 3, True, False),
+]
+
+
+def run(name, B, C0, C1, H, Cout, ks, coef, res, reps=5):
+    Cin = C0 + C1
+    x0 = torch.randn(B, H, H, C0, device=DEV)
+    x1 = torch.randn(B, H, H, C1, device=DEV) if C1 else None
+    w = torch.randn(Cout, Cin, ks, ks, device=DEV) * 0.05
+    bias = torch.randn(Cout, device=DEV)
+    out = torch.empty(B, H, H, Cout, device=DEV)
+    a = _lib.ConvArgs()
+    a.src0, a.C0 = x0.data_ptr(), C0
+    if C1:
+        a.src1, a.C1 = x1.data_ptr(), C1
+    a.B, a.Hin, a.Win, a.Hout, a.Wout = B, H, H, H, H
+    a.ksize, a.stride, a.upsample = ks, 1, 0
+    a.weight, a.bias = w.data_ptr(), bias.data_ptr()
+    keep = []
+    if coef:
+        cA, cB = torch.rand(B, Cin, device=DEV) + 0.5, torch.randn(B, Cin, device=DEV) * 0.1
+        keep += [cA, cB]
+        a.coefA, a.coefB, a.act_silu = cA.data_ptr(), cB.data_ptr(), 1
+    if res:
+        r = torch.randn(B, H, H, Cout, device=DEV)
+        keep.append(r)
+        a.res0, a.R0 = r.data_ptr(), Cout
+    a.out, a.Cout = out.data_ptr(), Cout
+    scratch = torch.empty(5 * w.numel() + 16 * 1024 * (1 + Cout // 32), device=DEV)
+    a.scratch_floats = scratch.numel()
+    st = _lib.stream_ptr()
+    ph = (C.c_ulonglong * 32)()
+    _lib.check(L.dlpm_conv2d_f32(C.byref(a), scratch.data_ptr(), st))
+    _lib.check(L.dlpm_debug_phases(C.byref(ph)))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _lib.check(L.dlpm_conv2d_f32(C.byref(a), scratch.data_ptr(), st))
+    e1.record()
+    torch.cuda.synchronize()
+    _lib.check(L.dlpm_debug_phases(C.byref(ph)))
+    base = 8 if ph[11] else 0
+    n = ph[base + 3]
+    pro, main, epi = (ph[base + i] / max(n, 1) for i in range(3))
+    tot = pro + main + epi
+    print('%-30s %8.3f ms/call(+relayout)  wgs/launch %6d  cycles/wg: prologue %7.0f (%4.1f%%)  loop %7.0f (%4.1f%%)  epilogue %7.0f (%4.1f%%)'
+          % (name, e0.elapsed_time(e1) / reps, n // reps, pro, 100 * pro / tot, main, 100 * main / tot, epi, 100 * epi / tot))
+
+
+for s in SHAPES:
+    run(*s)
