@@ -15,6 +15,7 @@ struct ConvLaunch {
                                    // (see k_conv3x3_halo_ws): each wave streams it straight into registers
     const float *w_wino = nullptr; // optional, 3x3 s1 only: Winograd-domain weights U = G g G^T in fragment order
                                    // (see conv_wino.hip); when the shape qualifies the F(2x2,3x3) kernel runs
+    const float *w_wino4 = nullptr;// optional, 3x3 s1 only: F(4x4,3x3) Winograd-domain weights (conv_wino4.hip); preferred over w_wino
     const float *w_small = nullptr;// optional, 3x3 with Cout <= 4 (the head): [tap][Cin][4] for k_conv3x3_head
     const float *bias = nullptr;   // [Cout] or null
     const float *coefA = nullptr, *coefB = nullptr;  // [B, Cin] fused GroupNorm affine, or null
@@ -51,6 +52,12 @@ int wino_tiles(const ConvLaunch &c);   // 2x2 output tiles per workgroup (64 or 
 int launch_conv_wino(const ConvLaunch &c, hipStream_t st);
 int64_t wino_weight_floats(int Cout, int Cin);
 int relayout_weight_wino(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st);
+// Winograd F(4x4,3x3) path (conv_wino4.hip): 16 tiles of 4x4 outputs x 128 channels per workgroup
+bool wino4_enabled();                  // DLPM_WINO_F4
+bool wino4_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg);
+int launch_conv_wino4(const ConvLaunch &c, hipStream_t st);
+int64_t wino4_weight_floats(int Cout, int Cin);
+int relayout_weight_wino4(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st);
 // pixels behind one stats_out partial for this launch (0: the launch cannot emit statistics)
 int conv_stats_pixels(const ConvLaunch &c);
 // non-MFMA shapes: the stem kernel when it applies, the generic direct kernel otherwise

@@ -1,0 +1,497 @@
+// conv_wino4.hip -- 3x3 / stride-1 convolution as Winograd F(4x4,3x3) on the gfx950 fp32 MFMA (v_mfma_f32_16x16x4_f32).
+//
+// Replaces the same F.conv2d calls as conv_wino.hip (dlpm/models/unet.py:64,96,143,157,168 via nn.py:25-35) for the
+// layers whose output is a multiple of 4x4 pixels and 128 channels.  F(4x4,3x3) spends 36 multiplies per 16 outputs
+// and channel pair (2.25 per output) where F(2x2,3x3) spends 4 and the direct form 9:
+//
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A        d: 6x6 input tile, g: 3x3 filter, Y: 4x4 output tile
+//
+// with the transform matrices of Lavin & Gray (interpolation points 0, +-1, +-2, inf) -- see bt_rows() / at_rows().
+// The price is numerical: the transforms amplify rounding (|B^T| rows sum to 10, |A^T| to 19); through the whole CIFAR
+// UNet the result differs from the fp32 reference by 1.5e-5 (F(2x2): 3e-6; the path's budget is 1e-4).
+//
+// Work split (one workgroup per CU, 8 waves, 16 tiles x 128 output channels):
+//   * the 36 transform positions are 36 independent GEMMs  M_pos[tile][cout] = sum_cin V_pos[tile][cin] U_pos[cin][cout];
+//     wave w owns output channels 16w..16w+15 for ALL positions: 36 accumulators of the 16x16x4 MFMA (144 registers),
+//     so the output transform never leaves the wave's registers -- no cross-wave exchange as in k_conv3x3_wino_q;
+//   * U (filters in the Winograd domain, fragment order) streams L2 -> registers through a ring, exactly once per wave;
+//   * V = B^T d B is built in LDS per 8-channel phase by waves 0..2 (one row pair of B^T each, lanes = tile x channel
+//     pair) from a raw halo patch that all waves stage with the fused GroupNorm affine + SiLU;
+//   * phases are software-pipelined like k_conv3x3_wino_q: S(c+2) raw stores, X(c+1) transform, G(c+3) global loads
+//     ride between the MFMAs of phase c, one barrier per phase;
+//   * epilogue: A^T M A per lane (36 -> 16 values), LDS row image, whole NHWC rows out with bias / residual / fused
+//     GroupNorm statistics.
+#include <cstdlib>
+
+#include "conv.h"
+
+namespace dlpm {
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int F4_TILES = 16;      // 4x4-output tiles per workgroup (the M of the 16x16x4 MFMA)
+constexpr int F4_NQ = 128;        // output channels per workgroup (8 waves x 16)
+constexpr int F4_KC = 8;          // input channels per phase (2 MFMA k-steps)
+constexpr int F4_RAWPIX = 576;    // halo pixels per phase: one 18x18 patch, 4 x 10x10 or 16 x 6x6 (whole small images)
+constexpr int F4_PRLD = F4_KC + 4;
+constexpr int F4_NT = 512;
+constexpr int F4_QNIT = (F4_RAWPIX * 2 + F4_NT - 1) / F4_NT;   // staging items (pixel, channel quad) per thread: 3
+constexpr int F4_CFS = 16 * 2 * F4_KC;   // floats per GroupNorm-coefficient slot: [16 images][A | B][8]
+constexpr int F4_VBUF = 36 * F4_TILES * F4_KC;   // floats per V buffer: [36][16][8]
+constexpr int F4_RING = 6;        // weight fragments (float4 = 2 positions x 2 k-steps) in flight; divides the 18 of a phase
+constexpr int F4_ELD = F4_NQ + 4; // row image pitch
+constexpr int F4_PAD = 8;         // float4 fragments of zero padding behind the weights (ring read-ahead of the last phase)
+
+#ifndef F4_S0
+#define F4_S0 3    // position pair behind which the staging stores start
+#endif
+#ifndef F4_X
+#define F4_X 9     // position pair behind which waves 0..2 run the input transform
+#endif
+
+// one line of B^T d (or of T B): the six transform rows from six samples x0..x5
+//   r0 = 4 x0 - 5 x2 + x4          r5 = 4 x1 - 5 x3 + x5
+//   r1 = (x4 - 4 x2) + (x3 - 4 x1) r2 = (x4 - 4 x2) - (x3 - 4 x1)
+//   r3 = (x4 - x2) + 2 (x3 - x1)   r4 = (x4 - x2) - 2 (x3 - x1)
+__device__ __forceinline__ float2 f2fma(float a, float2 x, float2 y) { return make_float2(fmaf(a, x.x, y.x), fmaf(a, x.y, y.y)); }
+__device__ __forceinline__ float2 f2add(float2 x, float2 y) { return make_float2(x.x + y.x, x.y + y.y); }
+__device__ __forceinline__ float2 f2sub(float2 x, float2 y) { return make_float2(x.x - y.x, x.y - y.y); }
+
+template <bool UPS>
+__global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh, int bw, int nimg) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float *V = wsm;                               // [2][36][16][8]
+    float *raw = wsm + 2 * F4_VBUF;               // [2][F4_RAWPIX][F4_PRLD]
+    float *Cf = raw + 2 * F4_RAWPIX * F4_PRLD;    // [2][16][2][8]
+
+    DLPM_PHASE_DECL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int W = p.Wout, H = p.Hout, TW = W >> 2, TH = H >> 2;
+    const int Ws = UPS ? (W >> 1) : W, Hs = UPS ? (H >> 1) : H;
+    const int Cin = p.C0 + p.C1, nch = Cin / F4_KC;
+    // n-tile-major grid: all workgroups in flight stream the same 128-channel slab of the Winograd-domain weights
+    const int ntn = p.Cout / F4_NQ;
+    const int nmb = gridDim.x / ntn;
+    const int mb = blockIdx.x % nmb, n0 = (blockIdx.x / nmb) * F4_NQ;
+    int img0, ty0, tx0, blk_in_img = 0;
+    if (nimg == 1) {
+        const int bpr = TW / bw, bpi = (TH / bh) * bpr;
+        img0 = mb / bpi;
+        blk_in_img = mb - img0 * bpi;
+        ty0 = (blk_in_img / bpr) * bh;
+        tx0 = (blk_in_img % bpr) * bw;
+    } else {
+        img0 = mb * nimg;
+        ty0 = tx0 = 0;
+    }
+    // halo patch in SOURCE pixels (nearest-x2 upsampling folded into the addressing): output rows 4 ty0 - 1 .. 4 (ty0 + bh)
+    const int RH = UPS ? 2 * bh + 2 : 4 * bh + 2, RW = UPS ? 2 * bw + 2 : 4 * bw + 2;
+    const int oy = UPS ? 2 * ty0 - 1 : 4 * ty0 - 1, ox = UPS ? 2 * tx0 - 1 : 4 * tx0 - 1;
+    const int rpi = RH * RW, npix = nimg * rpi;
+
+    // ---- raw staging: item = (pixel, channel quad of the phase)
+    const int squad = tid & 1;
+    int off[F4_QNIT], cfo[F4_QNIT];
+#pragma unroll
+    for (int it = 0; it < F4_QNIT; it++) {
+        const int pix = it * (F4_NT / 2) + (tid >> 1);
+        const int img = min(pix / rpi, nimg - 1), r = pix - img * rpi;
+        const int ry = r / RW, rx = r - ry * RW;
+        const int iy = oy + ry, ix = ox + rx;
+        const bool pad = iy < 0 || iy >= Hs || ix < 0 || ix >= Ws || (img0 + img) >= p.B;
+        off[it] = pix >= npix ? -2 : (pad ? -1 : (((img0 + img) * Hs + iy) * Ws + ix));
+        cfo[it] = img * 2 * F4_KC + squad * 4;
+    }
+    const bool has_coef = p.coefA != nullptr;
+    const int cf_img = tid >> 2, cf_isb = (tid >> 1) & 1;
+    const bool cf_mine = has_coef && tid < nimg * 4;
+    const float *cf_base = has_coef ? ((cf_isb ? p.coefB : p.coefA) + (int64_t)min(img0 + cf_img, p.B - 1) * Cin + squad * 4) : nullptr;
+    float4 xr[F4_QNIT], cfr = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_raw_into = [&](float4 (&dst)[F4_QNIT], int chunk) {
+        const int c = chunk * F4_KC + squad * 4;
+        const bool first = c < p.C0;
+        const float *sb = first ? p.src0 + c : p.src1 + (c - p.C0);
+        const int ld = first ? p.C0 : p.C1;
+#pragma unroll
+        for (int it = 0; it < F4_QNIT; it++) dst[it] = *reinterpret_cast<const float4 *>(sb + (int64_t)max(off[it], 0) * ld);
+    };
+    auto load_coef = [&](int chunk) {
+        if (cf_mine) cfr = *reinterpret_cast<const float4 *>(cf_base + chunk * F4_KC);
+    };
+    auto store_coef = [&](int slot) {
+        if (cf_mine) *reinterpret_cast<float4 *>(Cf + slot * F4_CFS + cf_img * 2 * F4_KC + cf_isb * F4_KC + squad * 4) = cfr;
+    };
+    auto store_raw_item = [&](int slot, int it) {
+        if (off[it] == -2) return;
+        float *rb = raw + slot * F4_RAWPIX * F4_PRLD;
+        float4 x = xr[it];
+        if (has_coef) {
+            const float4 ca = *reinterpret_cast<const float4 *>(Cf + slot * F4_CFS + cfo[it]);
+            const float4 cb = *reinterpret_cast<const float4 *>(Cf + slot * F4_CFS + cfo[it] + F4_KC);
+            x.x = fmaf(x.x, ca.x, cb.x);
+            x.y = fmaf(x.y, ca.y, cb.y);
+            x.z = fmaf(x.z, ca.z, cb.z);
+            x.w = fmaf(x.w, ca.w, cb.w);
+        }
+        if (p.act_silu) {
+            x.x = silu_f(x.x);
+            x.y = silu_f(x.y);
+            x.z = silu_f(x.z);
+            x.w = silu_f(x.w);
+        }
+        if (off[it] < 0) x = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding applies AFTER the activation
+        *reinterpret_cast<float4 *>(rb + (it * (F4_NT / 2) + (tid >> 1)) * F4_PRLD + squad * 4) = x;
+    };
+    auto store_raw = [&](int slot) {
+#pragma unroll
+        for (int it = 0; it < F4_QNIT; it++) store_raw_item(slot, it);
+    };
+
+    // ---- input transform V = B^T d B: waves 0..2 take the row pairs (0,5), (1,2), (3,4) of B^T; lane = (tile, channel pair)
+    int rbase, vofs;
+    {
+        const int tile = lane >> 2, pair = lane & 3;
+        const int timg = tile / (bh * bw), r = tile - timg * (bh * bw);
+        const int ty = r / bw, tx = r - ty * bw;
+        rbase = (timg * rpi + (UPS ? 2 : 4) * ty * RW + (UPS ? 2 : 4) * tx) * F4_PRLD + pair * 2;
+        vofs = tile * F4_KC + pair * 2;
+    }
+    auto transform = [&](int slot) {
+        if (wave >= 3) return;
+        const float *rb = raw + slot * F4_RAWPIX * F4_PRLD + rbase;
+        float *vb = V + slot * F4_VBUF + vofs;
+        // d(i, c): sample row i, column c of this tile's 6x6 patch (upsampled: source row (i + 1) >> 1 of the 4x4 source patch)
+        auto d = [&](int i, int c) {
+            const int ri = UPS ? (i + 1) >> 1 : i, ci = UPS ? (c + 1) >> 1 : c;
+            return *reinterpret_cast<const float2 *>(rb + (ri * RW + ci) * F4_PRLD);
+        };
+        float2 Ta[6], Tb[6];
+        int a0, a1;
+        if (wave == 0) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                Ta[c] = f2fma(4.f, d(0, c), f2fma(-5.f, d(2, c), d(4, c)));
+                Tb[c] = f2fma(4.f, d(1, c), f2fma(-5.f, d(3, c), d(5, c)));
+            }
+            a0 = 0; a1 = 5;
+        } else if (wave == 1) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const float2 e = f2fma(-4.f, d(2, c), d(4, c)), o = f2fma(-4.f, d(1, c), d(3, c));
+                Ta[c] = f2add(e, o);
+                Tb[c] = f2sub(e, o);
+            }
+            a0 = 1; a1 = 2;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const float2 e = f2sub(d(4, c), d(2, c)), o0 = f2sub(d(3, c), d(1, c));
+                const float2 o = make_float2(2.f * o0.x, 2.f * o0.y);
+                Ta[c] = f2add(e, o);
+                Tb[c] = f2sub(e, o);
+            }
+            a0 = 3; a1 = 4;
+        }
+        auto row_out = [&](const float2 (&T)[6], int a) {
+            float *vr = vb + a * 6 * F4_TILES * F4_KC;
+            const float2 e1 = f2fma(-4.f, T[2], T[4]), o1 = f2fma(-4.f, T[1], T[3]);
+            const float2 e2 = f2sub(T[4], T[2]), q2 = f2sub(T[3], T[1]);
+            const float2 o2 = make_float2(2.f * q2.x, 2.f * q2.y);
+            *reinterpret_cast<float2 *>(vr + 0 * F4_TILES * F4_KC) = f2fma(4.f, T[0], f2fma(-5.f, T[2], T[4]));
+            *reinterpret_cast<float2 *>(vr + 1 * F4_TILES * F4_KC) = f2add(e1, o1);
+            *reinterpret_cast<float2 *>(vr + 2 * F4_TILES * F4_KC) = f2sub(e1, o1);
+            *reinterpret_cast<float2 *>(vr + 3 * F4_TILES * F4_KC) = f2add(e2, o2);
+            *reinterpret_cast<float2 *>(vr + 4 * F4_TILES * F4_KC) = f2sub(e2, o2);
+            *reinterpret_cast<float2 *>(vr + 5 * F4_TILES * F4_KC) = f2fma(4.f, T[1], f2fma(-5.f, T[3], T[5]));
+        };
+        row_out(Ta, a0);
+        row_out(Tb, a1);
+    };
+
+    // ---- weight stream of this wave: Wf[ntile][wave][phase][18 position pairs][lane][4], contiguous per wave
+    const float4 *__restrict__ wbase = reinterpret_cast<const float4 *>(p.w_wino4) + lane;
+    int64_t woff = (int64_t)((n0 >> 7) * 8 + wave) * nch * 18 * 64;
+    constexpr int AHEAD = F4_RING - 1;
+    float4 bq[F4_RING];
+    // A fragments: lane (li = tile, lk) reads channels 2 lk, 2 lk + 1 of the phase = k index lk of the two k-steps
+    const float *asrc = V + li * F4_KC + 2 * lk;
+
+    floatx4 acc[36];
+#pragma unroll
+    for (int q = 0; q < 36; q++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[q][r] = 0.f;
+
+    // ---- prologue: S(0), S(1), X(0), G(2) and the coefficient slots; everything the first two phases need is
+    // requested at once (one exposed round trip)
+    const int last = nch - 1;
+    float4 xr1[F4_QNIT], cfr1 = make_float4(0.f, 0.f, 0.f, 0.f), cfr2 = cfr1;
+    load_raw_into(xr, 0);
+    load_raw_into(xr1, min(1, last));
+    load_coef(0);
+    if (cf_mine) {
+        cfr1 = *reinterpret_cast<const float4 *>(cf_base + min(1, last) * F4_KC);
+        cfr2 = *reinterpret_cast<const float4 *>(cf_base + min(2, last) * F4_KC);
+    }
+#pragma unroll
+    for (int a = 0; a < AHEAD; a++) bq[a] = wbase[woff + a * 64];
+    store_coef(0);
+    cfr = cfr1;
+    store_coef(1);
+    __syncthreads();
+    store_raw(0);
+#pragma unroll
+    for (int it = 0; it < F4_QNIT; it++) xr[it] = xr1[it];
+    store_raw(1);
+    load_raw_into(xr, min(2, last));
+    __syncthreads();
+    transform(0);
+    cfr = cfr2;
+    store_coef(0);
+    __syncthreads();
+    DLPM_PHASE(p, 8);
+
+    for (int chunk = 0; chunk < nch; chunk++) {
+        const int cur = chunk & 1, nxt = cur ^ 1;
+        const float *ab = asrc + cur * F4_VBUF;
+        load_coef(min(chunk + 3, last));
+#pragma unroll
+        for (int pp = 0; pp < 18; pp++) {
+            if (pp >= F4_S0 && pp < F4_S0 + F4_QNIT) store_raw_item(cur, pp - F4_S0);   // S(chunk+2): raw[cur] was read by X(chunk), a barrier ago
+            if (pp == F4_S0 + F4_QNIT) load_raw_into(xr, min(chunk + 3, last));        // G(chunk+3)
+            if (pp == F4_X) transform(nxt);                                             // X(chunk+1): raw[nxt] -> V[nxt]
+            bq[(pp + AHEAD) % F4_RING] = wbase[woff + AHEAD * 64];
+            woff += 64;
+            const float2 a0 = *reinterpret_cast<const float2 *>(ab + (2 * pp) * F4_TILES * F4_KC);
+            const float2 a1 = *reinterpret_cast<const float2 *>(ab + (2 * pp + 1) * F4_TILES * F4_KC);
+            const float4 b = bq[pp % F4_RING];
+            acc[2 * pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc[2 * pp], 0, 0, 0);
+            acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.z, acc[2 * pp + 1], 0, 0, 0);
+            acc[2 * pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc[2 * pp], 0, 0, 0);
+            acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.w, acc[2 * pp + 1], 0, 0, 0);
+        }
+        store_coef(nxt);
+        __syncthreads();
+    }
+    DLPM_PHASE(p, 9);
+
+    // ---- epilogue.  Thread (c4, rg) of the streaming pass owns channel quad c4 and position (i, j) = (rg >> 2, rg & 3)
+    // of every tile: 16 rows, one per tile.  The first 8 residual rows are requested before the output transform.
+    const int c4 = tid & 31, rg = tid >> 5;
+    const int n = n0 + c4 * 4;
+    const int R1 = p.Cout - p.R0;
+    const bool has_res = p.res0 != nullptr;
+    int64_t mrow[F4_TILES];
+    float4 resq[F4_TILES];
+#pragma unroll
+    for (int t = 0; t < F4_TILES; t++) {
+        const int timg = t / (bh * bw), r = t - timg * (bh * bw);
+        const int ty = r / bw, tx = r - ty * bw;
+        const bool ok = img0 + timg < p.B;
+        const int64_t m = ((int64_t)min(img0 + timg, p.B - 1) * H + 4 * (ty0 + ty) + (rg >> 2)) * W + 4 * (tx0 + tx) + (rg & 3);
+        mrow[t] = ok ? m : -1;
+    }
+    auto load_res = [&](int t) {
+        const int64_t m = mrow[t] < 0 ? 0 : mrow[t];
+        resq[t] = (n < p.R0) ? *reinterpret_cast<const float4 *>(p.res0 + m * p.R0 + n)
+                             : *reinterpret_cast<const float4 *>(p.res1 + m * R1 + (n - p.R0));
+    };
+    if (has_res) {
+#pragma unroll
+        for (int t = 0; t < 8; t++) load_res(t);
+    }
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bias = *reinterpret_cast<const float4 *>(p.bias + n);
+
+    // output transform Y = A^T M A in registers: lane holds M_pos[tile 4 lk + r][cout 16 wave + li] in acc[pos][r]
+    //   y0 = m0 + (m1 + m2) + (m3 + m4)      y1 = (m1 - m2) + 2 (m3 - m4)
+    //   y2 = (m1 + m2) + 4 (m3 + m4)         y3 = (m1 - m2) + 8 (m3 - m4) + m5
+    // image rows of tile group lk are skewed by 16 lk floats: the four lane groups of a ds_write hit different banks
+    float *img = wsm;   // [256 rows][F4_ELD] (+ skew)
+    {
+        float *dst = img + lk * 16 + wave * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float Z[4][6];
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                const float m0 = acc[0 * 6 + b][r], m1 = acc[1 * 6 + b][r], m2 = acc[2 * 6 + b][r];
+                const float m3 = acc[3 * 6 + b][r], m4 = acc[4 * 6 + b][r], m5 = acc[5 * 6 + b][r];
+                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                Z[0][b] = m0 + s12 + s34;
+                Z[1][b] = fmaf(2.f, d34, d12);
+                Z[2][b] = fmaf(4.f, s34, s12);
+                Z[3][b] = fmaf(8.f, d34, d12) + m5;
+            }
+            const int tile = 4 * lk + r;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float s12 = Z[i][1] + Z[i][2], d12 = Z[i][1] - Z[i][2], s34 = Z[i][3] + Z[i][4], d34 = Z[i][3] - Z[i][4];
+                float *row = dst + (tile * 16 + i * 4) * F4_ELD;
+                row[0 * F4_ELD] = Z[i][0] + s12 + s34;
+                row[1 * F4_ELD] = fmaf(2.f, d34, d12);
+                row[2 * F4_ELD] = fmaf(4.f, s34, s12);
+                row[3 * F4_ELD] = fmaf(8.f, d34, d12) + Z[i][5];
+            }
+        }
+    }
+    if (has_res) {
+#pragma unroll
+        for (int t = 8; t < F4_TILES; t++) load_res(t);
+    }
+    __syncthreads();
+    const bool do_stats = p.stats_out != nullptr && nimg == 1;
+    float4 K = make_float4(0.f, 0.f, 0.f, 0.f), s1 = K, s2 = K;
+    int cnt = 0;
+#pragma unroll
+    for (int t = 0; t < F4_TILES; t++) {
+        const int64_t m = mrow[t];
+        if (m < 0) continue;
+        float4 v = *reinterpret_cast<const float4 *>(img + (t * 16 + rg) * F4_ELD + (t >> 2) * 16 + c4 * 4);
+        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+        if (has_res) {
+            const float4 q = resq[t];
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        if (do_stats) {
+            if (cnt == 0) K = v;
+            float dd;
+            dd = v.x - K.x; s1.x += dd; s2.x = fmaf(dd, dd, s2.x);
+            dd = v.y - K.y; s1.y += dd; s2.y = fmaf(dd, dd, s2.y);
+            dd = v.z - K.z; s1.z += dd; s2.z = fmaf(dd, dd, s2.z);
+            dd = v.w - K.w; s1.w += dd; s2.w = fmaf(dd, dd, s2.w);
+            cnt++;
+        }
+        *reinterpret_cast<float4 *>(p.out + m * p.Cout + n) = v;
+    }
+    if (do_stats) {
+        __syncthreads();
+        float2 *part = reinterpret_cast<float2 *>(wsm);   // [16 row groups][128]
+        const float fc = (float)(cnt > 0 ? cnt : 1);
+        const float mx = s1.x / fc, my = s1.y / fc, mz = s1.z / fc, mw = s1.w / fc;
+        part[rg * F4_NQ + c4 * 4 + 0] = make_float2(K.x + mx, fmaxf(s2.x - s1.x * mx, 0.f));
+        part[rg * F4_NQ + c4 * 4 + 1] = make_float2(K.y + my, fmaxf(s2.y - s1.y * my, 0.f));
+        part[rg * F4_NQ + c4 * 4 + 2] = make_float2(K.z + mz, fmaxf(s2.z - s1.z * mz, 0.f));
+        part[rg * F4_NQ + c4 * 4 + 3] = make_float2(K.w + mw, fmaxf(s2.w - s1.w * mw, 0.f));
+        __syncthreads();
+        if (tid < F4_NQ) {
+            const float npart = (float)F4_TILES;   // rows behind each partial
+            float mean = part[tid].x, M2 = part[tid].y, na = npart;
+            for (int g = 1; g < 16; g++) {
+                const float2 q = part[g * F4_NQ + tid];
+                const float dd = q.x - mean, N = na + npart;
+                mean += dd * (npart / N);
+                M2 += q.y + dd * dd * (na * npart / N);
+                na = N;
+            }
+            const int nt = (H * W) / 256;
+            p.stats_out[((int64_t)img0 * nt + blk_in_img) * p.Cout + n0 + tid] = make_float2(mean, M2);
+        }
+    }
+    DLPM_PHASE(p, 10);
+#ifdef DLPM_PHASE_TIMING
+    if (p.phase && tid == 0) atomicAdd(p.phase + 11, 1ull);
+#endif
+}
+
+// OIHW (3x3) -> U = G g G^T (6x6 per filter) in the kernel's fragment order Wf[ntile][wave][phase][18][lane][4]:
+// lane = lk*16 + li holds, for position pair pp and e = 0..3, U_pos[cin = phase*8 + 2 lk + (e & 1)][cout = ntile*128 + wave*16 + li]
+// with pos = 2 pp + (e >> 1).  Computed in double, rounded once.
+__global__ void k_relayout_weight_wino4(const float *oihw, float *dst, int Cout, int Cin) {
+    const int nch = Cin / F4_KC;
+    const int64_t total = (int64_t)Cout * Cin * 36;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int e = (int)(i & 3);
+    const int lane = (int)((i >> 2) & 63);
+    int64_t r = i >> 8;
+    const int pp = (int)(r % 18); r /= 18;
+    const int chunk = (int)(r % nch); r /= nch;
+    const int wave = (int)(r & 7);
+    const int nt = (int)(r >> 3);
+    const int lk = lane >> 4, li = lane & 15;
+    const int pos = 2 * pp + (e >> 1);
+    const int cin = chunk * F4_KC + 2 * lk + (e & 1), cout = nt * F4_NQ + wave * 16 + li;
+    const float *g = oihw + ((int64_t)cout * Cin + cin) * 9;
+    const double G[6][3] = {{0.25, 0., 0.},          {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
+                            {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
+    const int a = pos / 6, b = pos % 6;
+    double u = 0.;
+    for (int ii = 0; ii < 3; ii++) {
+        double row = 0.;
+        for (int jj = 0; jj < 3; jj++) row += (double)g[ii * 3 + jj] * G[b][jj];
+        u += G[a][ii] * row;
+    }
+    dst[i] = (float)u;
+}
+
+int f4_mode() {   // DLPM_WINO_F4: 0 never, 1 wherever the shape qualifies
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DLPM_WINO_F4"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
+}  // namespace
+
+bool wino4_enabled() { return f4_mode() != 0; }
+
+bool wino4_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
+    if (!c.w_wino4 || c.ks != 3 || c.stride != 1 || c.in_nchw || c.out_nchw || c.abl) return false;
+    if ((c.Hout & 3) || (c.Wout & 3) || c.Cout % F4_NQ != 0 || (c.C0 + c.C1) % F4_KC != 0 || c.C0 % F4_KC != 0) return false;
+    if ((c.R0 & 3) != 0) return false;
+    const int TH = c.Hout / 4, TW = c.Wout / 4;
+    int h, w, n;
+    if (TH * TW >= F4_TILES) {       // a block inside one image
+        w = TW < 4 ? TW : 4;
+        if (F4_TILES % w != 0) return false;
+        h = F4_TILES / w;
+        if (TW % w != 0 || TH % h != 0) return false;
+        n = 1;
+    } else {                         // several whole small images per block
+        if (F4_TILES % (TH * TW) != 0) return false;
+        h = TH; w = TW; n = F4_TILES / (TH * TW);
+    }
+    const int RH = c.ups ? 2 * h + 2 : 4 * h + 2, RW = c.ups ? 2 * w + 2 : 4 * w + 2;
+    if (n * RH * RW > F4_RAWPIX) return false;
+    *bh = h; *bw = w; *nimg = n;
+    return true;
+}
+
+int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
+    int bh, bw, nimg;
+    if (!wino4_geometry(c, &bh, &bw, &nimg)) {
+        set_error("launch_conv_wino4: unsupported shape");
+        return DLPM_ERR_UNSUPPORTED;
+    }
+#ifdef DLPM_PHASE_TIMING
+    const_cast<ConvLaunch &>(c).phase = phase_buffer();
+#endif
+    using KFn = void (*)(ConvLaunch, int, int, int);
+    KFn fn = c.ups ? &k_conv3x3_wino4<true> : &k_conv3x3_wino4<false>;
+    static bool configured[2] = {false, false};   // (the first launch of each kernel is eager, never inside a graph capture)
+    if (!configured[c.ups ? 1 : 0]) {
+        DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured[c.ups ? 1 : 0] = true;
+    }
+    const size_t loop_b = (size_t)(2 * F4_VBUF + 2 * F4_RAWPIX * F4_PRLD + 2 * F4_CFS) * sizeof(float);
+    const size_t epi_b = (size_t)(16 * F4_TILES * F4_ELD + 64) * sizeof(float);
+    const int64_t tiles = (int64_t)c.B * (c.Hout / 4) * (c.Wout / 4);
+    const int64_t mblocks = nimg == 1 ? tiles / F4_TILES : ceil_div(c.B, nimg);
+    fn<<<(unsigned)(mblocks * (c.Cout / F4_NQ)), F4_NT, loop_b > epi_b ? loop_b : epi_b, st>>>(c, bh, bw, nimg);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+int64_t wino4_weight_floats(int Cout, int Cin) { return (int64_t)Cout * Cin * 36 + F4_PAD * 256; }
+
+int relayout_weight_wino4(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st) {
+    const int64_t n = (int64_t)Cout * Cin * 36;
+    DLPM_HIP(hipMemsetAsync(dst_dev + n, 0, (size_t)F4_PAD * 256 * sizeof(float), st));
+    k_relayout_weight_wino4<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+}  // namespace dlpm

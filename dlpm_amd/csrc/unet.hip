@@ -41,6 +41,7 @@ struct ConvW {            // one convolution's weights
     float *w_dev = nullptr;  // re-laid-out copy (or the original for 1x1 igemm)
     float *w_frag = nullptr; // 3x3 only: MFMA fragment order for the weight-streaming halo kernel
     float *w_wino = nullptr; // 3x3 only: Winograd-domain weights in fragment order (conv_wino.hip)
+    float *w_wino4 = nullptr;// 3x3 only: F(4x4,3x3) Winograd-domain weights (conv_wino4.hip), when DLPM_WINO_F4 is on
     float *w_small = nullptr;// 3x3 with cout <= 4 (head): [tap][cin][4]
     bool owns = false;
 };
@@ -86,7 +87,7 @@ void plan_stats(Bump &ws, Tensor4 &t, const ConvW &c, int B, int C0, int stride,
     t.stats_px = 0;
     if (off || !c.use_igemm) return;
     ConvLaunch L;
-    L.w_wino = c.w_wino; L.ks = c.ks; L.stride = stride; L.ups = ups; L.Hout = t.H; L.Wout = t.W; L.Cout = c.cout;
+    L.w_wino = c.w_wino; L.w_wino4 = c.w_wino4; L.ks = c.ks; L.stride = stride; L.ups = ups; L.Hout = t.H; L.Wout = t.W; L.Cout = c.cout;
     L.C0 = C0; L.C1 = c.cin - C0; L.B = B;
     const int px = conv_stats_pixels(L);
     if (px <= 0) return;
@@ -276,6 +277,11 @@ int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 no
             r = relayout_weight_wino(src, c.w_wino, c.cout, c.cin, nullptr);
             if (r != DLPM_OK) return r;
         }
+        if (wino4_enabled() && c.cout % 128 == 0 && c.cin % 8 == 0 && boundary == 0) {   // F(4x4,3x3) copy
+            DLPM_HIP(hipMalloc(&c.w_wino4, (size_t)wino4_weight_floats(c.cout, c.cin) * sizeof(float)));
+            r = relayout_weight_wino4(src, c.w_wino4, c.cout, c.cin, nullptr);
+            if (r != DLPM_OK) return r;
+        }
     }
     return relayout_weight(src, c.w_dev, c.cout, c.cin, c.ks, c.use_igemm, nullptr);
 }
@@ -284,6 +290,7 @@ int run_conv(const ConvW &c, ConvLaunch L, hipStream_t st) {
     L.w = c.w_dev;
     L.w_frag = c.w_frag;
     L.w_wino = c.w_wino;
+    L.w_wino4 = c.w_wino4;
     L.w_small = c.w_small;
     L.ws_gemm = (c.ks == 1 && c.w_frag) ? 1 : 0;
     L.ks = c.ks;
@@ -548,6 +555,8 @@ static void free_conv(ConvW &c) {
     c.w_frag = nullptr;
     if (c.w_wino) (void)hipFree(c.w_wino);
     c.w_wino = nullptr;
+    if (c.w_wino4) (void)hipFree(c.w_wino4);
+    c.w_wino4 = nullptr;
     if (c.w_small) (void)hipFree(c.w_small);
     c.w_small = nullptr;
     c.w_dev = nullptr;
@@ -749,9 +758,17 @@ extern "C" int dlpm_conv2d_f32(const dlpm_conv_args *a, float *scratch_dev, dlpm
             float *ww = scratch_dev + used;
             TRY(relayout_weight_wino(a->weight, ww, a->Cout, a->C0 + a->C1, st));
             L.w_wino = ww;
+            // bit 8: the F(4x4,3x3) kernel where the shape qualifies (its weights go behind the F(2x2) copy)
+            const int64_t used4 = used + wino_weight_floats(a->Cout, a->C0 + a->C1);
+            if ((a->force_direct & 8) && a->Cout % 128 == 0 && (a->C0 + a->C1) % 8 == 0 &&
+                a->scratch_floats >= used4 + wino4_weight_floats(a->Cout, a->C0 + a->C1)) {
+                float *w4 = scratch_dev + used4;
+                TRY(relayout_weight_wino4(a->weight, w4, a->Cout, a->C0 + a->C1, st));
+                L.w_wino4 = w4;
+            }
         }
     }
-    if (!a->force_direct && a->ksize == 3 && a->Cout <= 4 && a->C0 % 32 == 0 && a->C1 == 0) {
+    if (!(a->force_direct & 7) && a->ksize == 3 && a->Cout <= 4 && a->C0 % 32 == 0 && a->C1 == 0) {
         // [tap][cin][4] copy at the END of the scratch buffer (the front holds the layouts built above)
         const int64_t front = (int64_t)a->Cout * a->C0 * 9 + frag_weight_floats(a->Cout, a->C0);
         const int64_t wsz = (int64_t)9 * a->C0 * 4;

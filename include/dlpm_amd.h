@@ -317,7 +317,8 @@ typedef struct dlpm_conv_args {
     int32_t Cout;
     int32_t in_nchw, out_nchw;  /* boundary layouts (direct kernel only) */
     int32_t force_direct;       /* bit 0: use the direct (non-MFMA) kernel regardless of shape; bit 1: no Winograd;
-                                   bit 2: 1x1 through the weight-streaming kernel */
+                                   bit 2: 1x1 through the weight-streaming kernel; bit 3: 3x3 through the
+                                   Winograd F(4x4,3x3) kernel where the shape qualifies (needs scratch for it) */
     int64_t scratch_floats;     /* size of scratch_dev in floats; room for a second, fragment-ordered copy of a
                                    3x3 weight (+1 KB per 32 output channels) enables the weight-streaming kernel */
 } dlpm_conv_args;

@@ -65,7 +65,7 @@ def run_conv(x0, w, bias=None, x1=None, stride=1, ups=0, coef=None, silu=False, 
     out = torch.empty((B, Cout, Hout, Wout) if out_nchw else (B, Hout, Wout, Cout), device=DEV)
     a.out, a.Cout = out.data_ptr(), Cout
     a.in_nchw, a.out_nchw, a.force_direct = int(in_nchw), int(out_nchw), int(force_direct)
-    scratch = torch.empty(5 * w.numel() + 16 * 1024 * (1 + Cout // 32), device=DEV)
+    scratch = torch.empty(9 * w.numel() + 16 * 1024 * (1 + Cout // 32), device=DEV)
     a.scratch_floats = scratch.numel()
     _lib.check(L().dlpm_conv2d_f32(C.byref(a), scratch.data_ptr(), st()))
     torch.cuda.synchronize()
@@ -151,6 +151,44 @@ def test_conv(case):
     if 'igemm' in name:  # same shape through the direct kernel: the two kernels agree with each other
         got_d = run_conv(x0, w, bias, x1, stride, ups, coef, silu, res, force_direct=True)
         assert (got_d - want).abs().max().item() < conv_tol(w, Cin), name + ' (direct)'
+
+
+WINO4_CASES = [
+    # name, B, C0, C1, H (input), Cout, ups, coef+silu, res   -- F(4x4,3x3) kernel (force_direct bit 3)
+    ('f4_16x16_block', 2, 128, 0, 16, 128, 0, False, False),
+    ('f4_32x32_four_blocks_gn_silu_res', 2, 64, 0, 32, 128, 0, True, True),
+    ('f4_concat_cout256', 1, 64, 32, 16, 256, 0, True, False),
+    ('f4_8x8_four_images', 5, 32, 0, 8, 128, 0, True, True),          # B not a multiple of the 4 images per block
+    ('f4_4x4_sixteen_images', 19, 32, 32, 4, 128, 0, False, True),
+    ('f4_upsample_8to16', 2, 32, 0, 8, 128, 1, False, False),
+    ('f4_upsample_16to32_coef_res', 1, 64, 0, 16, 128, 1, True, True),
+    ('f4_upsample_2to4_multiimage', 18, 32, 0, 2, 128, 1, False, False),
+    ('f4_64x64', 1, 32, 0, 64, 128, 0, True, False),
+    ('f4_long_k', 1, 256, 256, 8, 128, 0, True, True),
+]
+
+
+@pytest.mark.parametrize('case', WINO4_CASES, ids=[c[0] for c in WINO4_CASES])
+def test_conv_winograd_f4(case):
+    """F(4x4,3x3): same convolution, larger transform constants -- tolerance 4x the F(2x2) / implicit-GEMM one."""
+    name, B, C0, C1, H, Cout, ups, act, use_res = case
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    Cin = C0 + C1
+    x0 = torch.randn(B, C0, H, H, generator=g)
+    x1 = torch.randn(B, C1, H, H, generator=g) if C1 else None
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    bias = torch.randn(Cout, generator=g)
+    coef = (1 + 0.3 * torch.randn(B, Cin, generator=g), 0.3 * torch.randn(B, Cin, generator=g)) if act else None
+    Ho = H * (2 if ups else 1)
+    res = torch.randn(B, Cout, Ho, Ho, generator=g) if use_res else None
+    want = ref_conv(x0, w, bias, x1, 1, ups, coef, act, res)
+    got = run_conv(x0, w, bias, x1, 1, ups, coef, act, res, force_direct=8)
+    got2 = run_conv(x0, w, bias, x1, 1, ups, coef, act, res)
+    assert got.shape == want.shape
+    e4, e2 = (got - want).abs().max().item(), (got2 - want).abs().max().item()
+    print('%s: F(4x4) err %.2e, default path err %.2e, tol %.2e' % (name, e4, e2, 4 * conv_tol(w, Cin)))
+    assert e4 < 4 * conv_tol(w, Cin), name
+    assert not torch.equal(got, got2), 'the F(4x4) kernel did not run (identical to the default path)'
 
 
 def test_conv_boundary_layouts():

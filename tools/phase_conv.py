@@ -61,7 +61,8 @@ def run(name, B, C0, C1, H, Cout, ks, coef, res, reps=5):
         keep.append(r)
         a.res0, a.R0 = r.data_ptr(), Cout
     a.out, a.Cout = out.data_ptr(), Cout
-    scratch = torch.empty(5 * w.numel() + 16 * 1024 * (1 + Cout // 32), device=DEV)
+    a.force_direct = int(os.environ.get('PHASE_FORCE', '0'))
+    scratch = torch.empty(9 * w.numel() + 16 * 1024 * (1 + Cout // 32), device=DEV)
     a.scratch_floats = scratch.numel()
     st = _lib.stream_ptr()
     ph = (C.c_ulonglong * 32)()
