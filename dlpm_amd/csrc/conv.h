@@ -55,6 +55,7 @@ int relayout_weight_wino(const float *oihw_dev, float *dst_dev, int Cout, int Ci
 // Winograd F(4x4,3x3) path (conv_wino4.hip): 16 tiles of 4x4 outputs x 128 channels per workgroup
 bool wino4_enabled();                  // DLPM_WINO_F4
 bool wino4_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg);
+bool wino4_preferred(const ConvLaunch &c, int *bh, int *bw, int *nimg);   // geometry + dispatch policy
 int launch_conv_wino4(const ConvLaunch &c, hipStream_t st);
 int64_t wino4_weight_floats(int Cout, int Cin);
 int relayout_weight_wino4(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st);

@@ -1085,7 +1085,7 @@ int launch_conv_stem(const ConvLaunch &c, hipStream_t st) {
 
 int conv_stats_pixels(const ConvLaunch &c) {
     int a, b, n;
-    if (wino4_geometry(c, &a, &b, &n)) return n == 1 ? 256 : 0;
+    if (wino4_preferred(c, &a, &b, &n)) return n == 1 ? 256 : 0;
     if (wino_geometry(c, &a, &b, &n)) return n == 1 ? 4 * wino_tiles(c) : 0;
     if (c.out_nchw || (c.Cout & 3) || (c.R0 & 3)) return 0;
     return ((int64_t)c.Hout * c.Wout) % BM == 0 ? BM : 0;
@@ -1106,7 +1106,7 @@ int launch_conv_igemm(const ConvLaunch &c, hipStream_t st) {
         snprintf(pname, sizeof(pname), "%s", c.ks == 3 ? (halo_ok(c, &th, &nimg) ? "conv3x3_halo" : "conv3x3_igemm") : "conv1x1_igemm");
     {
         int wb, ww, wi;
-        if (wino4_geometry(c, &wb, &ww, &wi)) {
+        if (wino4_preferred(c, &wb, &ww, &wi)) {
             if (prof_enabled() && prof_detail())
                 snprintf(pname, sizeof(pname), "conv3x3_wino4:H%d:Cin%d+%d:Cout%d:u%d:coef%d", c.Hout, c.C0, c.C1, c.Cout, c.ups, c.coefA ? 1 : 0);
             else

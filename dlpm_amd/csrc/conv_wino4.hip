@@ -92,11 +92,14 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
     const int rpi = RH * RW, npix = nimg * rpi;
 
     // ---- raw staging: item = (pixel, channel quad of the phase)
+    // (the second item of a thread runs over the threads in REVERSE order: a 324-pixel patch has 68 pixels beyond the first
+    //  256, and waves 0..2, which also run the input transform, are the last to get one of those)
     const int squad = tid & 1;
+    auto pix_of = [&](int it) { return it == 1 ? (F4_NT / 2) + ((F4_NT - 1 - tid) >> 1) : it * (F4_NT / 2) + (tid >> 1); };
     int off[F4_QNIT], cfo[F4_QNIT];
 #pragma unroll
     for (int it = 0; it < F4_QNIT; it++) {
-        const int pix = it * (F4_NT / 2) + (tid >> 1);
+        const int pix = pix_of(it);
         const int img = min(pix / rpi, nimg - 1), r = pix - img * rpi;
         const int ry = r / RW, rx = r - ry * RW;
         const int iy = oy + ry, ix = ox + rx;
@@ -142,7 +145,7 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
             x.w = silu_f(x.w);
         }
         if (off[it] < 0) x = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding applies AFTER the activation
-        *reinterpret_cast<float4 *>(rb + (it * (F4_NT / 2) + (tid >> 1)) * F4_PRLD + squad * 4) = x;
+        *reinterpret_cast<float4 *>(rb + pix_of(it) * F4_PRLD + squad * 4) = x;
     };
     auto store_raw = [&](int slot) {
 #pragma unroll
@@ -211,8 +214,9 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
     };
 
     // ---- weight stream of this wave: Wf[ntile][wave][phase][18 position pairs][lane][4], contiguous per wave
-    const float4 *__restrict__ wbase = reinterpret_cast<const float4 *>(p.w_wino4) + lane;
-    int64_t woff = (int64_t)((n0 >> 7) * 8 + wave) * nch * 18 * 64;
+    // (wave-uniform pointer + lane: the per-fragment advance is scalar arithmetic)
+    const float4 *__restrict__ wp = reinterpret_cast<const float4 *>(p.w_wino4) +
+                                    (int64_t)((n0 >> 7) * 8 + __builtin_amdgcn_readfirstlane(wave)) * nch * 18 * 64;
     constexpr int AHEAD = F4_RING - 1;
     float4 bq[F4_RING];
     // A fragments: lane (li = tile, lk) reads channels 2 lk, 2 lk + 1 of the phase = k index lk of the two k-steps
@@ -236,7 +240,7 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
         cfr2 = *reinterpret_cast<const float4 *>(cf_base + min(2, last) * F4_KC);
     }
 #pragma unroll
-    for (int a = 0; a < AHEAD; a++) bq[a] = wbase[woff + a * 64];
+    for (int a = 0; a < AHEAD; a++) bq[a] = wp[a * 64 + lane];
     store_coef(0);
     cfr = cfr1;
     store_coef(1);
@@ -262,8 +266,8 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
             if (pp >= F4_S0 && pp < F4_S0 + F4_QNIT) store_raw_item(cur, pp - F4_S0);   // S(chunk+2): raw[cur] was read by X(chunk), a barrier ago
             if (pp == F4_S0 + F4_QNIT) load_raw_into(xr, min(chunk + 3, last));        // G(chunk+3)
             if (pp == F4_X) transform(nxt);                                             // X(chunk+1): raw[nxt] -> V[nxt]
-            bq[(pp + AHEAD) % F4_RING] = wbase[woff + AHEAD * 64];
-            woff += 64;
+            bq[(pp + AHEAD) % F4_RING] = wp[AHEAD * 64 + lane];
+            wp += 64;
             const float2 a0 = *reinterpret_cast<const float2 *>(ab + (2 * pp) * F4_TILES * F4_KC);
             const float2 a1 = *reinterpret_cast<const float2 *>(ab + (2 * pp + 1) * F4_TILES * F4_KC);
             const float4 b = bq[pp % F4_RING];
@@ -457,6 +461,13 @@ bool wino4_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
     if (n * RH * RW > F4_RAWPIX) return false;
     *bh = h; *bw = w; *nimg = n;
     return true;
+}
+
+// dispatch policy: F(4x4) wherever it applies, except blocks of 16 one-tile images (4x4-pixel tensors) when the F(2x2)
+// weights are there too: those stage 576 halo pixels per 256 outputs and measured slower (1.55 vs 1.00 ms/step)
+bool wino4_preferred(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
+    if (!wino4_geometry(c, bh, bw, nimg)) return false;
+    return *nimg <= 4 || !c.w_wino;
 }
 
 int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {

@@ -765,6 +765,7 @@ extern "C" int dlpm_conv2d_f32(const dlpm_conv_args *a, float *scratch_dev, dlpm
                 float *w4 = scratch_dev + used4;
                 TRY(relayout_weight_wino4(a->weight, w4, a->Cout, a->C0 + a->C1, st));
                 L.w_wino4 = w4;
+                L.w_wino = nullptr;   // no F(2x2) alternative: every qualifying geometry takes the F(4x4) kernel
             }
         }
     }
