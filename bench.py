@@ -193,12 +193,18 @@ def main():
         _lib.check(L.dlpm_prof_enable(0))
         prof = parse_prof(buf.value.decode())
         breakdown = {k: round(v['ms'] / nprof, 4) for k, v in prof.items()}
-        wino = prof.get('conv3x3_wino')
-        c = wino or prof.get('conv3x3_halo') or prof.get('conv3x3_igemm')
+        wino4, wino = prof.get('conv3x3_wino4'), prof.get('conv3x3_wino')
+        c = wino4 or wino or prof.get('conv3x3_halo') or prof.get('conv3x3_igemm')
         if c:
             ach = c['flops'] / (c['ms'] * 1e-3) / 1e12
-            if wino:
-                kname = 'k_conv3x3_wino_q'
+            executed = None
+            if wino4:
+                kname, executed = 'k_conv3x3_wino4', 36.0 / 144.0
+                kdesc = ('k_conv3x3_wino4 (3x3 stride-1 conv as Winograd F(4x4,3x3) on the fp32 MFMA 16x16x4: 36 instead of 144 '
+                         'multiplies per 4x4 output tile and channel pair; fused GN+SiLU staging, in-register output transform, '
+                         'bias/residual/GN-stats epilogue)')
+            elif wino:
+                kname, executed = 'k_conv3x3_wino_q', 16.0 / 36.0
                 kdesc = ('k_conv3x3_wino_q (3x3 stride-1 conv as Winograd F(2x2,3x3) on the fp32 MFMA 32x32x2: 16 instead of 36 '
                          'multiplies per 2x2 output tile and channel pair; fused GN+SiLU staging, in-register output transform, '
                          'bias/residual/GN-stats epilogue)')
@@ -216,14 +222,14 @@ def main():
                             share_of_step_ms=round(c['ms'] / nprof, 3),
                             all_mfma_conv_classes_tflops=round(sum(v['flops'] for k, v in prof.items() if k.startswith('conv') and 'stem' not in k and 'direct' not in k)
                                                                / (sum(v['ms'] for k, v in prof.items() if k.startswith('conv') and 'stem' not in k and 'direct' not in k) * 1e-3) / 1e12, 3))
-            if wino:
+            if executed:
                 # `achieved` counts ALGORITHMIC flops (2*9*Cin*Cout per output pixel, the direct-convolution count of
-                # SURVEY 8d); the Winograd kernel executes 16/36 of them on the matrix pipe, so `frac` can exceed 1:
-                # the MFMA pipe's own utilisation is reported next to it
-                roofline['mfma_executed_tflops'] = round(ach * 16.0 / 36.0, 3)
-                roofline['mfma_utilisation'] = round(ach * 16.0 / 36.0 / PEAK_FP32_MFMA_TFLOPS, 4)
-                roofline['note'] = ('achieved = algorithmic (direct-convolution) FLOP/s; F(2x2,3x3) executes 16/36 of them, '
-                                    'mfma_utilisation = executed MFMA FLOP/s over the fp32 MFMA peak')
+                # SURVEY 8d); a Winograd kernel executes a fraction of them on the matrix pipe (36/144 for F(4x4,3x3),
+                # 16/36 for F(2x2,3x3)), so `frac` can exceed 1: the MFMA pipe's own utilisation is reported next to it
+                roofline['mfma_executed_tflops'] = round(ach * executed, 3)
+                roofline['mfma_utilisation'] = round(ach * executed / PEAK_FP32_MFMA_TFLOPS, 4)
+                roofline['note'] = ('achieved = algorithmic (direct-convolution) FLOP/s; the Winograd kernel executes %.4f of them on '
+                                    'the matrix pipe, mfma_utilisation = executed MFMA FLOP/s over the fp32 MFMA peak' % executed)
         at = prof.get('attention')
         if at and at['ms'] > 0:
             tf = at['flops'] / (at['ms'] * 1e-3) / 1e12

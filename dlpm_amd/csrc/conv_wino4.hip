@@ -58,7 +58,9 @@ __device__ __forceinline__ float2 f2fma(float a, float2 x, float2 y) { return ma
 __device__ __forceinline__ float2 f2add(float2 x, float2 y) { return make_float2(x.x + y.x, x.y + y.y); }
 __device__ __forceinline__ float2 f2sub(float2 x, float2 y) { return make_float2(x.x - y.x, x.y - y.y); }
 
-template <bool UPS>
+// ABL (DLPM_WINO_ABLATIONS builds, DLPM_WABL): timing-only ablations, results are wrong: 1 no staging stores, 2 no transform,
+// 4 no raw loads, 8 no barrier, 16 no weight loads, 32 no MFMA, 64 no A-fragment reads
+template <bool UPS, int ABL = 0>
 __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh, int bw, int nimg) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float *V = wsm;                               // [2][36][16][8]
@@ -263,22 +265,31 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
         load_coef(min(chunk + 3, last));
 #pragma unroll
         for (int pp = 0; pp < 18; pp++) {
-            if (pp >= F4_S0 && pp < F4_S0 + F4_QNIT) store_raw_item(cur, pp - F4_S0);   // S(chunk+2): raw[cur] was read by X(chunk), a barrier ago
-            if (pp == F4_S0 + F4_QNIT) load_raw_into(xr, min(chunk + 3, last));        // G(chunk+3)
-            if (pp == F4_X) transform(nxt);                                             // X(chunk+1): raw[nxt] -> V[nxt]
-            bq[(pp + AHEAD) % F4_RING] = wp[AHEAD * 64 + lane];
+            if (!(ABL & 1) && pp >= F4_S0 && pp < F4_S0 + F4_QNIT) store_raw_item(cur, pp - F4_S0);   // S(chunk+2): raw[cur] was read by X(chunk), a barrier ago
+            if (!(ABL & 4) && pp == F4_S0 + F4_QNIT) load_raw_into(xr, min(chunk + 3, last));        // G(chunk+3)
+            if (!(ABL & 2) && pp == F4_X) transform(nxt);                                             // X(chunk+1): raw[nxt] -> V[nxt]
+            if (!(ABL & 16)) bq[(pp + AHEAD) % F4_RING] = wp[AHEAD * 64 + lane];
             wp += 64;
-            const float2 a0 = *reinterpret_cast<const float2 *>(ab + (2 * pp) * F4_TILES * F4_KC);
-            const float2 a1 = *reinterpret_cast<const float2 *>(ab + (2 * pp + 1) * F4_TILES * F4_KC);
+            float2 a0 = make_float2(1.f, 2.f), a1 = a0;
+            if (!(ABL & 64)) {
+                a0 = *reinterpret_cast<const float2 *>(ab + (2 * pp) * F4_TILES * F4_KC);
+                a1 = *reinterpret_cast<const float2 *>(ab + (2 * pp + 1) * F4_TILES * F4_KC);
+            }
             const float4 b = bq[pp % F4_RING];
+            if (!(ABL & 32)) {
             acc[2 * pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc[2 * pp], 0, 0, 0);
             acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.z, acc[2 * pp + 1], 0, 0, 0);
             acc[2 * pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc[2 * pp], 0, 0, 0);
             acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.w, acc[2 * pp + 1], 0, 0, 0);
+            } else {
+                acc[2 * pp][0] += a0.x * b.x + a0.y * b.y;   // keep the operands alive
+                acc[2 * pp + 1][0] += a1.x * b.z + a1.y * b.w;
+            }
         }
         store_coef(nxt);
-        __syncthreads();
+        if (!(ABL & 8)) __syncthreads();
     }
+    if (ABL & 8) __syncthreads();
     DLPM_PHASE(p, 9);
 
     // ---- epilogue.  Thread (c4, rg) of the streaming pass owns channel quad c4 and position (i, j) = (rg >> 2, rg & 3)
@@ -431,9 +442,9 @@ __global__ void k_relayout_weight_wino4(const float *oihw, float *dst, int Cout,
     dst[i] = (float)u;
 }
 
-int f4_mode() {   // DLPM_WINO_F4: 0 never, 1 wherever the shape qualifies
+int f4_mode() {   // DLPM_WINO_F4=0: keep every 3x3 layer on the F(2x2,3x3) kernel (default: F(4x4) where the shape qualifies)
     static int v = -1;
-    if (v < 0) { const char *e = getenv("DLPM_WINO_F4"); v = e ? atoi(e) : 0; }
+    if (v < 0) { const char *e = getenv("DLPM_WINO_F4"); v = e ? atoi(e) : 1; }
     return v;
 }
 
@@ -481,10 +492,32 @@ int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
 #endif
     using KFn = void (*)(ConvLaunch, int, int, int);
     KFn fn = c.ups ? &k_conv3x3_wino4<true> : &k_conv3x3_wino4<false>;
-    static bool configured[2] = {false, false};   // (the first launch of each kernel is eager, never inside a graph capture)
-    if (!configured[c.ups ? 1 : 0]) {
+#ifdef DLPM_WINO_ABLATIONS
+    static int abl = -1;
+    if (abl < 0) { const char *e = getenv("DLPM_WABL"); abl = e ? atoi(e) : 0; }
+    if (!c.ups) {
+        switch (abl) {
+            case 1: fn = &k_conv3x3_wino4<false, 1>; break;
+            case 2: fn = &k_conv3x3_wino4<false, 2>; break;
+            case 3: fn = &k_conv3x3_wino4<false, 3>; break;
+            case 7: fn = &k_conv3x3_wino4<false, 7>; break;
+            case 8: fn = &k_conv3x3_wino4<false, 8>; break;
+            case 16: fn = &k_conv3x3_wino4<false, 16>; break;
+            case 32: fn = &k_conv3x3_wino4<false, 32>; break;
+            case 64: fn = &k_conv3x3_wino4<false, 64>; break;
+            case 80: fn = &k_conv3x3_wino4<false, 80>; break;
+            case 87: fn = &k_conv3x3_wino4<false, 87>; break;
+            default: break;
+        }
+    }
+#endif
+    static const void *configured[16] = {nullptr};   // (the first launch of each kernel is eager, never inside a graph capture)
+    bool seen = false;
+    for (const void *q : configured) seen = seen || q == reinterpret_cast<const void *>(fn);
+    if (!seen) {
         DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured[c.ups ? 1 : 0] = true;
+        for (auto &q : configured)
+            if (!q) { q = reinterpret_cast<const void *>(fn); break; }
     }
     const size_t loop_b = (size_t)(2 * F4_VBUF + 2 * F4_RAWPIX * F4_PRLD + 2 * F4_CFS) * sizeof(float);
     const size_t epi_b = (size_t)(16 * F4_TILES * F4_ELD + 64) * sizeof(float);
