@@ -43,11 +43,15 @@ constexpr int F4_RING = 6;        // weight fragments (float4 = 2 positions x 2 
 constexpr int F4_ELD = F4_NQ + 4; // row image pitch
 constexpr int F4_PAD = 8;         // float4 fragments of zero padding behind the weights (ring read-ahead of the last phase)
 
+#ifndef F4_AAHEAD
+#define F4_AAHEAD 1   // A-fragment read-ahead (position pairs); 2 spills three registers inside the phase loop
+#endif
 #ifndef F4_S0
-#define F4_S0 3    // position pair behind which the staging stores start
+#define F4_S0 5    // position pair behind which the staging stores start
 #endif
 #ifndef F4_X
-#define F4_X 9     // position pair behind which waves 0..2 run the input transform
+#define F4_X 13    // position pair behind which waves 0..2 run the input transform (placement sweep, DLPM_BUILD_DEFS="F4_S0=..
+                   // F4_X=..": X = 13 is 3-8 % faster than 3, 9, 11, 12, 14..17 for every S0; S0 = 3, 5, 7 are within 0.5 %)
 #endif
 
 // one line of B^T d (or of T B): the six transform rows from six samples x0..x5
@@ -263,6 +267,13 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
         const int cur = chunk & 1, nxt = cur ^ 1;
         const float *ab = asrc + cur * F4_VBUF;
         load_coef(min(chunk + 3, last));
+        float2 aq[F4_AAHEAD + 1][2];
+#pragma unroll
+        for (int a = 0; a < F4_AAHEAD; a++) {
+            aq[a][0] = (ABL & 64) ? make_float2(1.f, 2.f) : *reinterpret_cast<const float2 *>(ab + (2 * a) * F4_TILES * F4_KC);
+            aq[a][1] = (ABL & 64) ? make_float2(1.f, 2.f) : *reinterpret_cast<const float2 *>(ab + (2 * a + 1) * F4_TILES * F4_KC);
+        }
+        if (ABL & 64) aq[F4_AAHEAD][0] = aq[F4_AAHEAD][1] = make_float2(1.f, 2.f);
 #pragma unroll
         for (int pp = 0; pp < 18; pp++) {
             if (!(ABL & 1) && pp >= F4_S0 && pp < F4_S0 + F4_QNIT) store_raw_item(cur, pp - F4_S0);   // S(chunk+2): raw[cur] was read by X(chunk), a barrier ago
@@ -270,11 +281,13 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
             if (!(ABL & 2) && pp == F4_X) transform(nxt);                                             // X(chunk+1): raw[nxt] -> V[nxt]
             if (!(ABL & 16)) bq[(pp + AHEAD) % F4_RING] = wp[AHEAD * 64 + lane];
             wp += 64;
-            float2 a0 = make_float2(1.f, 2.f), a1 = a0;
-            if (!(ABL & 64)) {
-                a0 = *reinterpret_cast<const float2 *>(ab + (2 * pp) * F4_TILES * F4_KC);
-                a1 = *reinterpret_cast<const float2 *>(ab + (2 * pp + 1) * F4_TILES * F4_KC);
+            // A fragments are read F4_AAHEAD position pairs ahead (left to the compiler each ds_read sat directly in
+            // front of its MFMAs with an s_waitcnt lgkmcnt(0) between them)
+            if (!(ABL & 64) && pp + F4_AAHEAD < 18) {
+                aq[(pp + F4_AAHEAD) % (F4_AAHEAD + 1)][0] = *reinterpret_cast<const float2 *>(ab + (2 * (pp + F4_AAHEAD)) * F4_TILES * F4_KC);
+                aq[(pp + F4_AAHEAD) % (F4_AAHEAD + 1)][1] = *reinterpret_cast<const float2 *>(ab + (2 * (pp + F4_AAHEAD) + 1) * F4_TILES * F4_KC);
             }
+            const float2 a0 = aq[pp % (F4_AAHEAD + 1)][0], a1 = aq[pp % (F4_AAHEAD + 1)][1];
             const float4 b = bq[pp % F4_RING];
             if (!(ABL & 32)) {
             acc[2 * pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc[2 * pp], 0, 0, 0);
