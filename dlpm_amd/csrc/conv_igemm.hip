@@ -919,6 +919,10 @@ __global__ void __launch_bounds__(256) k_conv_stem_regw(ConvLaunch p, int ppb) {
     for (int k = 0; k < 9 * CIN; k++) w[k] = reinterpret_cast<const float4 *>(p.w + (int64_t)k * p.Cout)[nq];
     const float4 bias = reinterpret_cast<const float4 *>(p.bias)[nq];
     const int64_t m_lo = (int64_t)blockIdx.x * ppb;
+    // fused GroupNorm statistics of the output (launcher: only when an image is a whole number of blocks): every thread
+    // keeps shifted sums for its 4 channels over its ppb / pl_n pixels
+    const bool do_stats = p.stats_out != nullptr;
+    float4 K = make_float4(0.f, 0.f, 0.f, 0.f), s1 = K, s2 = K;
     for (int it = 0; it < ppb / pl_n; it++) {
         const int64_t m = m_lo + it * pl_n + pl;
         if (m >= M) break;
@@ -948,6 +952,35 @@ __global__ void __launch_bounds__(256) k_conv_stem_regw(ConvLaunch p, int ppb) {
             acc.w = fmaf(v[k], w[k].w, acc.w);
         }
         reinterpret_cast<float4 *>(p.out + m * p.Cout)[nq] = acc;
+        if (do_stats) {
+            if (it == 0) K = acc;  // pivot = this thread's first value per channel
+            float d;
+            d = acc.x - K.x; s1.x += d; s2.x = fmaf(d, d, s2.x);
+            d = acc.y - K.y; s1.y += d; s2.y = fmaf(d, d, s2.y);
+            d = acc.z - K.z; s1.z += d; s2.z = fmaf(d, d, s2.z);
+            d = acc.w - K.w; s1.w += d; s2.w = fmaf(d, d, s2.w);
+        }
+    }
+    if (do_stats) {   // per-thread (mean, M2) -> LDS [pl_n][Cout] -> threads < Cout merge the pl_n partials (Chan)
+        __shared__ float2 part[1024];
+        const float fc = (float)(ppb / pl_n);
+        const float mx = s1.x / fc, my = s1.y / fc, mz = s1.z / fc, mw = s1.w / fc;
+        part[pl * p.Cout + nq * 4 + 0] = make_float2(K.x + mx, fmaxf(s2.x - s1.x * mx, 0.f));
+        part[pl * p.Cout + nq * 4 + 1] = make_float2(K.y + my, fmaxf(s2.y - s1.y * my, 0.f));
+        part[pl * p.Cout + nq * 4 + 2] = make_float2(K.z + mz, fmaxf(s2.z - s1.z * mz, 0.f));
+        part[pl * p.Cout + nq * 4 + 3] = make_float2(K.w + mw, fmaxf(s2.w - s1.w * mw, 0.f));
+        __syncthreads();
+        if ((int)threadIdx.x < p.Cout) {
+            float mean = part[threadIdx.x].x, M2 = part[threadIdx.x].y, na = fc;
+            for (int g = 1; g < pl_n; g++) {
+                const float2 q = part[g * p.Cout + threadIdx.x];
+                const float d = q.x - mean, N = na + fc;
+                mean += d * (fc / N);
+                M2 += q.y + d * d * (na * fc / N);
+                na = N;
+            }
+            p.stats_out[(int64_t)blockIdx.x * p.Cout + threadIdx.x] = make_float2(mean, M2);
+        }
     }
 }
 
@@ -1067,6 +1100,13 @@ static int launch_halo(const ConvLaunch &c, int th, int nimg, int64_t grid, hipS
     return DLPM_OK;
 }
 
+// the register-weight stem kernel emits one partial per 1024-pixel block
+static bool stem_stats_ok(const ConvLaunch &c) {
+    const int Cq = c.Cout / 4;
+    return c.in_nchw && !c.out_nchw && c.ks == 3 && c.stride == 1 && !c.ups && c.C1 == 0 && (c.C0 == 3 || c.C0 == 1) && c.Cout % 4 == 0 &&
+           Cq >= 1 && Cq <= 256 && (Cq & (Cq - 1)) == 0 && ((int64_t)c.Hout * c.Wout) % 1024 == 0;
+}
+
 int launch_conv_stem(const ConvLaunch &c, hipStream_t st) {
     const int64_t total = (int64_t)c.B * c.Hout * c.Wout * (c.Cout / 4);
     ProfScope ps("conv_stem", 2.0 * total * 4 * c.C0 * 9, 4.0 * ((double)c.B * c.Hin * c.Win * c.C0 + total * 4.0), st);
@@ -1074,6 +1114,10 @@ int launch_conv_stem(const ConvLaunch &c, hipStream_t st) {
     const bool regw = Cq >= 1 && Cq <= 256 && (Cq & (Cq - 1)) == 0;   // power-of-two channel quads
     const int64_t Mpix = (int64_t)c.B * c.Hout * c.Wout;
     const int ppb = 1024;                                              // pixels per block
+    if (c.stats_out && !stem_stats_ok(c)) {
+        set_error("launch_conv_stem: statistics requested for a shape that cannot emit them");
+        return DLPM_ERR_UNSUPPORTED;
+    }
     if (c.C0 == 3 && regw) k_conv_stem_regw<3><<<(unsigned)ceil_div(Mpix, ppb), 256, 0, st>>>(c, ppb);
     else if (c.C0 == 1 && regw) k_conv_stem_regw<1><<<(unsigned)ceil_div(Mpix, ppb), 256, 0, st>>>(c, ppb);
     else if (c.C0 == 3) k_conv_stem<3><<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(c);
@@ -1085,6 +1129,7 @@ int launch_conv_stem(const ConvLaunch &c, hipStream_t st) {
 
 int conv_stats_pixels(const ConvLaunch &c) {
     int a, b, n;
+    if (c.in_nchw) return stem_stats_ok(c) ? 1024 : 0;
     if (wino4_preferred(c, &a, &b, &n)) return n == 1 ? 256 : 0;
     if (wino_geometry(c, &a, &b, &n)) return n == 1 ? 4 * wino_tiles(c) : 0;
     if (c.out_nchw || (c.Cout & 3) || (c.R0 & 3)) return 0;

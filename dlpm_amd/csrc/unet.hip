@@ -80,15 +80,16 @@ struct Bump {
 // GroupNorm statistics can ride on the producing conv's epilogue when its pixel tiles stay inside one image
 // and the conv runs on the MFMA kernels with the row epilogue.  Decides (at plan time) whether `t`, produced by
 // conv `c` with the given geometry, carries statistics, and allocates them: tile size per conv_stats_pixels.
-void plan_stats(Bump &ws, Tensor4 &t, const ConvW &c, int B, int C0, int stride, int ups) {
+void plan_stats(Bump &ws, Tensor4 &t, const ConvW &c, int B, int C0, int stride, int ups, bool stem = false) {
     static int off = -1;
     if (off < 0) { const char *e = getenv("DLPM_NO_GN_FUSION"); off = (e && e[0] == '1') ? 1 : 0; }
     t.stats = nullptr;
     t.stats_px = 0;
-    if (off || !c.use_igemm) return;
+    if (off || (!c.use_igemm && !stem)) return;
     ConvLaunch L;
     L.w_wino = c.w_wino; L.w_wino4 = c.w_wino4; L.ks = c.ks; L.stride = stride; L.ups = ups; L.Hout = t.H; L.Wout = t.W; L.Cout = c.cout;
     L.C0 = C0; L.C1 = c.cin - C0; L.B = B;
+    L.in_nchw = stem ? 1 : 0;
     const int px = conv_stats_pixels(L);
     if (px <= 0) return;
     t.stats_px = px;
@@ -389,10 +390,11 @@ int run_seq(Ctx &cx, const std::vector<Layer> &seq, Tensor4 x0, Tensor4 x1, cons
                 const int S = u->cfg.image_size;
                 o.C = L.cout; o.H = S; o.W = S;
                 o.p = cx.ws.alloc((int64_t)B * S * S * L.cout);
+                plan_stats(cx.ws, o, L.c1, B, L.cin, 1, 0, true);
                 if (!cx.dry()) {
                     ConvLaunch a;
                     a.src0 = x_nchw; a.C0 = L.cin; a.B = B; a.Hin = a.Hout = S; a.Win = a.Wout = S;
-                    a.bias = u->params[L.c1.p_b].dev; a.out = o.p; a.in_nchw = 1;
+                    a.bias = u->params[L.c1.p_b].dev; a.out = o.p; a.in_nchw = 1; a.stats_out = o.stats;
                     TRY(run_conv(L.c1, a, cx.st));
                 }
                 break;
