@@ -42,8 +42,8 @@ METRIC = {
 # FETCH_SIZE doubled per the gfx950 guide): profiles/r01/pmc_hbm_traffic_*.txt
 PMC_TRAFFIC_BYTES_PER_LAUNCH = {'k_conv3x3_halo_ws<128,2,2,2,2,2>': (0.6663 + 0.2194) * 1e9,  # fetch + write, mean over all three instantiations
                                 'k_conv3x3_wino_q': (0.7141 + 0.2238) * 1e9,   # fetch + write, mean over both instantiations (47 launches/step), v14
-                                'k_conv3x3_wino4': (1.0422 + 0.3134) * 1e9}    # fetch + write, mean over both instantiations (33 launches/step)
-PMC_TRAFFIC_FILE = 'profiles/r01/pmc_hbm_traffic_v17.txt'
+                                'k_conv3x3_wino4': (1.0377 + 0.3134) * 1e9}    # fetch + write, mean over both instantiations (33 launches/step)
+PMC_TRAFFIC_FILE = 'profiles/r01/pmc_hbm_traffic_v18.txt'
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 PEAK_HBM_GBS = 8000.0
 
