@@ -6,9 +6,10 @@
 //
 //     Y = A^T [ (G g G^T) .* (B^T d B) ] A        d: 6x6 input tile, g: 3x3 filter, Y: 4x4 output tile
 //
-// with the transform matrices of Lavin & Gray (interpolation points 0, +-1, +-2, inf) -- see bt_rows() / at_rows().
+// with the transform matrices of Lavin & Gray (interpolation points 0, +-1, +-2, inf): rows of B^T above transform(),
+// rows of A^T in the epilogue, G in k_relayout_weight_wino4.
 // The price is numerical: the transforms amplify rounding (|B^T| rows sum to 10, |A^T| to 19); through the whole CIFAR
-// UNet the result differs from the fp32 reference by 1.5e-5 (F(2x2): 3e-6; the path's budget is 1e-4).
+// UNet the result differs from the reference's own output by 1.6e-5 (F(2x2): 3e-6; the path's budget is 1e-4).
 //
 // Work split (one workgroup per CU, 8 waves, 16 tiles x 128 output channels):
 //   * the 36 transform positions are 36 independent GEMMs  M_pos[tile][cout] = sum_cin V_pos[tile][cin] U_pos[cin][cout];
