@@ -42,6 +42,27 @@ def test_unet_forward_matches_reference(name):
     assert np.abs(y2 - f['y_same_t']).max() < 1e-4
 
 
+@pytest.mark.parametrize('env,bound', [({'DLPM_WINO_F4': '0'}, 1e-5), ({'DLPM_WINO_F4': '0', 'DLPM_NO_WINO': '1'}, 1e-5),
+                                       ({}, 5e-5)], ids=['winograd_f2x2_only', 'implicit_gemm_only', 'default_f4x4'])
+def test_unet_every_convolution_generation_against_reference(env, bound):
+    """The kernel choice is read once per process, so each generation runs in a child process (tools/err_report.py):
+    CIFAR UNet vs the reference's own output.  Observed: F(4x4) 1.6e-5, F(2x2) 3e-6, implicit GEMM 4.4e-6."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'err_report.py')], env=e, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    errs = {m.group(1): float(m.group(2)) for m in re.finditer(r'(\w+)\s+max \|hip - reference\| = ([0-9.e+-]+)', out.stdout)}
+    assert set(errs) == {'tiny', 'tiny2', 'mnist', 'cifar'}, out.stdout
+    assert errs['cifar'] < bound, errs
+    assert max(errs[k] for k in ('tiny', 'tiny2', 'mnist')) < 5e-6, errs   # no layer of these nets takes F(4x4)
+
+
 def test_unet_tiny_every_block_against_reference_features():
     f = golden('f6_unet_tiny')
     net, _ = build_unet('tiny')
