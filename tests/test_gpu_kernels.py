@@ -191,6 +191,44 @@ def test_conv_winograd_f4(case):
     assert not torch.equal(got, got2), 'the F(4x4) kernel did not run (identical to the default path)'
 
 
+def test_conv_winograd_f4_full_size_batch_independence():
+    """BASELINE size (CIFAR step: B = 1024, 32x32, 128 -> 128 channels, GN+SiLU, residual) through a size-independent
+    property: the F(4x4) kernel's blocks never span images here, so every image of the big batch must come out
+    bit-identical to the same image convolved alone, and the result must match the fp64 reference on those images."""
+    B, Cc, H = 1024, 128, 32
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(B, H, H, Cc, device=DEV, generator=g)                      # NHWC
+    w = torch.randn(Cc, Cc, 3, 3, device=DEV, generator=g) / math.sqrt(Cc * 9)
+    bias = torch.randn(Cc, device=DEV, generator=g)
+    cA = 1 + 0.3 * torch.randn(B, Cc, device=DEV, generator=g)
+    cB = 0.3 * torch.randn(B, Cc, device=DEV, generator=g)
+    res = torch.randn(B, H, H, Cc, device=DEV, generator=g)
+    scratch = torch.empty(9 * w.numel() + 16 * 1024 * (1 + Cc // 32), device=DEV)
+
+    def conv(sl):
+        n = sl.stop - sl.start
+        out = torch.empty(n, H, H, Cc, device=DEV)
+        a = _lib.ConvArgs()
+        xs, As, Bs, rs = x[sl].contiguous(), cA[sl].contiguous(), cB[sl].contiguous(), res[sl].contiguous()
+        a.src0, a.C0, a.B, a.Hin, a.Win, a.Hout, a.Wout = xs.data_ptr(), Cc, n, H, H, H, H
+        a.ksize, a.stride, a.weight, a.bias = 3, 1, w.data_ptr(), bias.data_ptr()
+        a.coefA, a.coefB, a.act_silu = As.data_ptr(), Bs.data_ptr(), 1
+        a.res0, a.R0, a.out, a.Cout = rs.data_ptr(), Cc, out.data_ptr(), Cc
+        a.force_direct, a.scratch_floats = 8, scratch.numel()
+        _lib.check(L().dlpm_conv2d_f32(C.byref(a), scratch.data_ptr(), st()))
+        torch.cuda.synchronize()
+        return out
+
+    full = conv(slice(0, B))
+    assert torch.isfinite(full).all()
+    for b in (0, 517, 1023):
+        one = conv(slice(b, b + 1))
+        assert torch.equal(one[0], full[b]), 'image %d depends on its batch' % b
+        xb = nchw(x[b:b + 1]).cpu()
+        want = ref_conv(xb, w.cpu(), bias.cpu(), coef=(cA[b:b + 1].cpu(), cB[b:b + 1].cpu()), silu=True, res=nchw(res[b:b + 1]).cpu())
+        assert (nchw(full[b:b + 1]).cpu() - want).abs().max().item() < 4 * conv_tol(w, Cc)
+
+
 def test_conv_boundary_layouts():
     g = torch.Generator().manual_seed(4)
     x = torch.randn(2, 3, 8, 8, generator=g)
