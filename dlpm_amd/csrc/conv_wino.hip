@@ -5,20 +5,20 @@
 //     Y = A^T [ sum_c (G g_c G^T) . (B^T d_c B) ] A          (Lavin & Gray, arXiv:1509.09308, F(2x2,3x3))
 // In GEMM form: for each of the 16 transform positions p,  M_p[tile, cout] = sum_cin V_p[tile, cin] U_p[cin, cout].
 //
-// One workgroup = 64 output tiles (256 pixels: a bh x bw block of 2x2 tiles in nimg images) x 64 output channels,
-// ALL 16 positions, i.e. a 256-KB accumulator block -- half of the CU's register file -- held by 4 waves with
-// 16 x (32x32) MFMA accumulators each (1 wave per SIMD).  Because a wave owns every position of its
-// (32 tiles x 32 channels) sub-block, the output transform happens in registers: no cross-wave reduction.
-// Per 16-channel chunk of the input:
-//   1. the raw halo patch (<= 576 pixels x 16 channels) is loaded to registers one MFMA phase ahead and stored to
-//      LDS with the fused GroupNorm affine + SiLU applied once per element (zero padding = zeros AFTER activation);
-//      virtual concat and nearest-x2 upsampling are address arithmetic, as in the halo kernel;
-//   2. 256 threads (tile, channel quad) compute V = B^T d B (32 adds per channel) into LDS [16][64][20];
-//   3. each wave runs 16 positions x 8 k-steps of v_mfma_f32_32x32x2_f32: A fragments by ds_read_b128 from V (rows
-//      padded to 20 floats: conflict-free), B fragments (U, pre-transformed at finalize and stored in fragment
-//      order) streamed straight from L2 into a 4-deep register ring, exactly as in k_conv3x3_halo_ws.
-// Two workgroup barriers per chunk.  Numerics: fp32 throughout; F(2x2,3x3)'s transforms only add and halve, the
-// measured deviation from the direct convolution through the whole CIFAR UNet is 2e-6 (tolerance 1e-4).
+// Since conv_wino4.hip (F(4x4,3x3)) took over the layers at 8x8 pixels and above with Cout % 128 == 0, this kernel
+// serves what that one does not: 4x4-pixel tensors and Cout = 64 (MNIST / toy nets).  Two earlier generations of this
+// kernel (4 waves with all 16 positions per wave; the same software-pipelined inside the wave) are described in
+// DESIGN.md section 3 with their measurements and were removed from the source once k_conv3x3_wino_q had replaced them.
+//
+// Per 8-channel phase of the input:
+//   1. the raw halo patch is loaded to registers ahead of time and stored to LDS with the fused GroupNorm affine + SiLU
+//      applied once per element (zero padding = zeros AFTER activation); virtual concat and nearest-x2 upsampling are
+//      address arithmetic, as in the halo kernel;
+//   2. threads (tile, channel quad, row of V) compute V = B^T d B into LDS;
+//   3. the waves run the 16 position GEMMs on v_mfma_f32_32x32x2_f32: A fragments by ds_read_b128 from V, B fragments
+//      (U, pre-transformed at finalize and stored in fragment order) streamed from L2 into a register ring.
+// Numerics: fp32 throughout; F(2x2,3x3)'s transforms only add and halve, the measured deviation from the reference
+// through the whole CIFAR UNet is 3e-6 (tolerance 1e-4).
 #include <cstdlib>
 
 #include "conv.h"
@@ -28,698 +28,10 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int WT = 64;        // tiles per workgroup
-constexpr int WN = 64;        // output channels per workgroup
-constexpr int WKC = 16;       // input channels per chunk
-constexpr int VLD = 20;       // padded V row (floats)
-constexpr int RLD = 20;       // padded raw row (floats)
-constexpr int RAW_MAXPIX = 576;
-constexpr int RAW_NIT = RAW_MAXPIX * 4 / 256;   // 9 float4 per thread
-constexpr int WRING = 4;      // weight prefetch ring (groups of 4 MFMAs)
-constexpr int WGRP = 32;      // fragment groups per chunk: 16 positions x 2 k-quads
-
-template <bool UPS, int ABL>
-__global__ void __launch_bounds__(256, 1) k_conv3x3_wino(ConvLaunch p, int bh, int bw, int nimg) {
-    constexpr int abl = ABL;   // compile-time timing ablations (a runtime flag perturbs the schedule)
-    extern __shared__ __attribute__((aligned(16))) float wsm[];
-    float *V = wsm;                            // [16][WT][VLD]
-    float *raw = wsm + 16 * WT * VLD;          // [npix][RLD]
-    float *Cf = raw + RAW_MAXPIX * RLD;        // [2 slots][16 images][2][16]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, kh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int W = p.Wout, H = p.Hout, TW = W >> 1, TH = H >> 1;
-    const int Ws = UPS ? (W >> 1) : W, Hs = UPS ? (H >> 1) : H;
-    const int Cin = p.C0 + p.C1, nch = Cin / WKC;
-    const int ntn = p.Cout / WN;
-    const int mb = blockIdx.x / ntn, n0 = (blockIdx.x % ntn) * WN;
-    int img0, ty0, tx0, blk_in_img = 0;
-    if (nimg == 1) {
-        const int bpr = TW / bw, bpi = (TH / bh) * bpr;
-        img0 = mb / bpi;
-        blk_in_img = mb - img0 * bpi;
-        ty0 = (blk_in_img / bpr) * bh;
-        tx0 = (blk_in_img % bpr) * bw;
-    } else {
-        img0 = mb * nimg;
-        ty0 = tx0 = 0;
-    }
-    // raw patch geometry (source resolution): origin and size per image
-    const int RH = UPS ? bh + 2 : 2 * bh + 2, RW = UPS ? bw + 2 : 2 * bw + 2;
-    const int oy = UPS ? ty0 - 1 : 2 * ty0 - 1, ox = UPS ? tx0 - 1 : 2 * tx0 - 1;
-    const int rpi = RH * RW, npix = nimg * rpi;
-
-    // ---- raw staging: item = (pixel, channel quad)
-    const int quad = tid & 3;
-    int off[RAW_NIT];
-#pragma unroll
-    for (int it = 0; it < RAW_NIT; it++) {
-        const int pix = it * 64 + (tid >> 2);
-        const int img = pix / rpi, r = pix - img * rpi;
-        const int ry = r / RW, rx = r - ry * RW;
-        const int iy = oy + ry, ix = ox + rx;
-        const bool pad = iy < 0 || iy >= Hs || ix < 0 || ix >= Ws || (img0 + img) >= p.B;
-        off[it] = pix >= npix ? -2 : (pad ? -1 : (((img0 + img) * Hs + iy) * Ws + ix));
-    }
-    const bool has_coef = p.coefA != nullptr;
-    const int cf_img = tid >> 3, cf_isb = (tid >> 2) & 1;
-    const bool cf_mine = has_coef && tid < nimg * 8;
-    const float *cf_base = has_coef ? ((cf_isb ? p.coefB : p.coefA) + (int64_t)min(img0 + cf_img, p.B - 1) * Cin + quad * 4) : nullptr;
-    float4 xr[RAW_NIT], cfr = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto load_raw = [&](int chunk) {
-        const int c = chunk * WKC + quad * 4;
-        const bool first = c < p.C0;
-        const float *sb = first ? p.src0 + c : p.src1 + (c - p.C0);
-        const int ld = first ? p.C0 : p.C1;
-#pragma unroll
-        for (int it = 0; it < RAW_NIT; it++)
-            if (it * 64 < npix) xr[it] = *reinterpret_cast<const float4 *>(sb + (int64_t)max(off[it], 0) * ld);
-    };
-    auto load_coef = [&](int chunk) {
-        if (cf_mine) cfr = *reinterpret_cast<const float4 *>(cf_base + chunk * WKC);
-    };
-    auto store_coef = [&](int slot) {
-        if (cf_mine) *reinterpret_cast<float4 *>(Cf + slot * 512 + cf_img * 32 + cf_isb * 16 + quad * 4) = cfr;
-    };
-    auto store_raw = [&](int slot) {
-#pragma unroll
-        for (int it = 0; it < RAW_NIT; it++) {
-            if (off[it] == -2) continue;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (off[it] >= 0) {
-                x = xr[it];
-                if (has_coef) {
-                    const int img = (nimg > 1) ? (it * 64 + (tid >> 2)) / rpi : 0;
-                    const float4 ca = *reinterpret_cast<const float4 *>(Cf + slot * 512 + img * 32 + quad * 4);
-                    const float4 cb = *reinterpret_cast<const float4 *>(Cf + slot * 512 + img * 32 + 16 + quad * 4);
-                    x.x = fmaf(x.x, ca.x, cb.x);
-                    x.y = fmaf(x.y, ca.y, cb.y);
-                    x.z = fmaf(x.z, ca.z, cb.z);
-                    x.w = fmaf(x.w, ca.w, cb.w);
-                }
-                if (p.act_silu) {
-                    x.x = silu_f(x.x);
-                    x.y = silu_f(x.y);
-                    x.z = silu_f(x.z);
-                    x.w = silu_f(x.w);
-                }
-            }
-            *reinterpret_cast<float4 *>(raw + (it * 64 + (tid >> 2)) * RLD + quad * 4) = x;
-        }
-    };
-
-    // ---- input transform: thread = (tile, channel quad)
-    int rowoff[4], coloff[4];
-    {
-        const int tile = tid >> 2;
-        const int timg = tile / (bh * bw), r = tile - timg * (bh * bw);
-        const int ty = r / bw, tx = r - ty * bw;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            // UPS: up-row 2ty-1+k reads source row (2ty-1+k)>>1 = ty-1, ty, ty, ty+1 -> raw rows ty, ty+1, ty+1, ty+2
-            const int rr = UPS ? ty + ((k + 1) >> 1) : 2 * ty + k;
-            const int cc = UPS ? tx + ((k + 1) >> 1) : 2 * tx + k;
-            rowoff[k] = (timg * rpi + rr * RW) * RLD + quad * 4;
-            coloff[k] = cc * RLD;
-        }
-    }
-    float *vdst = V + (tid >> 2) * VLD + quad * 4;
-    auto transform = [&]() {
-        float4 t[4][4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const float4 d0 = *reinterpret_cast<const float4 *>(raw + rowoff[0] + coloff[c]);
-            const float4 d1 = *reinterpret_cast<const float4 *>(raw + rowoff[1] + coloff[c]);
-            const float4 d2 = *reinterpret_cast<const float4 *>(raw + rowoff[2] + coloff[c]);
-            const float4 d3 = *reinterpret_cast<const float4 *>(raw + rowoff[3] + coloff[c]);
-            t[0][c] = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
-            t[1][c] = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
-            t[2][c] = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
-            t[3][c] = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float4 a = t[r][0], b = t[r][1], c = t[r][2], d = t[r][3];
-            *reinterpret_cast<float4 *>(vdst + (r * 4 + 0) * WT * VLD) = make_float4(a.x - c.x, a.y - c.y, a.z - c.z, a.w - c.w);
-            *reinterpret_cast<float4 *>(vdst + (r * 4 + 1) * WT * VLD) = make_float4(b.x + c.x, b.y + c.y, b.z + c.z, b.w + c.w);
-            *reinterpret_cast<float4 *>(vdst + (r * 4 + 2) * WT * VLD) = make_float4(c.x - b.x, c.y - b.y, c.z - b.z, c.w - b.w);
-            *reinterpret_cast<float4 *>(vdst + (r * 4 + 3) * WT * VLD) = make_float4(b.x - d.x, b.y - d.y, b.z - d.z, b.w - d.w);
-        }
-    };
-
-    // ---- weight stream (see k_conv3x3_halo_ws): one linear stream of 1-KB fragment groups per 32-channel n-block
-    const float4 *__restrict__ wbase = reinterpret_cast<const float4 *>(p.w_wino) + lane;
-    int64_t woff = (int64_t)((n0 >> 5) + wn) * nch * WGRP * 64;
-    constexpr int AHEAD = WRING - 1;
-    float4 bq[WRING];
-    const float *asrc = V + (wm * 32 + l31) * VLD + kh * 8;
-
-    floatx16 acc[16];
-#pragma unroll
-    for (int q = 0; q < 16; q++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
-
-    // ---- prologue
-    load_raw(0);
-    load_coef(0);
-#pragma unroll
-    for (int a = 0; a < AHEAD; a++) bq[a] = wbase[woff + a * 64];
-    store_coef(0);
-    if (nch > 1) load_coef(1);
-    __syncthreads();
-    store_raw(0);
-    __syncthreads();
-    transform();
-    store_coef(1);
-    __syncthreads();
-
-    for (int chunk = 0; chunk < nch; chunk++) {
-        const bool more = chunk + 1 < nch;
-        if (more) load_raw(chunk + 1);
-        if (chunk + 2 < nch) load_coef(chunk + 2);
-#pragma unroll
-        for (int g = 0; g < ((abl & 1) ? 0 : WGRP); g++) {
-            if (!(abl & 16)) bq[(g + AHEAD) % WRING] = wbase[woff + AHEAD * 64];
-            woff += 64;
-            __builtin_amdgcn_sched_barrier(0);
-            const int q = g >> 1, jq = g & 1;
-            const float4 af = *reinterpret_cast<const float4 *>(asrc + q * WT * VLD + jq * 4);
-            const float4 b = bq[g % WRING];
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, b.x, acc[q], 0, 0, 0);
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, b.y, acc[q], 0, 0, 0);
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, b.z, acc[q], 0, 0, 0);
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, b.w, acc[q], 0, 0, 0);
-        }
-        if (more) {
-            if (!(abl & 4)) store_raw((chunk + 1) & 1);   // raw is free: transform(chunk) finished before the last barrier
-            if (!(abl & 8)) __syncthreads();              // raw(chunk+1) complete; every wave is done reading V(chunk)
-            if (!(abl & 2)) transform();
-            store_coef(chunk & 1);        // coefficients of chunk + 2 into the slot store_raw(chunk) used
-            if (!(abl & 8)) __syncthreads();
-        }
-    }
-    __syncthreads();   // the epilogue reuses V
-
-    // ---- epilogue addressing + residual prefetch: with one wave per SIMD nothing else hides a global load, so all 16
-    // residual rows of this thread are requested before the output transform and consumed after it
-    const int c4 = tid & 15, rg = tid >> 4;
-    const int n = n0 + c4 * 4;
-    const int R1 = p.Cout - p.R0;
-    int64_t mrow[16];
-    float4 resq[16];
-#pragma unroll
-    for (int pass = 0; pass < 16; pass++) {
-        const int row = pass * 16 + rg;
-        const int tile = row >> 2, i = (row >> 1) & 1, j = row & 1;
-        const int timg = tile / (bh * bw), r = tile - timg * (bh * bw);
-        const int ty = r / bw, tx = r - ty * bw;
-        const bool ok = img0 + timg < p.B;
-        const int64_t m = ((int64_t)min(img0 + timg, p.B - 1) * H + 2 * (ty0 + ty) + i) * W + 2 * (tx0 + tx) + j;
-        mrow[pass] = ok ? m : -1;
-        if (p.res0)
-            resq[pass] = (n < p.R0) ? *reinterpret_cast<const float4 *>(p.res0 + m * p.R0 + n)
-                                    : *reinterpret_cast<const float4 *>(p.res1 + m * R1 + (n - p.R0));
-    }
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias) bias = *reinterpret_cast<const float4 *>(p.bias + n);
-
-    // ---- output transform in registers: Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]
-    floatx16 y[4];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        float s0[4], s1[4];
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-            s0[a] = acc[a * 4 + 0][r] + acc[a * 4 + 1][r] + acc[a * 4 + 2][r];
-            s1[a] = acc[a * 4 + 1][r] - acc[a * 4 + 2][r] - acc[a * 4 + 3][r];
-        }
-        y[0][r] = s0[0] + s0[1] + s0[2];
-        y[1][r] = s1[0] + s1[1] + s1[2];
-        y[2][r] = s0[1] - s0[2] - s0[3];
-        y[3][r] = s1[1] - s1[2] - s1[3];
-    }
-    // row image [256 output pixels][WN + 4]: row = tile * 4 + i * 2 + j
-    constexpr int ELD = WN + 4;
-    float *img = wsm;
-#pragma unroll
-    for (int ij = 0; ij < 4; ij++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int tile = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            img[(tile * 4 + ij) * ELD + wn * 32 + l31] = y[ij][r];
-        }
-    __syncthreads();
-    const bool do_stats = p.stats_out != nullptr && nimg == 1;
-    float4 K = make_float4(0.f, 0.f, 0.f, 0.f), s1 = K, s2 = K;
-    int cnt = 0;
-#pragma unroll
-    for (int pass = 0; pass < 16; pass++) {
-        const int row = pass * 16 + rg;
-        const int64_t m = mrow[pass];
-        if (m < 0) continue;
-        float4 v = *reinterpret_cast<const float4 *>(img + row * ELD + c4 * 4);
-        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-        if (p.res0) {
-            const float4 q = resq[pass];
-            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-        }
-        if (do_stats) {
-            if (cnt == 0) K = v;
-            float d;
-            d = v.x - K.x; s1.x += d; s2.x = fmaf(d, d, s2.x);
-            d = v.y - K.y; s1.y += d; s2.y = fmaf(d, d, s2.y);
-            d = v.z - K.z; s1.z += d; s2.z = fmaf(d, d, s2.z);
-            d = v.w - K.w; s1.w += d; s2.w = fmaf(d, d, s2.w);
-            cnt++;
-        }
-        *reinterpret_cast<float4 *>(p.out + m * p.Cout + n) = v;
-    }
-    if (do_stats) {
-        __syncthreads();   // the row image is dead
-        float2 *part = reinterpret_cast<float2 *>(wsm);
-        const float fc = (float)(cnt > 0 ? cnt : 1);
-        const float mx = s1.x / fc, my = s1.y / fc, mz = s1.z / fc, mw = s1.w / fc;
-        part[rg * WN + c4 * 4 + 0] = make_float2(K.x + mx, fmaxf(s2.x - s1.x * mx, 0.f));
-        part[rg * WN + c4 * 4 + 1] = make_float2(K.y + my, fmaxf(s2.y - s1.y * my, 0.f));
-        part[rg * WN + c4 * 4 + 2] = make_float2(K.z + mz, fmaxf(s2.z - s1.z * mz, 0.f));
-        part[rg * WN + c4 * 4 + 3] = make_float2(K.w + mw, fmaxf(s2.w - s1.w * mw, 0.f));
-        __syncthreads();
-        if (tid < WN) {
-            const float npart = 16.0f;   // rows behind each partial
-            float mean = part[tid].x, M2 = part[tid].y, na = npart;
-            for (int g = 1; g < 16; g++) {
-                const float2 q = part[g * WN + tid];
-                const float d = q.x - mean, N = na + npart;
-                mean += d * (npart / N);
-                M2 += q.y + d * d * (na * npart / N);
-                na = N;
-            }
-            const int nt = (H * W) / 256;
-            p.stats_out[((int64_t)img0 * nt + blk_in_img) * p.Cout + n0 + tid] = make_float2(mean, M2);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_conv3x3_wino_p: the same algorithm, software-pipelined.  With 16 accumulator tiles per wave only ONE wave fits
-// a SIMD, so nothing but the wave's own instruction stream can fill the MFMA shadow: here every phase (one
-// 8-channel chunk) is a single straight-line block in which the 64 MFMAs of chunk c are interleaved by the
-// scheduler with   S(c+2) GroupNorm+SiLU and LDS store of the raw patch prefetched a phase ago,
-//                  G(c+3) the global loads of the next raw patch,
-//                  X(c+1) the input transform raw -> V for the next chunk,
-// on double-buffered raw and V tiles (one barrier per phase).  All stages run unconditionally on a clamped chunk
-// index (the tail repeats the last chunk into dead buffers): a load inside a conditional would end the block.
-// ---------------------------------------------------------------------------------------------
-constexpr int PKC = 8;        // input channels per chunk
-constexpr int PVLD = 12;      // padded V row (floats): conflict-free ds_read_b128 over 16 consecutive tiles
-constexpr int PRLD = 12;      // padded raw row
-constexpr int PRAW_NIT = (RAW_MAXPIX * 2 + 255) / 256;   // 5 float4 per thread
-constexpr int PRAW_ROWS = PRAW_NIT * 128;                // 640 rows: every staging item has a slot, no store guards
-constexpr int PRING = 8;      // weight ring: 7 slots (1792 MFMA cycles) of prefetch distance
-
-// ACT: fused GroupNorm affine + SiLU on the input (the ResBlock convs) or a plain input (the Upsample conv); other
-// combinations take the phase-separated kernel.  Compile-time so that the phase has no branches at all.
-template <bool UPS, bool ACT, int ABL = 0>
-__global__ void __launch_bounds__(256, 1) k_conv3x3_wino_p(ConvLaunch p, int bh, int bw, int nimg) {
-    // ABL (timing experiments, DLPM_WINO_ABLATIONS builds): 1 no S pieces, 2 no X pieces, 4 no raw loads, 8 no barrier,
-    // 16 no weight loads, 32 no MFMA
-    extern __shared__ __attribute__((aligned(16))) float wsm[];
-    float *V = wsm;                                  // [2][16][WT][PVLD]
-    float *raw = wsm + 2 * 16 * WT * PVLD;           // [2][PRAW_ROWS][PRLD]
-    float *Cf = raw + 2 * PRAW_ROWS * PRLD;          // [2 slots][16 images][2][8]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, kh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int W = p.Wout, H = p.Hout, TW = W >> 1, TH = H >> 1;
-    const int Ws = UPS ? (W >> 1) : W, Hs = UPS ? (H >> 1) : H;
-    const int Cin = p.C0 + p.C1, nch = Cin / PKC;
-    const int ntn = p.Cout / WN;
-    const int mb = blockIdx.x / ntn, n0 = (blockIdx.x % ntn) * WN;
-    int img0, ty0, tx0, blk_in_img = 0;
-    if (nimg == 1) {
-        const int bpr = TW / bw, bpi = (TH / bh) * bpr;
-        img0 = mb / bpi;
-        blk_in_img = mb - img0 * bpi;
-        ty0 = (blk_in_img / bpr) * bh;
-        tx0 = (blk_in_img % bpr) * bw;
-    } else {
-        img0 = mb * nimg;
-        ty0 = tx0 = 0;
-    }
-    const int RH = UPS ? bh + 2 : 2 * bh + 2, RW = UPS ? bw + 2 : 2 * bw + 2;
-    const int oy = UPS ? ty0 - 1 : 2 * ty0 - 1, ox = UPS ? tx0 - 1 : 2 * tx0 - 1;
-    const int rpi = RH * RW, npix = nimg * rpi;
-
-    // ---- raw staging: item = (pixel, channel quad of the 8-channel chunk)
-    const int squad = tid & 1;
-    int off[PRAW_NIT], cfo[PRAW_NIT];
-#pragma unroll
-    for (int it = 0; it < PRAW_NIT; it++) {
-        const int pix = it * 128 + (tid >> 1);
-        const int img = min(pix / rpi, nimg - 1), r = pix - img * rpi;
-        const int ry = r / RW, rx = r - ry * RW;
-        const int iy = oy + ry, ix = ox + rx;
-        const bool pad = pix >= npix || iy < 0 || iy >= Hs || ix < 0 || ix >= Ws || (img0 + img) >= p.B;
-        off[it] = pad ? -1 : (((img0 + img) * Hs + iy) * Ws + ix);
-        cfo[it] = img * 16 + squad * 4;
-    }
-    constexpr bool has_coef = ACT;
-    const int cf_img = tid >> 2, cf_isb = (tid >> 1) & 1;
-    const bool cf_mine = has_coef && tid < nimg * 4;
-    const float *cf_base = has_coef ? ((cf_isb ? p.coefB : p.coefA) + (int64_t)min(img0 + cf_img, p.B - 1) * Cin + squad * 4) : nullptr;
-    float4 xr[PRAW_NIT], cfr = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto load_raw = [&](int chunk) {
-        const int c = chunk * PKC + squad * 4;
-        const bool first = c < p.C0;
-        const float *sb = first ? p.src0 + c : p.src1 + (c - p.C0);
-        const int ld = first ? p.C0 : p.C1;
-#pragma unroll
-        for (int it = 0; it < PRAW_NIT; it++) xr[it] = *reinterpret_cast<const float4 *>(sb + (int64_t)max(off[it], 0) * ld);
-    };
-    auto load_coef = [&](int chunk) {
-        if (has_coef) cfr = *reinterpret_cast<const float4 *>(cf_base + chunk * PKC);
-    };
-    const int cf_dst = cf_mine ? cf_img * 16 + cf_isb * 8 + squad * 4 : -1;
-    auto store_coef = [&](int slot) {   // unconditional (threads without a coefficient write a dummy cell: no branch)
-        if (has_coef) *reinterpret_cast<float4 *>(Cf + (cf_dst >= 0 ? slot * 256 + cf_dst : 512 + squad * 4)) = cfr;
-    };
-    auto store_raw_item = [&](int slot, int it) {
-        float *rb = raw + slot * PRAW_ROWS * PRLD;
-        {
-            float4 x = xr[it];
-            if (ACT) {
-                const float4 ca = *reinterpret_cast<const float4 *>(Cf + slot * 256 + cfo[it]);
-                const float4 cb = *reinterpret_cast<const float4 *>(Cf + slot * 256 + cfo[it] + 8);
-                x.x = silu_f(fmaf(x.x, ca.x, cb.x));
-                x.y = silu_f(fmaf(x.y, ca.y, cb.y));
-                x.z = silu_f(fmaf(x.z, ca.z, cb.z));
-                x.w = silu_f(fmaf(x.w, ca.w, cb.w));
-            }
-            if (off[it] < 0) x = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding applies AFTER the activation
-            *reinterpret_cast<float4 *>(rb + (it * 128 + (tid >> 1)) * PRLD + squad * 4) = x;
-        }
-    };
-    auto store_raw = [&](int slot) {
-#pragma unroll
-        for (int it = 0; it < PRAW_NIT; it++) store_raw_item(slot, it);
-    };
-    // the same item in four pieces (one channel each), for the MFMA-interleaved phase body
-    float4 sca, scb, sx;
-    float4 nca[PRAW_NIT], ncb[PRAW_NIT];   // coefficient pairs read from LDS one slot ahead of their item
-    auto coef_prefetch = [&](int slot, int it) {
-        if (ACT) {
-            nca[it] = *reinterpret_cast<const float4 *>(Cf + slot * 256 + cfo[it]);
-            ncb[it] = *reinterpret_cast<const float4 *>(Cf + slot * 256 + cfo[it] + 8);
-        }
-    };
-    // One staging item in six stages, each a handful of INDEPENDENT instructions that fits an MFMA's 64-cycle shadow
-    // (v_exp / v_rcp are quarter rate: 16 cycles each, two per stage):
-    //   0: t = x*ca + cb, m = -t*log2(e)   1: e.xy = exp2(m.xy)   2: e.zw = exp2(m.zw)
-    //   3: d = 1 + e, r.xy = rcp(d.xy)     4: r.zw = rcp(d.zw), y = t*r            5: zero padding, LDS store
-    float4 st, sm;
-    auto store_raw_stage = [&](int slot, int it, int stg) {
-        if (!ACT) {
-            if (stg == 5) {
-                float4 x = xr[it];
-                if (off[it] < 0) x = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4 *>(raw + slot * PRAW_ROWS * PRLD + (it * 128 + (tid >> 1)) * PRLD + squad * 4) = x;
-            }
-            return;
-        }
-        if (stg == 0) {
-            const float4 x = xr[it], ca = nca[it], cb = ncb[it];
-            st = make_float4(fmaf(x.x, ca.x, cb.x), fmaf(x.y, ca.y, cb.y), fmaf(x.z, ca.z, cb.z), fmaf(x.w, ca.w, cb.w));
-            const float k = -1.4426950408889634f;
-            sm = make_float4(st.x * k, st.y * k, st.z * k, st.w * k);
-        }
-        if (stg == 1) { sm.x = __builtin_amdgcn_exp2f(sm.x); sm.y = __builtin_amdgcn_exp2f(sm.y); }
-        if (stg == 2) { sm.z = __builtin_amdgcn_exp2f(sm.z); sm.w = __builtin_amdgcn_exp2f(sm.w); }
-        if (stg == 3) {
-            sm = make_float4(1.0f + sm.x, 1.0f + sm.y, 1.0f + sm.z, 1.0f + sm.w);
-            sm.x = __builtin_amdgcn_rcpf(sm.x);
-            sm.y = __builtin_amdgcn_rcpf(sm.y);
-        }
-        if (stg == 4) {
-            sm.z = __builtin_amdgcn_rcpf(sm.z);
-            sm.w = __builtin_amdgcn_rcpf(sm.w);
-            st = make_float4(st.x * sm.x, st.y * sm.y, st.z * sm.z, st.w * sm.w);
-        }
-        if (stg == 5) {
-            if (off[it] < 0) st = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(raw + slot * PRAW_ROWS * PRLD + (it * 128 + (tid >> 1)) * PRLD + squad * 4) = st;
-        }
-    };
-
-    // ---- input transform: (tile, quad) pairs over lanes, the row half is wave-uniform
-    const int half = wave & 1;
-    int rowoff[3], coloff[4];
-    int vofs;
-    {
-        const int pair = (wave >> 1) * 64 + lane;
-        const int tile = pair >> 1, tquad = pair & 1;
-        const int timg = tile / (bh * bw), r = tile - timg * (bh * bw);
-        const int ty = r / bw, tx = r - ty * bw;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int cc = UPS ? tx + ((k + 1) >> 1) : 2 * tx + k;
-            coloff[k] = cc * PRLD;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; k++) {   // patch rows half .. half + 2
-            const int kk = k + half;
-            const int rr = UPS ? ty + ((kk + 1) >> 1) : 2 * ty + kk;
-            rowoff[k] = (timg * rpi + rr * RW) * PRLD + tquad * 4;
-        }
-        vofs = tile * PVLD + tquad * 4;
-    }
-    const float sg = half ? -1.f : 1.f;
-    const int rowA = half ? 3 : 0, rowB = half ? 2 : 1;   // V rows produced from ta / tb
-    float4 ta[4], tb[4];
-    auto transform_col = [&](int slot, int c) {   // B^T d for patch column c (3 LDS reads)
-        const float *rb = raw + slot * PRAW_ROWS * PRLD;
-        const float4 e0 = *reinterpret_cast<const float4 *>(rb + rowoff[0] + coloff[c]);
-        const float4 e1 = *reinterpret_cast<const float4 *>(rb + rowoff[1] + coloff[c]);
-        const float4 e2 = *reinterpret_cast<const float4 *>(rb + rowoff[2] + coloff[c]);
-        // branch-free on the wave-uniform half (a branch would split the phase's straight-line block):
-        //   half 0 (e = d0,d1,d2): ta = d0 - d2 -> row 0,  tb = d1 + d2 -> row 1
-        //   half 1 (e = d1,d2,d3): ta = d1 - d3 -> row 3,  tb = d2 - d1 -> row 2
-        const float4 w = half ? e0 : e2;
-        ta[c] = make_float4(e0.x - e2.x, e0.y - e2.y, e0.z - e2.z, e0.w - e2.w);
-        tb[c] = make_float4(fmaf(sg, w.x, e1.x), fmaf(sg, w.y, e1.y), fmaf(sg, w.z, e1.z), fmaf(sg, w.w, e1.w));
-    };
-    auto transform_out = [&](int slot, int k) {   // (.) B for V row (k >> 2 ? rowB : rowA), column k & 3 (1 LDS write)
-        const int rr = k >> 2, cc = k & 3;
-        const float4 a = rr ? tb[0] : ta[0], b = rr ? tb[1] : ta[1], c = rr ? tb[2] : ta[2], d = rr ? tb[3] : ta[3];
-        float *o = V + slot * 16 * WT * PVLD + vofs + ((rr ? rowB : rowA) * 4 + cc) * WT * PVLD;
-        float4 v;
-        if (cc == 0) v = make_float4(a.x - c.x, a.y - c.y, a.z - c.z, a.w - c.w);
-        else if (cc == 1) v = make_float4(b.x + c.x, b.y + c.y, b.z + c.z, b.w + c.w);
-        else if (cc == 2) v = make_float4(c.x - b.x, c.y - b.y, c.z - b.z, c.w - b.w);
-        else v = make_float4(b.x - d.x, b.y - d.y, b.z - d.z, b.w - d.w);
-        *reinterpret_cast<float4 *>(o) = v;
-    };
-    float4 te0, te1, te2;
-    float4 ne[4][3];                        // patch columns read from LDS one slot ahead of their transform
-    auto col_prefetch = [&](int slot, int c) {
-        const float *rb = raw + slot * PRAW_ROWS * PRLD;
-        ne[c][0] = *reinterpret_cast<const float4 *>(rb + rowoff[0] + coloff[c]);
-        ne[c][1] = *reinterpret_cast<const float4 *>(rb + rowoff[1] + coloff[c]);
-        ne[c][2] = *reinterpret_cast<const float4 *>(rb + rowoff[2] + coloff[c]);
-    };
-    auto transform_col_part = [&](int c, int part) {   // part 0: channels x,y   part 1: z,w
-        if (part == 0) {
-            te0 = ne[c][0]; te1 = ne[c][1]; te2 = ne[c][2];
-            ta[c].x = te0.x - te2.x; tb[c].x = fmaf(sg, half ? te0.x : te2.x, te1.x);
-            ta[c].y = te0.y - te2.y; tb[c].y = fmaf(sg, half ? te0.y : te2.y, te1.y);
-        } else {
-            ta[c].z = te0.z - te2.z; tb[c].z = fmaf(sg, half ? te0.z : te2.z, te1.z);
-            ta[c].w = te0.w - te2.w; tb[c].w = fmaf(sg, half ? te0.w : te2.w, te1.w);
-        }
-    };
-    auto transform = [&](int slot) {
-#pragma unroll
-        for (int c = 0; c < 4; c++) transform_col(slot, c);
-#pragma unroll
-        for (int k = 0; k < 8; k++) transform_out(slot, k);
-    };
-
-    // ---- weight stream: Wf[nb][chunk][pos][lane][4], one float4 per position and chunk
-    const float4 *__restrict__ wbase = reinterpret_cast<const float4 *>(p.w_wino) + lane;
-    int64_t woff = (int64_t)((n0 >> 5) + wn) * nch * 16 * 64;
-    constexpr int AHEAD = PRING - 1;
-    float4 bq[PRING];
-    const float *asrc = V + (wm * 32 + l31) * PVLD + kh * 4;
-
-    floatx16 acc[16];
-#pragma unroll
-    for (int q = 0; q < 16; q++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
-
-    // ---- prologue: S(0), S(1), X(0), G(2) and the coefficient slots
-    const int last = nch - 1;
-    load_raw(0);
-    load_coef(0);
-#pragma unroll
-    for (int a = 0; a < AHEAD; a++) bq[a] = wbase[woff + a * 64];
-    store_coef(0);
-    load_coef(min(1, last));
-    __syncthreads();
-    store_raw(0);
-    load_raw(min(1, last));
-    store_coef(1);
-    load_coef(min(2, last));
-    __syncthreads();
-    transform(0);
-    store_raw(1);
-    load_raw(min(2, last));
-    store_coef(0);   // coefficients of chunk 2 (slot 0 was last read by S(0), a barrier ago)
-    __syncthreads();
-
-    for (int chunk = 0; chunk < nch; chunk++) {
-        const int cur = chunk & 1, nxt = cur ^ 1;
-        load_coef(min(chunk + 3, last));
-        const float *ab = asrc + cur * 16 * WT * PVLD;
-        // One wave per SIMD: nothing hides a latency except this wave's own instruction stream, and the wave issues in
-        // order -- only what sits BETWEEN two MFMAs runs in an MFMA's 64-cycle shadow.  The phase is therefore a fixed
-        // program of 64 gaps g = 4*position + k-step, each MFMA followed by one small piece of the side work, the order
-        // pinned with sched_barrier; every LDS read is issued two or more gaps before its first use.
-        //   g  2..31   S(chunk+2): item (g-2)/6, stage (g-2)%6 -> raw[cur]  (raw[cur] was read by X(chunk), a barrier ago)
-        //   g 32       G(chunk+3): reload the staging registers
-        //   g 34..41   X(chunk+1): column (g-34)/2 of B^T d, half of the channels each
-        //   g 44..51   X(chunk+1): output g-44 of (.) B -> V[nxt]
-        float4 afn = *reinterpret_cast<const float4 *>(ab);
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const float4 af = afn;
-            if (q < 15) afn = *reinterpret_cast<const float4 *>(ab + (q + 1) * WT * PVLD);
-            if (!(ABL & 16)) bq[(q + AHEAD) % PRING] = wbase[woff + AHEAD * 64];
-            woff += 64;
-            const float4 b = bq[q % PRING];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int g = q * 4 + j;
-                const float av = j == 0 ? af.x : j == 1 ? af.y : j == 2 ? af.z : af.w;
-                const float bv = j == 0 ? b.x : j == 1 ? b.y : j == 2 ? b.z : b.w;
-                if (!(ABL & 32)) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[q], 0, 0, 0);
-                if (!(ABL & 1)) {
-                    if (g < 30 && g % 6 == 0) coef_prefetch(cur, g / 6);          // 2 gaps ahead of stage 0 of item g/6
-                    if (g >= 2 && g < 32) store_raw_stage(cur, (g - 2) / 6, (g - 2) % 6);
-                }
-                if (g == 32 && !(ABL & 4)) load_raw(min(chunk + 3, last));
-                if (!(ABL & 2)) {
-                    if (g >= 32 && g < 40 && g % 2 == 0) col_prefetch(nxt, (g - 32) / 2);   // 2 gaps ahead of its column
-                    if (g >= 34 && g < 42) transform_col_part((g - 34) / 2, (g - 34) % 2);
-                    if (g >= 44 && g < 52) transform_out(nxt, g - 44);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        store_coef(nxt);                        // coefficients of chunk+3 -> slot (chunk+3)&1
-        if (!(ABL & 8)) __syncthreads();
-    }
-    if (ABL & 8) __syncthreads();
-    // (the last barrier of the loop also fences V: the epilogue reuses it)
-
-    const int c4 = tid & 15, rg = tid >> 4;
-    const int n = n0 + c4 * 4;
-    const int R1 = p.Cout - p.R0;
-    int64_t mrow[16];
-    float4 resq[16];
-#pragma unroll
-    for (int pass = 0; pass < 16; pass++) {
-        const int row = pass * 16 + rg;
-        const int tile = row >> 2, i = (row >> 1) & 1, j = row & 1;
-        const int timg = tile / (bh * bw), r = tile - timg * (bh * bw);
-        const int ty = r / bw, tx = r - ty * bw;
-        const bool ok = img0 + timg < p.B;
-        const int64_t m = ((int64_t)min(img0 + timg, p.B - 1) * H + 2 * (ty0 + ty) + i) * W + 2 * (tx0 + tx) + j;
-        mrow[pass] = ok ? m : -1;
-        if (p.res0)
-            resq[pass] = (n < p.R0) ? *reinterpret_cast<const float4 *>(p.res0 + m * p.R0 + n)
-                                    : *reinterpret_cast<const float4 *>(p.res1 + m * R1 + (n - p.R0));
-    }
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias) bias = *reinterpret_cast<const float4 *>(p.bias + n);
-
-    floatx16 y[4];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        float s0[4], s1[4];
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-            s0[a] = acc[a * 4 + 0][r] + acc[a * 4 + 1][r] + acc[a * 4 + 2][r];
-            s1[a] = acc[a * 4 + 1][r] - acc[a * 4 + 2][r] - acc[a * 4 + 3][r];
-        }
-        y[0][r] = s0[0] + s0[1] + s0[2];
-        y[1][r] = s1[0] + s1[1] + s1[2];
-        y[2][r] = s0[1] - s0[2] - s0[3];
-        y[3][r] = s1[1] - s1[2] - s1[3];
-    }
-    constexpr int ELD = WN + 4;
-    float *img = wsm;
-#pragma unroll
-    for (int ij = 0; ij < 4; ij++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int tile = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            img[(tile * 4 + ij) * ELD + wn * 32 + l31] = y[ij][r];
-        }
-    __syncthreads();
-    const bool do_stats = p.stats_out != nullptr && nimg == 1;
-    float4 K = make_float4(0.f, 0.f, 0.f, 0.f), s1 = K, s2 = K;
-    int cnt = 0;
-#pragma unroll
-    for (int pass = 0; pass < 16; pass++) {
-        const int row = pass * 16 + rg;
-        const int64_t m = mrow[pass];
-        if (m < 0) continue;
-        float4 v = *reinterpret_cast<const float4 *>(img + row * ELD + c4 * 4);
-        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-        if (p.res0) {
-            const float4 q = resq[pass];
-            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-        }
-        if (do_stats) {
-            if (cnt == 0) K = v;
-            float d;
-            d = v.x - K.x; s1.x += d; s2.x = fmaf(d, d, s2.x);
-            d = v.y - K.y; s1.y += d; s2.y = fmaf(d, d, s2.y);
-            d = v.z - K.z; s1.z += d; s2.z = fmaf(d, d, s2.z);
-            d = v.w - K.w; s1.w += d; s2.w = fmaf(d, d, s2.w);
-            cnt++;
-        }
-        *reinterpret_cast<float4 *>(p.out + m * p.Cout + n) = v;
-    }
-    if (do_stats) {
-        __syncthreads();
-        float2 *part = reinterpret_cast<float2 *>(wsm);
-        const float fc = (float)(cnt > 0 ? cnt : 1);
-        const float mx = s1.x / fc, my = s1.y / fc, mz = s1.z / fc, mw = s1.w / fc;
-        part[rg * WN + c4 * 4 + 0] = make_float2(K.x + mx, fmaxf(s2.x - s1.x * mx, 0.f));
-        part[rg * WN + c4 * 4 + 1] = make_float2(K.y + my, fmaxf(s2.y - s1.y * my, 0.f));
-        part[rg * WN + c4 * 4 + 2] = make_float2(K.z + mz, fmaxf(s2.z - s1.z * mz, 0.f));
-        part[rg * WN + c4 * 4 + 3] = make_float2(K.w + mw, fmaxf(s2.w - s1.w * mw, 0.f));
-        __syncthreads();
-        if (tid < WN) {
-            const float npart = 16.0f;
-            float mean = part[tid].x, M2 = part[tid].y, na = npart;
-            for (int g = 1; g < 16; g++) {
-                const float2 q = part[g * WN + tid];
-                const float d = q.x - mean, N = na + npart;
-                mean += d * (npart / N);
-                M2 += q.y + d * d * (na * npart / N);
-                na = N;
-            }
-            const int nt = (H * W) / 256;
-            p.stats_out[((int64_t)img0 * nt + blk_in_img) * p.Cout + n0 + tid] = make_float2(mean, M2);
-        }
-    }
-}
+constexpr int WN = 64;        // output channels a layer must be a multiple of
+constexpr int WKC = 16;       // input channels a layer must be a multiple of
+constexpr int RAW_MAXPIX = 576;   // halo pixels per phase of a 64-tile block (half of it for 32 tiles)
+constexpr int WGRP = 32;      // weight fragment groups (256 floats) per 16 input channels and 32 output channels
 
 // ---------------------------------------------------------------------------------------------
 // k_conv3x3_wino_q: eight waves per workgroup, two per SIMD.
@@ -730,9 +42,8 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_wino_p(ConvLaunch p, int bh,
 // waves per SIMD), and the staging / transform work of one wave overlaps the MFMAs of its SIMD neighbour.  The output
 // transform Y = A^T M A splits by rows: each wave reduces its 8 accumulators to 4 partial 2x2-output tiles in registers,
 // the ph = 1 waves pass theirs through LDS, the ph = 0 waves add them (fixed order: deterministic).
-// Phase structure as in k_conv3x3_wino_p: double-buffered raw / V, one barrier per 8-channel chunk.
+// Phases are software-pipelined: double-buffered raw / V, one barrier per 8-channel chunk.
 // ---------------------------------------------------------------------------------------------
-constexpr int QRAW_NIT = (RAW_MAXPIX * 2 + 511) / 512;   // 3 float4 per thread (512 threads)
 constexpr int QRING = 8;      // weight prefetch ring of the 8-wave kernel (groups of 4 MFMAs); must divide the 8 groups of a phase
 
 // MT = tiles per workgroup: 64 (x 64 output channels) or 32 (x 128 channels).  The accumulator block is 256 KB either
@@ -752,7 +63,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
     constexpr int RAWPIX = MT == 64 ? RAW_MAXPIX : RAW_MAXPIX / 2;
     constexpr int NQD = KC / 4;                      // channel quads per pixel and chunk
     constexpr int QNIT = (RAWPIX * NQD + NT - 1) / NT; // staging items per thread
-    constexpr int PVLD = KC + 4, PRLD = KC + 4;      // padded V / raw rows (shadow the 8-channel constants)
+    constexpr int PVLD = KC + 4, PRLD = KC + 4;      // padded V / raw rows: conflict-free ds_read_b128 over consecutive tiles
     constexpr int CFS = 16 * 2 * KC;                 // floats per coefficient slot: [16 images][2][KC]
     constexpr int NJQ = KC / 8;                      // float4 fragments per position and lane
     extern __shared__ __attribute__((aligned(16))) float wsm[];
@@ -1124,69 +435,7 @@ __global__ void k_relayout_weight_wino_q(const float *oihw, float *dst, int Cout
     dst[i] = u;
 }
 
-// OIHW (3x3) -> U = G g G^T in the pipelined kernel's fragment order  Wf[nb][chunk8][pos][lane][4]:
-// lane = h*32 + n holds U_pos[cin = chunk*8 + h*4 + e][cout = nb*32 + n].
-__global__ void k_relayout_weight_wino_p(const float *oihw, float *dst, int Cout, int Cin) {
-    const int nbk = Cout / 32, nch = Cin / PKC;
-    const int64_t total = (int64_t)nbk * nch * 16 * 64 * 4;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int e = (int)(i & 3);
-    const int lane = (int)((i >> 2) & 63);
-    int64_t r = i >> 8;
-    const int pos = (int)(r & 15); r >>= 4;
-    const int chunk = (int)(r % nch);
-    const int nb = (int)(r / nch);
-    const int h = lane >> 5, nn = lane & 31;
-    const int cin = chunk * PKC + h * 4 + e, cout = nb * 32 + nn;
-    const float *g = oihw + ((int64_t)cout * Cin + cin) * 9;
-    const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
-    const int a = pos >> 2, b = pos & 3;
-    float u = 0.f;
-    for (int ii = 0; ii < 3; ii++) {
-        float row = 0.f;
-        for (int jj = 0; jj < 3; jj++) row += g[ii * 3 + jj] * G[b][jj];
-        u += G[a][ii] * row;
-    }
-    dst[i] = u;
-}
-
-// OIHW (3x3) -> U = G g G^T in fragment order  Wf[nb][chunk][pos][jq][lane][4]:
-// lane = h*32 + n holds U_pos[cin = chunk*16 + h*8 + jq*4 + e][cout = nb*32 + n].
-__global__ void k_relayout_weight_wino(const float *oihw, float *dst, int Cout, int Cin) {
-    const int nbk = Cout / 32, nch = Cin / WKC;
-    const int64_t total = (int64_t)nbk * nch * WGRP * 64 * 4;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int e = (int)(i & 3);
-    const int lane = (int)((i >> 2) & 63);
-    int64_t r = i >> 8;
-    const int jq = (int)(r & 1); r >>= 1;
-    const int pos = (int)(r & 15); r >>= 4;
-    const int chunk = (int)(r % nch);
-    const int nb = (int)(r / nch);
-    const int h = lane >> 5, nn = lane & 31;
-    const int cin = chunk * WKC + h * 8 + jq * 4 + e, cout = nb * 32 + nn;
-    const float *g = oihw + ((int64_t)cout * Cin + cin) * 9;
-    const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
-    const int a = pos >> 2, b = pos & 3;
-    float u = 0.f;
-    for (int ii = 0; ii < 3; ii++) {
-        float row = 0.f;
-        for (int jj = 0; jj < 3; jj++) row += g[ii * 3 + jj] * G[b][jj];
-        u += G[a][ii] * row;
-    }
-    dst[i] = u;
-}
-
 }  // namespace
-
-static int wino_variant() {   // DLPM_WINO_P: 0 phase-separated 4-wave kernel, 1 pipelined 4-wave kernel, 2 (default) 8-wave kernel
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("DLPM_WINO_P"); v = e ? atoi(e) : 2; }
-    return v;
-}
-static bool wino_pipelined() { return wino_variant() == 1; }
 
 static bool wino_disabled() {
     static int v = -1;
@@ -1211,15 +460,15 @@ static int wino_kc_for(int Cout) {
 int wino_tiles(const ConvLaunch &c) {
     static int pref = -1;
     if (pref < 0) { const char *e = getenv("DLPM_WINO_MT"); pref = e ? atoi(e) : 32; }
-    if (wino_variant() == 2 && wino_waves(c) == 4) return 32;
-    return (wino_variant() == 2 && pref == 32 && c.Cout % 128 == 0) ? 32 : 64;
+    if (wino_waves(c) == 4) return 32;
+    return (pref == 32 && c.Cout % 128 == 0) ? 32 : 64;
 }
 
 // waves per workgroup of the 8-wave kernel family: DLPM_WINO_NW=4 selects the two-workgroups-per-CU shape (32 x 64 blocks)
 int wino_waves(const ConvLaunch &c) {
     static int pref = -1;
     if (pref < 0) { const char *e = getenv("DLPM_WINO_NW"); pref = e ? atoi(e) : 8; }
-    return (pref == 4 && wino_variant() == 2) ? 4 : 8;
+    return pref == 4 ? 4 : 8;
 }
 
 bool wino_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
@@ -1257,98 +506,46 @@ int launch_conv_wino(const ConvLaunch &c, hipStream_t st) {
 #ifdef DLPM_PHASE_TIMING
     const_cast<ConvLaunch &>(c).phase = phase_buffer();
 #endif
-    const int64_t tiles = (int64_t)c.B * (c.Hout / 2) * (c.Wout / 2);
-    const int64_t mblocks = nimg == 1 ? tiles / WT : ceil_div(c.B, nimg);
-    const int64_t grid = mblocks * (c.Cout / WN);
-    const size_t shmem = (size_t)(16 * WT * VLD + RAW_MAXPIX * RLD + 2 * 512) * sizeof(float);
-    static int abl = -1;   // timing-only ablations (results are wrong when set): 1 no MFMA loop, 2 no transform,
-    if (abl < 0) { const char *e = getenv("DLPM_WABL"); abl = e ? atoi(e) : 0; }   // 4 no raw store, 8 no barriers, 16 no weight loads
     using KFn = void (*)(ConvLaunch, int, int, int);
-    KFn fn = c.ups ? &k_conv3x3_wino<true, 0> : &k_conv3x3_wino<false, 0>;
-    size_t shmem_p = (size_t)(2 * 16 * WT * PVLD + 2 * PRAW_ROWS * PRLD + 512 + 8) * sizeof(float);
-    const bool act = c.coefA && c.act_silu, plain = !c.coefA && !c.act_silu;
-    const bool piped = wino_pipelined() && (act || plain);
-    if (piped) {
-        if (act) fn = c.ups ? &k_conv3x3_wino_p<true, true> : &k_conv3x3_wino_p<false, true>;
-        else fn = c.ups ? &k_conv3x3_wino_p<true, false> : &k_conv3x3_wino_p<false, false>;
-    }
+    const int mt = wino_tiles(c);
+    const int nw = wino_waves(c);
+    const int kc = wino_kc_for(c.Cout);
+    KFn fn;
+    if (mt == 32 && nw == 4) fn = c.ups ? &k_conv3x3_wino_q<true, 32, 4> : &k_conv3x3_wino_q<false, 32, 4>;
+    else if (mt == 32 && kc == 16) fn = c.ups ? &k_conv3x3_wino_q<true, 32, 8, 0, 16> : &k_conv3x3_wino_q<false, 32, 8, 0, 16>;
+    else if (mt == 32) fn = c.ups ? &k_conv3x3_wino_q<true, 32> : &k_conv3x3_wino_q<false, 32>;
+    else fn = c.ups ? &k_conv3x3_wino_q<true, 64> : &k_conv3x3_wino_q<false, 64>;
 #ifdef DLPM_WINO_ABLATIONS
-    if (piped && act && !c.ups) {
+    static int abl = -1;   // timing-only ablations (results are wrong when set)
+    if (abl < 0) { const char *e = getenv("DLPM_WABL"); abl = e ? atoi(e) : 0; }
+    if (!c.ups && mt == 32 && nw == 8 && kc == 8) {
         switch (abl) {
-            case 1: fn = &k_conv3x3_wino_p<false, true, 1>; break;
-            case 2: fn = &k_conv3x3_wino_p<false, true, 2>; break;
-            case 3: fn = &k_conv3x3_wino_p<false, true, 3>; break;
-            case 4: fn = &k_conv3x3_wino_p<false, true, 4>; break;
-            case 7: fn = &k_conv3x3_wino_p<false, true, 7>; break;
-            case 8: fn = &k_conv3x3_wino_p<false, true, 8>; break;
-            case 15: fn = &k_conv3x3_wino_p<false, true, 15>; break;
-            case 16: fn = &k_conv3x3_wino_p<false, true, 16>; break;
-            case 31: fn = &k_conv3x3_wino_p<false, true, 31>; break;
-            case 32: fn = &k_conv3x3_wino_p<false, true, 32>; break;
-            default: break;
-        }
-    } else if (!c.ups) {
-        switch (abl) {
-            case 1: fn = &k_conv3x3_wino<false, 1>; break;
-            case 2: fn = &k_conv3x3_wino<false, 2>; break;
-            case 4: fn = &k_conv3x3_wino<false, 4>; break;
-            case 6: fn = &k_conv3x3_wino<false, 6>; break;
-            case 8: fn = &k_conv3x3_wino<false, 8>; break;
-            case 16: fn = &k_conv3x3_wino<false, 16>; break;
-            case 14: fn = &k_conv3x3_wino<false, 14>; break;
-            case 15: fn = &k_conv3x3_wino<false, 15>; break;
+            case 1: fn = &k_conv3x3_wino_q<false, 32, 8, 1>; break;
+            case 2: fn = &k_conv3x3_wino_q<false, 32, 8, 2>; break;
+            case 3: fn = &k_conv3x3_wino_q<false, 32, 8, 3>; break;
+            case 8: fn = &k_conv3x3_wino_q<false, 32, 8, 8>; break;
+            case 16: fn = &k_conv3x3_wino_q<false, 32, 8, 16>; break;
+            case 31: fn = &k_conv3x3_wino_q<false, 32, 8, 31>; break;
+            case 32: fn = &k_conv3x3_wino_q<false, 32, 8, 32>; break;
             default: break;
         }
     }
 #endif
-    static const void *configured[24] = {nullptr};   // (not during graph capture: the first
-    bool seen = false;                                                          //  launch of each kernel is eager)
+    static const void *configured[24] = {nullptr};   // (not during graph capture: the first launch of each kernel is eager)
+    bool seen = false;
     for (const void *q : configured) seen = seen || q == reinterpret_cast<const void *>(fn);
     if (!seen) {
         DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         for (auto &q : configured)
             if (!q) { q = reinterpret_cast<const void *>(fn); break; }
     }
-    if (wino_variant() == 2) {
-        const int mt = wino_tiles(c);
-        const int nw = wino_waves(c);
-        const int kc = wino_kc_for(c.Cout);
-        if (mt == 32 && nw == 4) fn = c.ups ? &k_conv3x3_wino_q<true, 32, 4> : &k_conv3x3_wino_q<false, 32, 4>;
-        else if (mt == 32 && kc == 16) fn = c.ups ? &k_conv3x3_wino_q<true, 32, 8, 0, 16> : &k_conv3x3_wino_q<false, 32, 8, 0, 16>;
-        else if (mt == 32) fn = c.ups ? &k_conv3x3_wino_q<true, 32> : &k_conv3x3_wino_q<false, 32>;
-        else fn = c.ups ? &k_conv3x3_wino_q<true, 64> : &k_conv3x3_wino_q<false, 64>;
-#ifdef DLPM_WINO_ABLATIONS
-        if (!c.ups && mt == 32 && nw == 8 && kc == 8) {
-            switch (abl) {
-                case 1: fn = &k_conv3x3_wino_q<false, 32, 8, 1>; break;
-                case 2: fn = &k_conv3x3_wino_q<false, 32, 8, 2>; break;
-                case 3: fn = &k_conv3x3_wino_q<false, 32, 8, 3>; break;
-                case 8: fn = &k_conv3x3_wino_q<false, 32, 8, 8>; break;
-                case 16: fn = &k_conv3x3_wino_q<false, 32, 8, 16>; break;
-                case 31: fn = &k_conv3x3_wino_q<false, 32, 8, 31>; break;
-                case 32: fn = &k_conv3x3_wino_q<false, 32, 8, 32>; break;
-                default: break;
-            }
-        }
-#endif
-        bool seen2 = false;
-        for (const void *q : configured) seen2 = seen2 || q == reinterpret_cast<const void *>(fn);
-        if (!seen2) {
-            DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            for (auto &q : configured)
-                if (!q) { q = reinterpret_cast<const void *>(fn); break; }
-        }
-        const int nq = nw == 8 ? 4096 / mt : 64;
-        size_t shmem_q = (size_t)(2 * 16 * mt * (kc + 4) + 2 * (mt == 64 ? RAW_MAXPIX : RAW_MAXPIX / 2) * (kc + 4) + 2 * 16 * 2 * kc) * sizeof(float);
-        const size_t epi_q = (size_t)((nw / 2) * 4 * 16 * 64 + 4 * mt * (nq + 4)) * sizeof(float);   // exchange + row image
-        if (shmem_q < epi_q) shmem_q = epi_q;
-        const int64_t tiles_q = (int64_t)c.B * (c.Hout / 2) * (c.Wout / 2);
-        const int64_t mblocks_q = nimg == 1 ? tiles_q / mt : ceil_div(c.B, nimg);
-        fn<<<(unsigned)(mblocks_q * (c.Cout / nq)), nw * 64, shmem_q, st>>>(c, bh, bw, nimg);
-        DLPM_LAUNCH_CHECK();
-        return DLPM_OK;
-    }
-    fn<<<(unsigned)grid, 256, piped ? shmem_p : shmem, st>>>(c, bh, bw, nimg);
+    const int nq = nw == 8 ? 4096 / mt : 64;
+    size_t shmem = (size_t)(2 * 16 * mt * (kc + 4) + 2 * (mt == 64 ? RAW_MAXPIX : RAW_MAXPIX / 2) * (kc + 4) + 2 * 16 * 2 * kc) * sizeof(float);
+    const size_t epi = (size_t)((nw / 2) * 4 * 16 * 64 + 4 * mt * (nq + 4)) * sizeof(float);   // exchange + row image
+    if (shmem < epi) shmem = epi;
+    const int64_t tiles = (int64_t)c.B * (c.Hout / 2) * (c.Wout / 2);
+    const int64_t mblocks = nimg == 1 ? tiles / mt : ceil_div(c.B, nimg);
+    fn<<<(unsigned)(mblocks * (c.Cout / nq)), nw * 64, shmem, st>>>(c, bh, bw, nimg);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }
@@ -1361,9 +558,7 @@ int64_t wino_weight_floats(int Cout, int Cin) {
 int relayout_weight_wino(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st) {
     const int64_t n = (int64_t)(Cout / 32) * (Cin / WKC) * WGRP * 256;
     DLPM_HIP(hipMemsetAsync(dst_dev + n, 0, (size_t)8 * 256 * sizeof(float), st));
-    if (wino_variant() == 2) k_relayout_weight_wino_q<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin, wino_kc_for(Cout));
-    else if (wino_pipelined()) k_relayout_weight_wino_p<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
-    else k_relayout_weight_wino<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
+    k_relayout_weight_wino_q<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin, wino_kc_for(Cout));
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }
