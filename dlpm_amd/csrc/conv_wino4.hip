@@ -497,11 +497,17 @@ bool wino4_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
     return true;
 }
 
-// dispatch policy: F(4x4) wherever it applies, except blocks of 16 one-tile images (4x4-pixel tensors) when the F(2x2)
-// weights are there too: those stage 576 halo pixels per 256 outputs and measured slower (1.55 vs 1.00 ms/step)
+// dispatch policy: F(4x4) wherever it applies, except -- when the F(2x2) weights are there too --
+//   * blocks of 16 one-tile images (4x4-pixel tensors): 576 halo pixels staged per 256 outputs, measured 1.55 vs 1.00 ms/step;
+//   * launches whose grid would leave CUs empty (fewer than 256 workgroups of 256 pixels x 128 channels, e.g. 8x8 tensors
+//     at batch 256): the F(2x2) kernel's 128-pixel blocks give twice as many workgroups.
 bool wino4_preferred(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
     if (!wino4_geometry(c, bh, bw, nimg)) return false;
-    return *nimg <= 4 || !c.w_wino;
+    if (!c.w_wino) return true;
+    if (*nimg > 4) return false;
+    const int64_t tiles = (int64_t)c.B * (c.Hout / 4) * (c.Wout / 4);
+    const int64_t mblocks = *nimg == 1 ? tiles / F4_TILES : ceil_div(c.B, *nimg);
+    return mblocks * (c.Cout / F4_NQ) >= 256;
 }
 
 int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
