@@ -233,11 +233,19 @@ def main():
                                     'the matrix pipe, mfma_utilisation = executed MFMA FLOP/s over the fp32 MFMA peak' % executed)
         at = prof.get('attention')
         if at and at['ms'] > 0:
+            # QKV attention reads qkv (3C) and writes out (C) per token: 16 T C bytes for 4 T^2 C flops per sample, i.e.
+            # T/4 FLOP/B -- below the ridge (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B) for T <= 64: HBM-bound there
             tf = at['flops'] / (at['ms'] * 1e-3) / 1e12
-            att = dict(kernel='k_attention<64,NT> (QK^T / softmax / AV on the fp32 MFMA 16x16x4, one workgroup per head)', bound='mfma',
-                       achieved=round(tf, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s', frac=round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+            gbs = at['bytes'] / (at['ms'] * 1e-3) / 1e9
+            hbm_bound = at['flops'] / at['bytes'] < PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+            att = dict(kernel='k_attention<64,NT> (QK^T / softmax / AV on the fp32 MFMA 16x16x4, K and V of a head in LDS, one workgroup per (sample, head, 64 queries))',
+                       bound='hbm' if hbm_bound else 'mfma',
+                       achieved=round(gbs, 1) if hbm_bound else round(tf, 2),
+                       peak=PEAK_HBM_GBS if hbm_bound else PEAK_FP32_MFMA_TFLOPS, unit='GB/s' if hbm_bound else 'TFLOP/s',
+                       frac=round(gbs / PEAK_HBM_GBS, 4) if hbm_bound else round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                       tflops=round(tf, 2), gbytes_per_s=round(gbs, 1), flop_per_byte=round(at['flops'] / at['bytes'], 2),
                        launches_per_step=at['launches'] // nprof, avg_launch_ms=round(at['ms'] / at['launches'], 5),
-                       note='T <= 256 tokens per head: latency-bound (0.2 % of the step FLOPs)')
+                       note='algorithmic bytes = qkv read + out write; 0.2 % of the step FLOPs')
         u = prof.get('update')
         if u:
             gbs = u['bytes'] / (u['ms'] * 1e-3) / 1e9
