@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- samples/sec of DLPM's reverse-sampling loop at T=1000 on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1: started under torch.distributed.run (RANK / WORLD_SIZE set) the process is one rank; started
+plainly, it spawns the N ranks itself (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 ...`, before this process has touched the GPU), waits, and exits with their code.
 
 Workload (N = 1 and per GPU for N > 1, weak scaling): BASELINE.json configs[2] -- CIFAR-10 shaped
 state [1024, 3, 32, 32], the reference's cifar10.yml UNet (39.6 M parameters, attention at 8x8 and
@@ -9,16 +13,20 @@ state [1024, 3, 32, 32], the reference's cifar10.yml UNet (39.6 M parameters, at
 alpha = 1.7, clamp_a = 10, clamp_eps = 50, fp32, Philox noise keyed by the global sample index.
 
 A "step" is ONE reverse step (UNet forward + fused update) over the whole batch: W warm-up steps,
-then exactly K timed steps between barrier + synchronize pairs, max over ranks.  The trajectory has
-T-1 = 999 identical steps, so
-    value = B_total / (init_s + 999 * ms_per_step / 1000 + allgather_s)        [samples/s at T=1000]
-with init (A draws + tables + x_T) and the final RCCL all-gather measured in the same run.  With
---steps 999 --warmup 0 the timed region IS the whole trajectory.
+then exactly K timed steps between barrier + synchronize pairs, max over ranks -> `ms_per_step`.
+`value` [samples/s at T=1000] is then MEASURED, not extrapolated: one whole trajectory -- init (A
+draws, tables, x_T) + all T-1 = 999 reverse steps + the final RCCL all-gather (N > 1) -- is timed
+between barriers in the same run (`full_trajectory_s`, max over ranks) and value = B_total / that.
+`--no-full-trajectory` skips it; value is then init + 999 * ms_per_step + gather and says so
+(`value_source`).  With --steps 999 --warmup 0 the K-step region is itself a whole trajectory.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,14 +46,38 @@ METRIC = {
     'mnist': 'samples/sec at T=1000 (MNIST 32x32, alpha=1.7) [parity config, not the headline]',
     'celeba64': 'samples/sec at T=1000 (CelebA 64x64, alpha=1.8) [builder-defined net, not the headline]',
 }
-# HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc runs,
-# FETCH_SIZE doubled per the gfx950 guide): profiles/r01/pmc_hbm_traffic_*.txt
-PMC_TRAFFIC_BYTES_PER_LAUNCH = {'k_conv3x3_halo_ws<128,2,2,2,2,2>': (0.6663 + 0.2194) * 1e9,  # fetch + write, mean over all three instantiations
-                                'k_conv3x3_wino_q': (0.7141 + 0.2238) * 1e9,   # fetch + write, mean over both instantiations (47 launches/step), v14
-                                'k_conv3x3_wino4': (1.0377 + 0.3134) * 1e9}    # fetch + write, mean over both instantiations (33 launches/step)
-PMC_TRAFFIC_FILE = 'profiles/r01/pmc_hbm_traffic_v18.txt'
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 PEAK_HBM_GBS = 8000.0
+# HBM traffic of the dominant kernel comes from rocprofv3 PMC passes (separate --pmc runs, FETCH_SIZE doubled per the
+# gfx950 guide), which cannot run inside this process.  tools/pmc_summarize.py --json writes profiles/pmc_traffic.json
+# with the digest of the kernel sources it measured; the figure is reported only while that digest matches this build.
+PMC_TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+
+
+def source_digest():
+    """sha256 over the kernel sources: identifies the build a PMC measurement belongs to."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'dlpm_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h', '.cpp')):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kname, workload):
+    try:
+        rec = json.load(open(PMC_TRAFFIC_JSON))
+    except Exception:
+        return None, 'no PMC pass recorded (profiles/pmc_traffic.json absent)'
+    if rec.get('source_digest') != source_digest():
+        return None, 'the recorded PMC pass (%s) measured an older build of the kernels; not reported' % rec.get('file')
+    if rec.get('workload') != workload:
+        return None, 'the recorded PMC pass measured workload %s' % rec.get('workload')
+    v = rec.get('kernels', {}).get(kname)
+    if v is None:
+        return None, 'kernel absent from %s' % rec.get('file')
+    return v, 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, mean over the launches of a step) from the rocprofv3 PMC passes of this build: %s' % rec.get('file')
 
 
 def parse_prof(txt):
@@ -58,7 +90,7 @@ def parse_prof(txt):
 
 def cpu_baseline(cfg_name, T, alpha, budget_s=20.0):
     """The oracle (a torch-CPU port of the reference loop) on this box's host cores, bounded sample."""
-    from oracle import nets, sampler as osampler, process as P
+    from oracle import nets, sampler as osampler
     import dlpm_amd
     p = dlpm_amd.load_config(cfg_name)
     torch.manual_seed(1234)
@@ -88,6 +120,125 @@ def cpu_baseline(cfg_name, T, alpha, budget_s=20.0):
                        '(%.1f s), extrapolated linearly to 999 steps' % (B, steps, dt))
 
 
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` started plainly: launch the N ranks as children.  This process has not initialised the GPU
+    (importing torch does not), and it never execs: it waits and hands the children's exit code on."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    return subprocess.run(cmd, env=env).returncode
+
+
+class NativeRunner:
+    """The hot path through the C ABI: dlpm_sampler_begin / _steps / _copy_state on this rank's GPU."""
+
+    def __init__(self, args, cfg_name, B, T, alpha, rank, dev):
+        import dlpm_amd
+        from dlpm_amd import _lib
+        self.lib, self.L, self.dev = _lib, _lib.lib(), dev
+        p = dlpm_amd.load_config(cfg_name)
+        torch.manual_seed(1234)
+        self.net = dlpm_amd.rerandomize_(dlpm_amd.init_model_by_parameter(p), 4321)
+        if args.conv != 'auto' or args.dispatch_batch:
+            self.net.set_conv_policy(args.conv, args.dispatch_batch)
+        self.shape = [B, p['data']['channels'], p['data']['image_size'], p['data']['image_size']]
+        ev = p['eval']['dlpm']
+        self.meth = dlpm_amd.GenerativeLevyProcess(alpha, str(dev), T, rescale_timesteps=True, seed=0, sample_offset=rank * B,
+                                                   use_graph=not args.no_graph, isotropic=not args.non_iso, LIM=args.lim)
+        self.st = _lib.stream_ptr()
+        self.h = self.meth._native_sampler(self.net, self.shape, _lib.SMP_LIM if args.lim else 0, 0.0, ev['clamp_a'],
+                                           ev['clamp_eps'], 0)
+        self.flops_per_sample = self.net.flops_per_sample(self.shape[2])
+
+    def begin(self):
+        self.lib.check(self.L.dlpm_sampler_begin(self.h, self.st))
+
+    def steps(self, n):
+        self.lib.check(self.L.dlpm_sampler_steps(self.h, n, self.st))
+
+    def state(self):
+        x = torch.empty(self.shape, device=self.dev)
+        self.lib.check(self.L.dlpm_sampler_copy_state(self.h, x.data_ptr(), self.st))
+        return x
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def profile(self, nprof):
+        self.lib.check(self.L.dlpm_prof_enable(1))
+        self.steps(nprof)
+        buf = C.create_string_buffer(1 << 16)
+        self.lib.check(self.L.dlpm_prof_report(buf, len(buf)))
+        self.lib.check(self.L.dlpm_prof_enable(0))
+        return parse_prof(buf.value.decode())
+
+
+class DryRunner:
+    """DLPM_BENCH_DRY_RUN=1 (tests only, never a measurement): the same launch / rendezvous / barrier / gather / JSON
+    control flow on CPU tensors, with the sampler replaced by a stub, so the N-rank path is exercised without a GPU."""
+
+    def __init__(self, args, cfg_name, B, T, alpha, rank, dev):
+        self.shape, self.rank, self.flops_per_sample, self.t = [B, 3, 4, 4], rank, 1.0, 0
+
+    def begin(self):
+        self.t = 0
+
+    def steps(self, n):
+        self.t += n
+        time.sleep(1e-4 * n)
+
+    def state(self):
+        B = self.shape[0]
+        idx = torch.arange(self.rank * B, (self.rank + 1) * B, dtype=torch.float32)
+        return idx.view(-1, 1, 1, 1) * torch.ones(self.shape) + self.t
+
+    def sync(self):
+        pass
+
+    def profile(self, nprof):
+        return {}
+
+
+def roofline_block(prof, nprof, cfg_name, B, workload):
+    wino4, wino = prof.get('conv3x3_wino4'), prof.get('conv3x3_wino')
+    c = wino4 or wino or prof.get('conv3x3_halo') or prof.get('conv3x3_igemm')
+    if not c:
+        return None
+    alg = c['flops'] / (c['ms'] * 1e-3) / 1e12
+    if wino4:
+        kname, executed = 'k_conv3x3_wino4', 36.0 / 144.0
+        kdesc = ('k_conv3x3_wino4 (3x3 stride-1 conv as Winograd F(4x4,3x3) on the fp32 MFMA 16x16x4: 36 instead of 144 '
+                 'multiplies per 4x4 output tile and channel pair; fused GN+SiLU staging, in-register output transform, '
+                 'bias/residual/GN-stats epilogue)')
+    elif wino:
+        kname, executed = 'k_conv3x3_wino_q', 16.0 / 36.0
+        kdesc = ('k_conv3x3_wino_q (3x3 stride-1 conv as Winograd F(2x2,3x3) on the fp32 MFMA 32x32x2: 16 instead of 36 '
+                 'multiplies per 2x2 output tile and channel pair; fused GN+SiLU staging, in-register output transform, '
+                 'bias/residual/GN-stats epilogue)')
+    else:
+        kname, executed = 'k_conv3x3_halo_ws', 1.0
+        kdesc = ('k_conv3x3_halo_ws<128,2,2,2,2,2> (3x3 stride-1 conv, fp32 MFMA 32x32x2, LDS halo tile + register-streamed '
+                 'weights, fused GN+SiLU/bias/residual/GN-stats)')
+    ach = alg * executed                      # FLOP/s actually executed on the matrix pipe
+    traffic, tnote = pmc_traffic(kname, workload)
+    mfma = [v for k, v in prof.items() if k.startswith('conv') and 'stem' not in k and 'direct' not in k and 'head' not in k]
+    return dict(kernel=kdesc, bound='mfma', achieved=round(ach, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
+                frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_note=tnote,
+                algorithmic_bytes_per_launch=c['bytes'] / c['launches'],
+                note=('achieved = FLOP/s EXECUTED on the fp32 matrix pipe = algorithmic (direct-convolution, 2*9*Cin*Cout per '
+                      'output pixel) FLOP/s x %.4f, the share of those multiplies this kernel executes; frac = achieved / the '
+                      'dense fp32 MFMA peak' % executed),
+                algorithmic_tflops=round(alg, 3), executed_share_of_algorithmic_flops=round(executed, 4),
+                launches_per_step=c['launches'] // nprof, avg_launch_ms=round(c['ms'] / c['launches'], 5),
+                algorithmic_flops_per_launch_avg=c['flops'] / c['launches'], share_of_step_ms=round(c['ms'] / nprof, 3),
+                all_mfma_conv_classes_algorithmic_tflops=round(sum(v['flops'] for v in mfma) / (sum(v['ms'] for v in mfma) * 1e-3) / 1e12, 3))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -98,6 +249,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='skip the instrumented eager pass (roofline = null)')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-full-trajectory', action='store_true',
+                    help='do not time a whole T-step trajectory; value = init + (T-1) * ms_per_step + gather')
+    ap.add_argument('--conv', default='auto', choices=['auto', 'f4', 'f2', 'igemm'], help='convolution generation (A/B runs)')
+    ap.add_argument('--dispatch-batch', type=int, default=0, help='dlpm_unet_set_conv_policy dispatch batch (A/B runs)')
     ap.add_argument('--non-iso', action='store_true',
                     help='non-isotropic noise variant (--non_iso of the reference): [T,B,D] tables; not the headline config')
     ap.add_argument('--lim', action='store_true',
@@ -105,16 +260,24 @@ def main():
                          'not the headline config')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    assert world == args.gpus, 'WORLD_SIZE=%d but --gpus %d (use torch.distributed.run for N > 1)' % (world, args.gpus)
-    # test hooks (not used by the driver): run the N-rank control flow on a 1-GPU box -- every rank on cuda:0 with gloo
+    assert world == args.gpus, 'WORLD_SIZE=%d but --gpus %d' % (world, args.gpus)
+    # test hooks (never used by the driver): DLPM_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 (N-rank control flow on a
+    # 1-GPU box, with DLPM_BENCH_BACKEND=gloo); DLPM_BENCH_DRY_RUN=1 replaces the sampler by a CPU stub (no measurement)
+    dry = os.environ.get('DLPM_BENCH_DRY_RUN') == '1'
     if os.environ.get('DLPM_BENCH_SINGLE_DEVICE') == '1':
         local = 0
-    backend = os.environ.get('DLPM_BENCH_BACKEND', 'nccl')
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+    backend = 'gloo' if dry else os.environ.get('DLPM_BENCH_BACKEND', 'nccl')
+    if dry:
+        dev = torch.device('cpu')
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device('cuda', local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -122,11 +285,7 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-
-    import dlpm_amd
-    from dlpm_amd import _lib
     from dlpm_amd.dist import all_gather_samples
-    L = _lib.lib()
 
     cfg_name, B, T, alpha = WORKLOADS[args.workload]
     if args.batch:
@@ -134,103 +293,82 @@ def main():
     K, W = args.steps, args.warmup
     nsteps = T if args.lim else T - 1        # network evaluations of one sample() call
     assert 1 <= K and W + K <= nsteps, 'at most %d steps exist' % nsteps
-    p = dlpm_amd.load_config(cfg_name)
-    torch.manual_seed(1234)
-    net = dlpm_amd.rerandomize_(dlpm_amd.init_model_by_parameter(p), 4321)
-    shape = [B, p['data']['channels'], p['data']['image_size'], p['data']['image_size']]
-    ev = p['eval']['dlpm']
-    meth = dlpm_amd.GenerativeLevyProcess(alpha, str(dev), T, rescale_timesteps=True, seed=0, sample_offset=rank * B,
-                                          use_graph=not args.no_graph, isotropic=not args.non_iso, LIM=args.lim)
-    st = _lib.stream_ptr()
-    h = meth._native_sampler(net, shape, _lib.SMP_LIM if args.lim else 0, 0.0, ev['clamp_a'], ev['clamp_eps'], 0)
-    flops_per_sample = net.flops_per_sample(shape[2])
+    run = (DryRunner if dry else NativeRunner)(args, cfg_name, B, T, alpha, rank, dev)
+    shape = run.shape
 
     def barrier():
-        torch.cuda.synchronize()
+        run.sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        run.sync()
+
+    def max_over_ranks(*vals):
+        t = torch.tensor(vals, dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.tolist()
 
     # ---- init (A, tables, x_T)
     barrier()
     t0 = time.perf_counter()
-    _lib.check(L.dlpm_sampler_begin(h, st))
-    torch.cuda.synchronize()
+    run.begin()
+    run.sync()
     init_s = time.perf_counter() - t0
     # ---- warm-up (the first step runs eagerly, the second is captured into the graph)
-    _lib.check(L.dlpm_sampler_steps(h, W, st))
+    run.steps(W)
     # ---- timed region: exactly K steps
     barrier()
     t0 = time.perf_counter()
-    _lib.check(L.dlpm_sampler_steps(h, K, st))
+    run.steps(K)
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt, init_s], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt, init_s = tmax.tolist()
+    dt, init_s = max_over_ranks(dt, init_s)
     ms_per_step = dt / K * 1e3
-    # ---- final gather of the finished samples (single RCCL all-gather)
-    x = torch.empty(shape, device=dev)
-    _lib.check(L.dlpm_sampler_copy_state(h, x.data_ptr(), st))
-    barrier()
-    t0 = time.perf_counter()
-    full = all_gather_samples(x, B * world)
-    barrier()
-    gather_s = time.perf_counter() - t0
+    # ---- final gather of the finished samples: ONE RCCL all-gather (nothing to gather on one GPU)
+    x = run.state()
+    gather_s = None
+    if world > 1:
+        barrier()
+        t0 = time.perf_counter()
+        full = all_gather_samples(x, B * world)
+        barrier()
+        gather_s = max_over_ranks(time.perf_counter() - t0)[0]
+    else:
+        full = x
     finite = bool(torch.isfinite(full).all().item())
+    assert full.shape[0] == B * world
 
-    total_s = init_s + nsteps * ms_per_step / 1e3 + gather_s
-    value = B * world / total_s
+    # ---- one WHOLE trajectory, timed end to end: init + every reverse step + gather
+    full_s = None
+    if K == nsteps and W == 0:
+        full_s = init_s + dt + (gather_s or 0.0)
+    elif not args.no_full_trajectory:
+        barrier()
+        t0 = time.perf_counter()
+        run.begin()
+        run.steps(nsteps)
+        x = run.state()
+        full = all_gather_samples(x, B * world) if world > 1 else x
+        barrier()
+        full_s = max_over_ranks(time.perf_counter() - t0)[0]
+        finite = finite and bool(torch.isfinite(full).all().item())
+    if full_s is not None:
+        value, value_source = B * world / full_s, 'measured: one whole trajectory (init + %d reverse steps%s) timed between barriers' % (
+            nsteps, ' + all-gather' if world > 1 else '')
+    else:
+        total_s = init_s + nsteps * ms_per_step / 1e3 + (gather_s or 0.0)
+        value, value_source = B * world / total_s, 'extrapolated: init + %d x ms_per_step (%d timed steps)%s' % (
+            nsteps, K, ' + all-gather' if world > 1 else '')
 
     roofline, upd, breakdown, att = None, None, None, None
-    if not args.no_prof and rank == 0:
+    if not args.no_prof and rank == 0 and not dry:
         # instrumented eager pass on the same stream: HIP events around every launch, by kernel class
-        _lib.check(L.dlpm_prof_enable(1))
         nprof = 3
-        _lib.check(L.dlpm_sampler_steps(h, nprof, st))
-        buf = C.create_string_buffer(1 << 16)
-        _lib.check(L.dlpm_prof_report(buf, len(buf)))
-        _lib.check(L.dlpm_prof_enable(0))
-        prof = parse_prof(buf.value.decode())
+        run.begin()
+        run.steps(2)
+        prof = run.profile(nprof)
         breakdown = {k: round(v['ms'] / nprof, 4) for k, v in prof.items()}
-        wino4, wino = prof.get('conv3x3_wino4'), prof.get('conv3x3_wino')
-        c = wino4 or wino or prof.get('conv3x3_halo') or prof.get('conv3x3_igemm')
-        if c:
-            ach = c['flops'] / (c['ms'] * 1e-3) / 1e12
-            executed = None
-            if wino4:
-                kname, executed = 'k_conv3x3_wino4', 36.0 / 144.0
-                kdesc = ('k_conv3x3_wino4 (3x3 stride-1 conv as Winograd F(4x4,3x3) on the fp32 MFMA 16x16x4: 36 instead of 144 '
-                         'multiplies per 4x4 output tile and channel pair; fused GN+SiLU staging, in-register output transform, '
-                         'bias/residual/GN-stats epilogue)')
-            elif wino:
-                kname, executed = 'k_conv3x3_wino_q', 16.0 / 36.0
-                kdesc = ('k_conv3x3_wino_q (3x3 stride-1 conv as Winograd F(2x2,3x3) on the fp32 MFMA 32x32x2: 16 instead of 36 '
-                         'multiplies per 2x2 output tile and channel pair; fused GN+SiLU staging, in-register output transform, '
-                         'bias/residual/GN-stats epilogue)')
-            else:
-                kname = 'k_conv3x3_halo_ws<128,2,2,2,2,2>'
-                kdesc = ('k_conv3x3_halo_ws<128,2,2,2,2,2> (3x3 stride-1 conv, fp32 MFMA 32x32x2, LDS halo tile + register-streamed '
-                         'weights, fused GN+SiLU/bias/residual/GN-stats)')
-            roofline = dict(kernel=kdesc,
-                            bound='mfma', achieved=round(ach, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                            frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                            traffic=(PMC_TRAFFIC_BYTES_PER_LAUNCH.get(kname) if cfg_name == 'cifar10' and B == 1024 else None),
-                            traffic_note='HBM bytes per launch (mean over the launches of a step) from committed rocprofv3 PMC passes, %s; algorithmic bytes per launch = %.4g' % (PMC_TRAFFIC_FILE, c['bytes'] / c['launches']),
-                            launches_per_step=c['launches'] // nprof, avg_launch_ms=round(c['ms'] / c['launches'], 5),
-                            flops_per_launch_avg=c['flops'] / c['launches'],
-                            share_of_step_ms=round(c['ms'] / nprof, 3),
-                            all_mfma_conv_classes_tflops=round(sum(v['flops'] for k, v in prof.items() if k.startswith('conv') and 'stem' not in k and 'direct' not in k)
-                                                               / (sum(v['ms'] for k, v in prof.items() if k.startswith('conv') and 'stem' not in k and 'direct' not in k) * 1e-3) / 1e12, 3))
-            if executed:
-                # `achieved` counts ALGORITHMIC flops (2*9*Cin*Cout per output pixel, the direct-convolution count of
-                # SURVEY 8d); a Winograd kernel executes a fraction of them on the matrix pipe (36/144 for F(4x4,3x3),
-                # 16/36 for F(2x2,3x3)), so `frac` can exceed 1: the MFMA pipe's own utilisation is reported next to it
-                roofline['mfma_executed_tflops'] = round(ach * executed, 3)
-                roofline['mfma_utilisation'] = round(ach * executed / PEAK_FP32_MFMA_TFLOPS, 4)
-                roofline['note'] = ('achieved = algorithmic (direct-convolution) FLOP/s; the Winograd kernel executes %.4f of them on '
-                                    'the matrix pipe, mfma_utilisation = executed MFMA FLOP/s over the fp32 MFMA peak' % executed)
+        roofline = roofline_block(prof, nprof, cfg_name, B, args.workload if not args.batch else '%s@B%d' % (args.workload, B))
         at = prof.get('attention')
         if at and at['ms'] > 0:
             # QKV attention reads qkv (3C) and writes out (C) per token: 16 T C bytes for 4 T^2 C flops per sample, i.e.
@@ -251,32 +389,40 @@ def main():
             gbs = u['bytes'] / (u['ms'] * 1e-3) / 1e9
             upd = dict(kernel='k_update_rows (fused x_{t-1} update, Philox noise)', bound='hbm', achieved=round(gbs, 1),
                        peak=PEAK_HBM_GBS, unit='GB/s', frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None,
-                       bytes_per_launch=u['bytes'] / u['launches'], avg_launch_ms=round(u['ms'] / u['launches'], 5))
+                       bytes_per_launch=u['bytes'] / u['launches'], avg_launch_ms=round(u['ms'] / u['launches'], 5),
+                       note='algorithmic bytes = read x + read eps + write x (12 B/element, in-kernel Philox); in-loop launch '
+                            'time from HIP events (the state was last touched a whole UNet forward earlier: HBM, not cache)')
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
         cpu = cpu_baseline(cfg_name, T, alpha)
 
     if rank == 0:
-        step_tflops = flops_per_sample * B * world / (ms_per_step * 1e-3) / 1e12
+        step_tflops = run.flops_per_sample * B * world / (ms_per_step * 1e-3) / 1e12
         out = {
             'metric': METRIC[cfg_name], 'value': round(value, 4),
             'unit': 'samples/s', 'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(ms_per_step, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': args.workload + ('+non_iso' if args.non_iso else '') + ('+lim_sde' if args.lim else ''), 'state_shape_per_gpu': shape, 'global_batch': B * world,
                        'reverse_steps': T, 'alpha': alpha, 'timed_steps': K, 'trajectory_steps': nsteps,
-                       'init_ms': round(init_s * 1e3, 3), 'allgather_ms': round(gather_s * 1e3, 3),
+                       'init_ms': round(init_s * 1e3, 3), 'allgather_ms': None if gather_s is None else round(gather_s * 1e3, 3),
                        'net': 'reference cifar10.yml UNet (mc=128, 39.6M params), random init + re-drawn zero tensors'
                        if cfg_name == 'cifar10' else cfg_name,
                        'rng': 'philox (device, keyed by global sample index)', 'hip_graph': not args.no_graph,
-                       'parallelism': 'batch-sharded x%d, one RCCL all-gather at the end' % world},
-            'gflop_per_sample_step': round(flops_per_sample / 1e9, 4),
+                       'conv_generation': args.conv,
+                       'parallelism': ('batch-sharded x%d, one RCCL all-gather at the end' % world) if world > 1 else 'single GPU (no collective)'},
+            'value_source': value_source,
+            'full_trajectory_s': None if full_s is None else round(full_s, 4),
+            'extrapolated_value': round(B * world / (init_s + nsteps * ms_per_step / 1e3 + (gather_s or 0.0)), 4),
+            'gflop_per_sample_step': round(run.flops_per_sample / 1e9, 4),
             'whole_step_tflops': round(step_tflops, 3),
             'whole_step_frac_of_fp32_peak': round(step_tflops / (PEAK_FP32_MFMA_TFLOPS * world), 4),
             'samples_finite': finite,
             'roofline': roofline, 'update_kernel': upd, 'attention_kernel': att, 'ms_per_step_by_kernel_class': breakdown, 'cpu_baseline': cpu,
         }
-        print(json.dumps(out))
+        if dry:
+            out['dry_run'] = 'control-flow test only (DLPM_BENCH_DRY_RUN=1): stub sampler on CPU, NOT a measurement'
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

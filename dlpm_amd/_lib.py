@@ -12,8 +12,9 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libdlpm_amd.so')
 
 vp, i32, i64, u32, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
 
-ABI_VERSION = 2   # must equal dlpm_abi_version(): struct layouts below mirror include/dlpm_amd.h at this version
+ABI_VERSION = 3   # must equal dlpm_abi_version(): struct layouts below mirror include/dlpm_amd.h at this version
 UPD_DLIM, UPD_CLIP, UPD_ADVANCE, SMP_NO_FUSED_MLP, UPD_ELEMENTWISE, SMP_LIM = 1, 2, 4, 8, 16, 32
+CONV_AUTO, CONV_F4, CONV_F2, CONV_IGEMM = 0, 1, 2, 3
 
 
 class MT19937(C.Structure):
@@ -91,6 +92,8 @@ SIGNATURES = {
     'dlpm_unet_feature_shape': (C.c_int, [vp, C.c_int, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     'dlpm_unet_get_feature': (C.c_int, [vp, C.c_int, vp, i64, vp]),
     'dlpm_unet_flops_per_sample': (i64, [vp]),
+    'dlpm_unet_set_conv_policy': (C.c_int, [vp, i32, i64]),
+    'dlpm_unet_plan_version': (i64, [vp]),
     'dlpm_unet_destroy': (None, [vp]),
     'dlpm_mlp_create': (C.c_int, [i32, i32, i32, i32, C.POINTER(vp)]),
     'dlpm_mlp_set_param': (C.c_int, [vp, C.c_char_p, vp, i64]),
@@ -108,6 +111,7 @@ SIGNATURES = {
     'dlpm_sampler_reseed': (C.c_int, [vp, u64, i64]),
     'dlpm_sampler_begin': (C.c_int, [vp, vp]),
     'dlpm_sampler_begin_injected': (C.c_int, [vp, vp, vp, vp]),
+    'dlpm_sampler_set_state': (C.c_int, [vp, vp, i32, vp]),
     'dlpm_sampler_step_injected': (C.c_int, [vp, vp, vp]),
     'dlpm_sampler_steps': (C.c_int, [vp, i32, vp]),
     'dlpm_sampler_set_history': (C.c_int, [vp, vp, vp]),

@@ -27,6 +27,12 @@ struct ConvLaunch {
     int in_nchw = 0, out_nchw = 0;  // boundary layouts
     int ws_gemm = 0;                // 1x1 only: use the weight-streaming kernel (TAPS = 1) instead of k_conv_igemm
     int abl = 0;                    // timing-only ablation bits (DLPM_ABL env; results are wrong when set)
+    // Which kernel generation a 3x3 stride-1 launch takes is a function of the LAYER (geometry + this policy), never of the
+    // batch the launch happens to carry: the generations round differently, and a sample must not depend on how its batch
+    // was sharded or chunked.  gen = DLPM_CONV_AUTO / _F4 / _F2 / _IGEMM (include/dlpm_amd.h); dispatch_B > 0 lets AUTO
+    // weigh grid occupancy for a caller-declared batch (a property of the configuration, the same on every rank / chunk).
+    int gen = 0;
+    int64_t dispatch_B = 0;
     // Optional fused GroupNorm statistics of the OUTPUT: per (image, pixel tile, channel) the
     // pair (mean, centred sum of squares) over the tile's pixels, written by the MFMA kernels'
     // epilogue when the tile lies inside one image.  [B][HW/tile][Cout] float2 with tile =

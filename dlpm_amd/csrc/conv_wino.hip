@@ -472,7 +472,7 @@ int wino_waves(const ConvLaunch &c) {
 }
 
 bool wino_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
-    if (wino_disabled() || !c.w_wino || c.ks != 3 || c.stride != 1 || c.in_nchw || c.out_nchw || c.abl) return false;
+    if (wino_disabled() || c.gen == DLPM_CONV_IGEMM || !c.w_wino || c.ks != 3 || c.stride != 1 || c.in_nchw || c.out_nchw || c.abl) return false;
     if ((c.Hout & 1) || (c.Wout & 1) || c.Cout % WN != 0 || (c.C0 + c.C1) % WKC != 0 || c.C0 % WKC != 0) return false;
     if ((c.R0 & 3) != 0) return false;
     if (c.ups && ((c.Hout & 3) || (c.Wout & 3))) return false;

@@ -497,16 +497,23 @@ bool wino4_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
     return true;
 }
 
-// dispatch policy: F(4x4) wherever it applies, except -- when the F(2x2) weights are there too --
-//   * blocks of 16 one-tile images (4x4-pixel tensors): 576 halo pixels staged per 256 outputs, measured 1.55 vs 1.00 ms/step;
-//   * launches whose grid would leave CUs empty (fewer than 256 workgroups of 256 pixels x 128 channels, e.g. 8x8 tensors
-//     at batch 256): the F(2x2) kernel's 128-pixel blocks give twice as many workgroups.
+// dispatch policy (a function of the layer and of ConvLaunch::gen / dispatch_B, never of the batch in this launch:
+// the generations round differently and a sample must not depend on how its batch was sharded or chunked):
+//   DLPM_CONV_F4     F(4x4) wherever the geometry qualifies;
+//   DLPM_CONV_F2 / DLPM_CONV_IGEMM   never;
+//   DLPM_CONV_AUTO   F(4x4) wherever it applies, except -- when the F(2x2) weights are there too --
+//     * blocks of 16 one-tile images (4x4-pixel tensors): 576 halo pixels staged per 256 outputs, measured 1.55 vs 1.00 ms/step;
+//     * with a caller-declared dispatch batch: launches whose grid would leave CUs empty AT THAT BATCH (fewer than 256
+//       workgroups of 256 pixels x 128 channels, e.g. 8x8 tensors at batch 256): the F(2x2) kernel's 128-pixel blocks give
+//       twice as many workgroups.
 bool wino4_preferred(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
+    if (c.gen == DLPM_CONV_F2 || c.gen == DLPM_CONV_IGEMM) return false;
     if (!wino4_geometry(c, bh, bw, nimg)) return false;
-    if (!c.w_wino) return true;
+    if (!c.w_wino || c.gen == DLPM_CONV_F4) return true;
     if (*nimg > 4) return false;
-    const int64_t tiles = (int64_t)c.B * (c.Hout / 4) * (c.Wout / 4);
-    const int64_t mblocks = *nimg == 1 ? tiles / F4_TILES : ceil_div(c.B, *nimg);
+    if (c.dispatch_B <= 0) return true;
+    const int64_t tiles = c.dispatch_B * (c.Hout / 4) * (c.Wout / 4);
+    const int64_t mblocks = *nimg == 1 ? tiles / F4_TILES : ceil_div(c.dispatch_B, (int64_t)*nimg);
     return mblocks * (c.Cout / F4_NQ) >= 256;
 }
 

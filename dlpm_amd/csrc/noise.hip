@@ -585,7 +585,7 @@ extern "C" int dlpm_update_f32(const dlpm_update_args *a, dlpm_stream_t stream) 
     // algorithmic bytes: read x, read eps, write x (+ read z when injected)
     const bool elem = a->flags & DLPM_UPD_ELEMENTWISE;
     ProfScope ps(elem ? "update_elem" : "update", 0.0,
-                 4.0 * (double)a->B * a->D * ((a->z_dev ? 4 : 3) + (elem ? 2 : 0) + (a->hist_pp ? 1 : 0)), as_stream(stream));
+                 4.0 * (double)a->B * a->D * ((a->z_dev ? 4 : 3) + (elem ? 2 : 0) + ((a->hist_pp && (a->flags & DLPM_UPD_HIST_ON)) ? 1 : 0)), as_stream(stream));
     if (elem) {
         const bool evec = vec && ((reinterpret_cast<uintptr_t>(a->c_eps_dev) | reinterpret_cast<uintptr_t>(a->c_noise_dev) |
                                    reinterpret_cast<uintptr_t>(a->A_dev)) % 16 == 0);
@@ -611,7 +611,7 @@ extern "C" int dlpm_lim_update_f32(const dlpm_lim_update_args *a, dlpm_stream_t 
     const bool vec = (a->D % 4 == 0) && ((reinterpret_cast<uintptr_t>(a->x_dev) | reinterpret_cast<uintptr_t>(a->eps_dev) |
                                           reinterpret_cast<uintptr_t>(a->z_dev)) % 16 == 0);
     const bool ode = a->flags & DLPM_UPD_DLIM;
-    ProfScope ps("lim_update", 0.0, 4.0 * (double)a->B * a->D * ((a->z_dev && !ode ? 4 : 3) + (a->hist_pp ? 1 : 0)),
+    ProfScope ps("lim_update", 0.0, 4.0 * (double)a->B * a->D * ((a->z_dev && !ode ? 4 : 3) + ((a->hist_pp && (a->flags & DLPM_UPD_HIST_ON)) ? 1 : 0)),
                  as_stream(stream));
     const int64_t items = vec ? a->D / 4 : a->D;
     const unsigned threads = items >= 256 ? 256 : 64;

@@ -33,6 +33,7 @@ struct dlpm_sampler {
     void *ws = nullptr;
     int64_t ws_bytes = 0;
     int32_t t_host = 0;
+    int64_t plan_version = 0;      // dlpm_unet_plan_version at capture / workspace sizing time
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     // Graph capture is illegal on the legacy default stream (which is what torch hands out by
@@ -54,6 +55,29 @@ __global__ void k_set_t(int32_t *t, int32_t v) {
         if (_r != DLPM_OK) return _r; \
     } while (0)
 
+// The net's launch plan may change under a live sampler (dlpm_unet_set_conv_policy): drop the captured graph and
+// re-size the activation workspace before the next step.
+int sync_plan(dlpm_sampler *s) {
+    if (!s->cfg.unet) return DLPM_OK;
+    const int64_t v = dlpm_unet_plan_version(s->cfg.unet);
+    if (v == s->plan_version) return DLPM_OK;
+    DLPM_HIP(hipDeviceSynchronize());
+    if (s->exec) (void)hipGraphExecDestroy(s->exec);
+    if (s->graph) (void)hipGraphDestroy(s->graph);
+    s->exec = nullptr;
+    s->graph = nullptr;
+    const int64_t need = dlpm_unet_workspace_bytes(s->cfg.unet, s->cfg.B);
+    if (need < 0) return DLPM_ERR_STATE;
+    if (need > s->ws_bytes) {
+        if (s->ws) DLPM_HIP(hipFree(s->ws));
+        s->ws = nullptr;
+        DLPM_HIP(hipMalloc(&s->ws, (size_t)need));
+        s->ws_bytes = need;
+    }
+    s->plan_version = v;
+    return DLPM_OK;
+}
+
 int model_forward(dlpm_sampler *s, hipStream_t st) {
     const float *xin = s->x;
     if (s->in_scale) {
@@ -74,7 +98,7 @@ int one_step(dlpm_sampler *s, const float *z, bool advance, hipStream_t st) {
         a.tmp_dev = s->lim_tmp; a.cx_dev = s->lim_cx; a.cs_dev = s->lim_cs; a.cn_dev = s->lim_cn;
         a.A_dev = s->cfg.alpha == 2.0 ? nullptr : s->A;      // alpha = 2: e_B = randn_like(x) (sampler.py:135)
         a.B = s->cfg.B; a.D = s->D; a.T = s->cfg.T;
-        a.flags = (s->cfg.flags & DLPM_UPD_DLIM) | (advance ? DLPM_UPD_ADVANCE : 0);
+        a.flags = (s->cfg.flags & DLPM_UPD_DLIM) | (advance ? DLPM_UPD_ADVANCE : 0) | (s->hist ? DLPM_UPD_HIST_ON : 0);
         a.clamp_eps = (float)s->cfg.clamp_eps;
         a.seed = s->cfg.seed; a.sample_offset = s->cfg.sample_offset; a.key_dev = s->key_dev;
         a.hist_pp = s->hist_cell;
@@ -87,7 +111,8 @@ int one_step(dlpm_sampler *s, const float *z, bool advance, hipStream_t st) {
     a.g_dev = s->g; a.bg_dev = s->bg; a.bs_dev = s->bs;
     a.c_eps_dev = s->c_eps; a.c_noise_dev = s->c_noise; a.A_dev = s->A;
     a.B = s->cfg.B; a.D = s->D; a.T = s->cfg.T;
-    a.flags = (s->cfg.flags & (DLPM_UPD_DLIM | DLPM_UPD_CLIP | DLPM_UPD_ELEMENTWISE)) | (advance ? DLPM_UPD_ADVANCE : 0);
+    a.flags = (s->cfg.flags & (DLPM_UPD_DLIM | DLPM_UPD_CLIP | DLPM_UPD_ELEMENTWISE)) | (advance ? DLPM_UPD_ADVANCE : 0) |
+              (s->hist ? DLPM_UPD_HIST_ON : 0);
     a.hist_pp = s->hist_cell;
     a.dlim_eta = s->cfg.dlim_eta; a.alpha = (float)s->cfg.alpha;
     a.seed = s->cfg.seed; a.sample_offset = s->cfg.sample_offset; a.key_dev = s->key_dev;
@@ -215,6 +240,7 @@ extern "C" int dlpm_sampler_create(const dlpm_sampler_config *cfg, dlpm_sampler 
             return DLPM_ERR_STATE;
         }
         if ((e = hipMalloc(&s->ws, (size_t)s->ws_bytes)) != hipSuccess) return fail(e);
+        s->plan_version = dlpm_unet_plan_version(cfg->unet);
     }
     *out = s;
     return DLPM_OK;
@@ -261,9 +287,22 @@ extern "C" int dlpm_sampler_begin_injected(dlpm_sampler *s, const float *A_dev, 
     return build_tables(s, st);
 }
 
+extern "C" int dlpm_sampler_set_state(dlpm_sampler *s, const float *x_dev, int32_t t, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(s, "dlpm_sampler_set_state: null handle");
+    DLPM_CHECK_ARG(t >= 1 && t <= s->cfg.T - 1, "dlpm_sampler_set_state: t = %d outside 1..%d", t, s->cfg.T - 1);
+    hipStream_t st = as_stream(stream);
+    if (x_dev)
+        DLPM_HIP(hipMemcpyAsync(s->x, x_dev, (size_t)s->cfg.B * s->D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    k_set_t<<<1, 64, 0, st>>>(s->t_dev, t);
+    DLPM_LAUNCH_CHECK();
+    s->t_host = t;
+    return DLPM_OK;
+}
+
 extern "C" int dlpm_sampler_step_injected(dlpm_sampler *s, const float *z_dev, dlpm_stream_t stream) {
     DLPM_CHECK_ARG(s, "dlpm_sampler_step_injected: null handle");
     if (s->t_host < 1) return DLPM_OK;
+    TRY(sync_plan(s));
     TRY(one_step(s, z_dev, true, as_stream(stream)));
     s->t_host -= 1;
     return DLPM_OK;
@@ -313,6 +352,7 @@ extern "C" int dlpm_sampler_steps(dlpm_sampler *s, int32_t nsteps, dlpm_stream_t
     hipStream_t st = as_stream(stream);
     if (nsteps > s->t_host) nsteps = s->t_host;
     if (nsteps == 0) return DLPM_OK;
+    TRY(sync_plan(s));
     // toy net, plain stochastic DLPM steps: the whole run of steps is one launch (state in registers)
     // (one wave per sample: best while the batch is latency-bound; beyond ~16k samples the 4-samples-per-wave
     //  forward kernel + update kernel reuse the weights better)

@@ -77,10 +77,12 @@ struct Bump {
     }
 };
 
+void policy_of(const dlpm_unet *u, ConvLaunch &L);   // copies the net's conv policy into a launch (defined below the struct)
+
 // GroupNorm statistics can ride on the producing conv's epilogue when its pixel tiles stay inside one image
 // and the conv runs on the MFMA kernels with the row epilogue.  Decides (at plan time) whether `t`, produced by
 // conv `c` with the given geometry, carries statistics, and allocates them: tile size per conv_stats_pixels.
-void plan_stats(Bump &ws, Tensor4 &t, const ConvW &c, int B, int C0, int stride, int ups, bool stem = false) {
+void plan_stats(const dlpm_unet *u, Bump &ws, Tensor4 &t, const ConvW &c, int B, int C0, int stride, int ups, bool stem = false) {
     static int off = -1;
     if (off < 0) { const char *e = getenv("DLPM_NO_GN_FUSION"); off = (e && e[0] == '1') ? 1 : 0; }
     t.stats = nullptr;
@@ -90,6 +92,7 @@ void plan_stats(Bump &ws, Tensor4 &t, const ConvW &c, int B, int C0, int stride,
     L.w_wino = c.w_wino; L.w_wino4 = c.w_wino4; L.ks = c.ks; L.stride = stride; L.ups = ups; L.Hout = t.H; L.Wout = t.W; L.Cout = c.cout;
     L.C0 = C0; L.C1 = c.cin - C0; L.B = B;
     L.in_nchw = stem ? 1 : 0;
+    policy_of(u, L);
     const int px = conv_stats_pixels(L);
     if (px <= 0) return;
     t.stats_px = px;
@@ -123,6 +126,9 @@ struct dlpm_unet {
     bool finalized = false;
     std::vector<Tensor4> feats;      // block outputs of the last forward
     int64_t flops = 0;
+    int gen = DLPM_CONV_AUTO;        // dlpm_unet_set_conv_policy
+    int64_t dispatch_B = 0;
+    int64_t plan_version = 0;
 
     int add(const std::string &key, int64_t numel) {
         Param p;
@@ -173,6 +179,11 @@ struct dlpm_unet {
 };
 
 namespace {
+
+void policy_of(const dlpm_unet *u, ConvLaunch &L) {
+    L.gen = u->gen;
+    L.dispatch_B = u->dispatch_B;
+}
 
 // The block structure the reference constructor produces (unet.py:334-436).
 void build_arch(dlpm_unet *u) {
@@ -287,7 +298,8 @@ int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 no
     return relayout_weight(src, c.w_dev, c.cout, c.cin, c.ks, c.use_igemm, nullptr);
 }
 
-int run_conv(const ConvW &c, ConvLaunch L, hipStream_t st) {
+int run_conv(const dlpm_unet *u, const ConvW &c, ConvLaunch L, hipStream_t st) {
+    policy_of(u, L);
     L.w = c.w_dev;
     L.w_frag = c.w_frag;
     L.w_wino = c.w_wino;
@@ -323,19 +335,19 @@ int run_res(Ctx &cx, const Layer &L, Tensor4 x0, Tensor4 x1, Tensor4 *out) {
     Tensor4 h1;
     h1.C = Co; h1.H = H; h1.W = W;
     h1.p = cx.ws.alloc((int64_t)B * HW * Co);
-    plan_stats(cx.ws, h1, L.c1, B, C0, 1, 0);
+    plan_stats(cx.u, cx.ws, h1, L.c1, B, C0, 1, 0);
     float *cA2 = cx.ws.alloc((int64_t)B * Co), *cB2 = cx.ws.alloc((int64_t)B * Co);
     float *sk = L.has_skip ? cx.ws.alloc((int64_t)B * HW * Co) : nullptr;
     float *o = cx.ws.alloc((int64_t)B * HW * Co);
     out->p = o; out->C = Co; out->H = H; out->W = W;
-    plan_stats(cx.ws, *out, L.c2, B, Co, 1, 0);
+    plan_stats(cx.u, cx.ws, *out, L.c2, B, Co, 1, 0);
     if (cx.dry()) return DLPM_OK;
     const int G1 = Cin < 32 ? Cin : 32, G2 = Co < 32 ? Co : 32;
     TRY(gn_any(x0, x1, B, G1, u->params[L.p_gn1_w].dev, u->params[L.p_gn1_b].dev, nullptr, 0, 0, cA1, cB1, cx.st));
     ConvLaunch a;
     a.src0 = x0.p; a.src1 = x1.p; a.C0 = C0; a.C1 = C1; a.B = B; a.Hin = a.Hout = H; a.Win = a.Wout = W;
     a.bias = u->params[L.c1.p_b].dev; a.coefA = cA1; a.coefB = cB1; a.act_silu = 1; a.out = h1.p; a.stats_out = h1.stats;
-    TRY(run_conv(L.c1, a, cx.st));
+    TRY(run_conv(u, L.c1, a, cx.st));
     TRY(gn_any(h1, Tensor4(), B, G2, u->params[L.p_gn2_w].dev, u->params[L.p_gn2_b].dev, cx.embout, u->emb_total, L.emb_off,
                cA2, cB2, cx.st));
     ConvLaunch b;
@@ -345,12 +357,12 @@ int run_res(Ctx &cx, const Layer &L, Tensor4 x0, Tensor4 x1, Tensor4 *out) {
         ConvLaunch s;
         s.src0 = x0.p; s.src1 = x1.p; s.C0 = C0; s.C1 = C1; s.B = B; s.Hin = s.Hout = H; s.Win = s.Wout = W;
         s.bias = u->params[L.skip.p_b].dev; s.out = sk;
-        TRY(run_conv(L.skip, s, cx.st));
+        TRY(run_conv(u, L.skip, s, cx.st));
         b.res0 = sk; b.R0 = Co;
     } else {
         b.res0 = x0.p; b.res1 = x1.p; b.R0 = C0;
     }
-    return run_conv(L.c2, b, cx.st);
+    return run_conv(u, L.c2, b, cx.st);
 }
 
 int run_attn(Ctx &cx, const Layer &L, Tensor4 x, Tensor4 *out) {
@@ -363,19 +375,19 @@ int run_attn(Ctx &cx, const Layer &L, Tensor4 x, Tensor4 *out) {
     const Tensor4 xin = x;
     *out = x;
     out->p = o;
-    plan_stats(cx.ws, *out, L.c2, B, C, 1, 0);
+    plan_stats(cx.u, cx.ws, *out, L.c2, B, C, 1, 0);
     if (cx.dry()) return DLPM_OK;
     TRY(gn_any(xin, Tensor4(), B, C < 32 ? C : 32, u->params[L.p_gn1_w].dev, u->params[L.p_gn1_b].dev, nullptr, 0, 0, cA, cB,
                cx.st));
     ConvLaunch q;
     q.src0 = x.p; q.C0 = C; q.B = B; q.Hin = q.Hout = x.H; q.Win = q.Wout = x.W;
     q.bias = u->params[L.c1.p_b].dev; q.coefA = cA; q.coefB = cB; q.out = qkv;
-    TRY(run_conv(L.c1, q, cx.st));
+    TRY(run_conv(u, L.c1, q, cx.st));
     TRY(launch_attention(qkv, av, B, T, C, u->cfg.num_heads, cx.st));
     ConvLaunch p;
     p.src0 = av; p.C0 = C; p.B = B; p.Hin = p.Hout = x.H; p.Win = p.Wout = x.W;
     p.bias = u->params[L.c2.p_b].dev; p.res0 = x.p; p.R0 = C; p.out = o; p.stats_out = out->stats;
-    return run_conv(L.c2, p, cx.st);
+    return run_conv(u, L.c2, p, cx.st);
 }
 
 int run_seq(Ctx &cx, const std::vector<Layer> &seq, Tensor4 x0, Tensor4 x1, const float *x_nchw, Tensor4 *out) {
@@ -390,12 +402,12 @@ int run_seq(Ctx &cx, const std::vector<Layer> &seq, Tensor4 x0, Tensor4 x1, cons
                 const int S = u->cfg.image_size;
                 o.C = L.cout; o.H = S; o.W = S;
                 o.p = cx.ws.alloc((int64_t)B * S * S * L.cout);
-                plan_stats(cx.ws, o, L.c1, B, L.cin, 1, 0, true);
+                plan_stats(cx.u, cx.ws, o, L.c1, B, L.cin, 1, 0, true);
                 if (!cx.dry()) {
                     ConvLaunch a;
                     a.src0 = x_nchw; a.C0 = L.cin; a.B = B; a.Hin = a.Hout = S; a.Win = a.Wout = S;
                     a.bias = u->params[L.c1.p_b].dev; a.out = o.p; a.in_nchw = 1; a.stats_out = o.stats;
-                    TRY(run_conv(L.c1, a, cx.st));
+                    TRY(run_conv(u, L.c1, a, cx.st));
                 }
                 break;
             }
@@ -412,13 +424,13 @@ int run_seq(Ctx &cx, const std::vector<Layer> &seq, Tensor4 x0, Tensor4 x1, cons
                 o.H = up ? h.H * 2 : (h.H - 1) / 2 + 1;
                 o.W = up ? h.W * 2 : (h.W - 1) / 2 + 1;
                 o.p = cx.ws.alloc((int64_t)B * o.H * o.W * o.C);
-                plan_stats(cx.ws, o, L.c1, B, h.C, up ? 1 : 2, up ? 1 : 0);
+                plan_stats(cx.u, cx.ws, o, L.c1, B, h.C, up ? 1 : 2, up ? 1 : 0);
                 if (!cx.dry()) {
                     ConvLaunch a;
                     a.src0 = h.p; a.C0 = h.C; a.B = B; a.Hin = h.H; a.Win = h.W; a.Hout = o.H; a.Wout = o.W;
                     a.stride = up ? 1 : 2; a.ups = up ? 1 : 0;
                     a.bias = u->params[L.c1.p_b].dev; a.out = o.p; a.stats_out = o.stats;
-                    TRY(run_conv(L.c1, a, cx.st));
+                    TRY(run_conv(u, L.c1, a, cx.st));
                 }
                 break;
             }
@@ -438,11 +450,11 @@ int walk(dlpm_unet *u, Ctx &cx, const float *x, const float *t, float *eps) {
         ConvLaunch g;
         g.B = B; g.Hin = g.Win = g.Hout = g.Wout = 1;
         g.src0 = e0; g.C0 = mc; g.bias = u->params[u->te0.p_b].dev; g.out = e1;
-        TRY(run_conv(u->te0, g, cx.st));
+        TRY(run_conv(u, u->te0, g, cx.st));
         g.src0 = e1; g.C0 = ted; g.bias = u->params[u->te2.p_b].dev; g.out = e2; g.act_silu = 1;
-        TRY(run_conv(u->te2, g, cx.st));
+        TRY(run_conv(u, u->te2, g, cx.st));
         g.src0 = e2; g.bias = u->embcat_b; g.out = cx.embout;
-        TRY(run_conv(u->embcat, g, cx.st));
+        TRY(run_conv(u, u->embcat, g, cx.st));
     }
     u->feats.clear();
     std::vector<Tensor4> hs;
@@ -472,7 +484,7 @@ int walk(dlpm_unet *u, Ctx &cx, const float *x, const float *t, float *eps) {
         ConvLaunch a;
         a.src0 = h.p; a.C0 = h.C; a.B = B; a.Hin = a.Hout = h.H; a.Win = a.Wout = h.W;
         a.bias = u->params[u->head.p_b].dev; a.coefA = cA; a.coefB = cB; a.act_silu = 1; a.out = eps; a.out_nchw = 1;
-        TRY(run_conv(u->head, a, cx.st));
+        TRY(run_conv(u, u->head, a, cx.st));
     }
     return DLPM_OK;
 }
@@ -648,8 +660,23 @@ extern "C" int dlpm_unet_finalize(dlpm_unet *u) {
     DLPM_HIP(hipDeviceSynchronize());
     u->flops = count_flops(u);
     u->finalized = true;
+    u->plan_version++;
     return DLPM_OK;
 }
+
+extern "C" int dlpm_unet_set_conv_policy(dlpm_unet *u, int32_t generation, int64_t dispatch_batch) {
+    DLPM_CHECK_ARG(u, "dlpm_unet_set_conv_policy: null handle");
+    DLPM_CHECK_ARG(generation >= DLPM_CONV_AUTO && generation <= DLPM_CONV_IGEMM, "dlpm_unet_set_conv_policy: unknown generation %d",
+                   generation);
+    DLPM_CHECK_ARG(dispatch_batch >= 0, "dlpm_unet_set_conv_policy: negative dispatch batch");
+    if (u->gen == generation && u->dispatch_B == dispatch_batch) return DLPM_OK;
+    u->gen = generation;
+    u->dispatch_B = dispatch_batch;
+    u->plan_version++;
+    return DLPM_OK;
+}
+
+extern "C" int64_t dlpm_unet_plan_version(const dlpm_unet *u) { return u ? u->plan_version : -1; }
 
 extern "C" int64_t dlpm_unet_workspace_bytes(const dlpm_unet *net, int64_t B) {
     if (!net || B <= 0) return -1;

@@ -18,6 +18,7 @@ Two RNG modes:
 """
 import contextlib
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -157,7 +158,9 @@ class GenerativeLevyProcess:
             handles = dict(unet=None, mlp=model.native_handle())
         if not self.isotropic:
             flags |= _lib.UPD_ELEMENTWISE
-        key = (id(model), handles['unet'].value if handles['unet'] else handles['mlp'].value, tuple(shape),
+        # the handle GENERATION, not its address: after load_state_dict / invalidate() a new handle is likely to get the
+        # old one's address back from the allocator, and a cached sampler's hipGraph still points at the freed weights
+        key = (id(model), model.handle_generation, tuple(shape),
                self.reverse_steps, self.alpha, flags, eta, clamp_a, clamp_eps, self.use_graph, self.fused_mlp,
                self.dlpm.host_schedule[3].data_ptr(), self._input_scale() is not None)
         ent = self._samplers.get(key)
@@ -193,8 +196,16 @@ class GenerativeLevyProcess:
             cfg.lim_ts, cfg.lim_tmp, cfg.lim_cx, cfg.lim_cs, cfg.lim_cn = (v.data_ptr() for v in tabs)
         h = C.c_void_p()
         _lib.check(_lib.lib().dlpm_sampler_create(C.byref(cfg), C.byref(h)))
-        self._samplers[key] = dict(h=h)
+        self._samplers[key] = dict(h=h, model=weakref.ref(model))
+        model._dependents.add(self)
         return h
+
+    def _drop_samplers_of(self, model):
+        """Called by a model before it destroys its native handle: samplers built on it go first."""
+        for k in list(self._samplers):
+            m = self._samplers[k]['model']()
+            if m is None or m is model:
+                _lib.lib().dlpm_sampler_destroy(self._samplers.pop(k)['h'])
 
     def close(self):
         for k in list(self._samplers):

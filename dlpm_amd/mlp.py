@@ -4,6 +4,7 @@ nn.Sequential re-registrations create) and the same construction order, hence th
 initialisation under a given torch.manual_seed.
 """
 import ctypes as C
+import weakref
 
 import torch
 import torch.nn as nn
@@ -52,10 +53,15 @@ class MLPModel(nn.Module):
         self.outblocks_mean = nn.ModuleList([_cond_block(self.nunits, self.time_emb_size),
                                              nn.Linear(self.nunits, self.nfeatures)])
         self._handle = None
+        self.handle_generation = 0          # bumped whenever the native handle is destroyed (sampler cache keys carry it)
+        self._dependents = weakref.WeakSet()  # method objects holding native samplers built on this handle
 
     def invalidate(self):
+        for m in list(self._dependents):
+            m._drop_samplers_of(self)
         if self._handle is not None:
             _lib.lib().dlpm_mlp_destroy(self._handle)
+            self.handle_generation += 1
         self._handle = None
 
     def load_state_dict(self, *a, **k):

@@ -8,6 +8,7 @@ reference's construction order (unet.py:334-436), the SAME default initialisatio
 no PyTorch compute path and it raises if the library is unavailable.
 """
 import ctypes as C
+import weakref
 
 import torch
 import torch.nn as nn
@@ -108,13 +109,30 @@ class UNetModel(nn.Module):
         self._handle = None
         self._handle_size = None
         self._ws = None
+        self._conv_policy = (_lib.CONV_AUTO, 0)
+        self.handle_generation = 0          # bumped whenever the native handle is destroyed (sampler cache keys carry it)
+        self._dependents = weakref.WeakSet()  # method objects holding native samplers built on this handle
 
     # ------------------------------------------------------------------ native handle management
     def invalidate(self):
-        """Call after changing parameters in place; the next forward re-uploads them."""
+        """Call after changing parameters in place; the next forward re-uploads them.  Native samplers captured
+        against the old handle (their hipGraphs hold its weight pointers) are destroyed first."""
+        for m in list(self._dependents):
+            m._drop_samplers_of(self)
         if self._handle is not None:
             _lib.lib().dlpm_unet_destroy(self._handle)
+            self.handle_generation += 1
         self._handle = None
+
+    def set_conv_policy(self, generation='auto', dispatch_batch=0):
+        """Which kernel generation the 3x3 stride-1 convolutions take (dlpm_unet_set_conv_policy): 'auto' (fastest per
+        layer geometry), 'f4' (Winograd F(4x4,3x3)), 'f2' (Winograd F(2x2,3x3)), 'igemm'.  Never a function of the batch
+        of a call, so samples do not depend on sharding / chunking; `dispatch_batch` lets 'auto' weigh grid occupancy
+        for a batch the caller declares for the whole configuration."""
+        gen = {'auto': _lib.CONV_AUTO, 'f4': _lib.CONV_F4, 'f2': _lib.CONV_F2, 'igemm': _lib.CONV_IGEMM}[generation]
+        self._conv_policy = (gen, int(dispatch_batch))
+        if self._handle is not None:
+            _lib.check(_lib.lib().dlpm_unet_set_conv_policy(self._handle, gen, int(dispatch_batch)))
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
@@ -153,6 +171,7 @@ class UNetModel(nn.Module):
             w = v.detach().to('cpu', torch.float32).contiguous()
             _lib.check(L.dlpm_unet_set_param(h, k.encode(), w.data_ptr(), w.numel()))
         _lib.check(L.dlpm_unet_finalize(h))
+        _lib.check(L.dlpm_unet_set_conv_policy(h, self._conv_policy[0], self._conv_policy[1]))
         self._handle, self._handle_size = h, image_size
         return h
 

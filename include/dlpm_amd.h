@@ -132,7 +132,9 @@ enum dlpm_update_flags {
     DLPM_UPD_ADVANCE = 4,     /* after the update, thread 0 decrements *t_dev (graph replay)     */
     DLPM_SMP_NO_FUSED_MLP = 8,/* sampler only: do not use the one-launch toy-net loop            */
     DLPM_UPD_ELEMENTWISE = 16,/* non-isotropic noise: c_eps / c_noise / A are [T,B,D] (also a sampler flag) */
-    DLPM_SMP_LIM = 32         /* sampler only: continuous-time LIM sampler (`method: lim`); DLPM_UPD_DLIM = its ODE */
+    DLPM_SMP_LIM = 32,        /* sampler only: continuous-time LIM sampler (`method: lim`); DLPM_UPD_DLIM = its ODE */
+    DLPM_UPD_HIST_ON = 64     /* accounting hint for dlpm_prof_*: the history cell currently holds a buffer, so the launch
+                                 also writes 4 B/element (the kernel itself reads the cell; arithmetic is unaffected)  */
 };
 
 typedef struct dlpm_update_args {
@@ -277,6 +279,20 @@ int dlpm_unet_num_features(const dlpm_unet *net);
 int dlpm_unet_feature_shape(const dlpm_unet *net, int index, int32_t *C, int32_t *H, int32_t *W);
 int dlpm_unet_get_feature(dlpm_unet *net, int index, float *out_nchw_dev, int64_t B, dlpm_stream_t stream);
 int64_t dlpm_unet_flops_per_sample(const dlpm_unet *net);   /* 2*MAC, conv/linear/attention */
+
+/* Which kernel generation the 3x3 stride-1 convolutions take.  The generations (Winograd F(4x4,3x3), Winograd
+ * F(2x2,3x3), implicit GEMM) round differently, so the choice is a function of the layer's geometry and of this
+ * per-net policy ONLY -- never of the batch a call happens to carry: a sample's value must not depend on how its batch
+ * was sharded over GPUs or cut into chunks.
+ *   DLPM_CONV_AUTO   the fastest generation each layer's geometry admits (default);
+ *   DLPM_CONV_F4 / _F2 / _IGEMM   that generation wherever the geometry admits it (tests, A/B measurements).
+ * dispatch_batch > 0 (AUTO only): additionally weigh grid occupancy for THAT batch -- a property the caller declares
+ * for the whole configuration (e.g. the per-GPU shard of the global batch), identical on every rank and chunk; 0 = off.
+ * May be called any time after dlpm_unet_finalize; samplers re-capture their graph on the next step. */
+enum dlpm_conv_generation { DLPM_CONV_AUTO = 0, DLPM_CONV_F4 = 1, DLPM_CONV_F2 = 2, DLPM_CONV_IGEMM = 3 };
+int dlpm_unet_set_conv_policy(dlpm_unet *net, int32_t generation, int64_t dispatch_batch);
+/* Bumped by every call that changes the launch plan (dlpm_unet_set_conv_policy, dlpm_unet_finalize). */
+int64_t dlpm_unet_plan_version(const dlpm_unet *net);
 void dlpm_unet_destroy(dlpm_unet *net);
 
 typedef struct dlpm_mlp dlpm_mlp;   /* MLPModel of 2d_data.yml: dlpm/models/Model.py:17-211 */
@@ -389,6 +405,10 @@ int dlpm_sampler_begin(dlpm_sampler *s, dlpm_stream_t stream);
  * A_dev[T,B] and xT_dev[B,C,H,W] are copied in; the tables are built from A.  (Non-isotropic: A_dev[T,B,D].
  * LIM: A_dev[T-1,B] holds the per-step a of gen_sas, row i for step i; xT_dev is x_0 = gen_eps.generate.) */
 int dlpm_sampler_begin_injected(dlpm_sampler *s, const float *A_dev, const float *xT_dev, dlpm_stream_t stream);
+/* Jump to step t (1 <= t <= T-1) of the trajectory with state x_dev[B,C,H,W] (NULL keeps the current state): the next
+ * step maps x_t to x_{t-1} with the tables of the last begin*().  For teacher-forced parity checks against single
+ * reference p_sample calls (GenerativeLevyProcess.py:225-239) and for resuming a trajectory. */
+int dlpm_sampler_set_state(dlpm_sampler *s, const float *x_dev, int32_t t, dlpm_stream_t stream);
 /* One reverse step with caller-provided N(0,1) noise z_dev[B,C,H,W] (eager, no graph). */
 int dlpm_sampler_step_injected(dlpm_sampler *s, const float *z_dev, dlpm_stream_t stream);
 /* Run `nsteps` reverse steps (model forward + fused update), stopping at t == 0.  Loop body of

@@ -60,3 +60,35 @@ def test_two_rank_gather_equals_unsharded(total):
     want = FakeMethod(0).sample(None, [total, 3, 2, 2], 10)
     for rank, full, ok in got:
         assert ok and torch.equal(full, want), rank
+
+
+def _run_bench(extra_env, *argv, timeout=300):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(argv), env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    return r, [json.loads(l) for l in lines]
+
+
+def test_bench_spawns_its_own_ranks_and_propagates_failure():
+    """`python bench.py --gpus 2` started plainly launches its two ranks itself (torch.distributed.run, 127.0.0.1),
+    runs the barrier / max-over-ranks / all-gather control flow and prints ONE JSON line; a failing rank makes the
+    parent exit non-zero.  DLPM_BENCH_DRY_RUN swaps the sampler for a CPU stub (gloo): control flow only."""
+    r, out = _run_bench({'DLPM_BENCH_DRY_RUN': '1'}, '--gpus', '2', '--steps', '5', '--warmup', '2', '--batch', '6')
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(out) == 1, r.stdout
+    j = out[0]
+    assert j['n_gpus'] == 2 and j['steps'] == 5 and j['warmup'] == 2 and j['scaling'] == 'weak'
+    assert j['config']['global_batch'] == 12 and j['config']['allgather_ms'] is not None
+    assert j['full_trajectory_s'] is not None and j['value_source'].startswith('measured') and 'dry_run' in j
+    # single rank: no collective, no allgather time
+    r, out = _run_bench({'DLPM_BENCH_DRY_RUN': '1'}, '--gpus', '1', '--steps', '3', '--warmup', '1', '--batch', '4')
+    assert r.returncode == 0 and out[0]['n_gpus'] == 1 and out[0]['config']['allgather_ms'] is None
+    # a rank that dies (more steps than exist -> assertion in every rank) must surface as a non-zero exit code
+    r, out = _run_bench({'DLPM_BENCH_DRY_RUN': '1'}, '--gpus', '2', '--steps', '5000', '--warmup', '0')
+    assert r.returncode != 0 and not out

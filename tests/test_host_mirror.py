@@ -21,6 +21,8 @@ UNETS = {
     'tiny2': dict(in_ch=1, mc=32, mult=[1, 2, 2], attn=[2, 4], heads=4, res=2),
     'mnist': dict(in_ch=1, mc=32, mult=[1, 2, 2, 2], attn=[2, 4], heads=4, res=2),
     'cifar': dict(in_ch=3, mc=128, mult=[1, 2, 2, 2], attn=[4, 8, 16], heads=4, res=2),
+    # mc = 128 at 16x16: every ResBlock / Upsample conv qualifies for the Winograd F(4x4,3x3) kernel
+    'wide': dict(in_ch=3, mc=128, mult=[1, 2], attn=[2], heads=4, res=2),
 }
 
 
@@ -42,7 +44,7 @@ def test_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), 'libdlpm_amd.so does not export %s' % name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert L.dlpm_abi_version() == _lib.ABI_VERSION == 2
+    assert L.dlpm_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_error_channel():

@@ -228,3 +228,46 @@ def test_unet_trajectory_same_seeds():
     scale = np.abs(want).max(axis=(1, 2, 3, 4), keepdims=True) + 1e-6
     assert np.max(np.abs(got - want) / scale) < 2e-5
     assert np.abs(x.numpy() - f['final']).max() < 1e-4 * max(1.0, np.abs(f['final']).max())
+
+
+def test_wide_unet_trajectory_oracle_vs_reference():
+    """mc = 128 net (the one whose layers take the F(4x4) Winograd kernel on the GPU) inside a full T = 50 sample() on
+    identical seeds: oracle vs the reference run."""
+    from test_host_mirror import build_unet
+    from dlpm_amd.weights import state_digest
+    f = golden('f5_traj_unet_wide')
+    net, _ = build_unet('wide')
+    assert state_digest(net) == bytes(f['digest']).hex()
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    T, alpha, ca, ce = f['meta']
+    with torch.no_grad():
+        x, hist = sampler.sample(lambda x, t: nets.unet_forward(sd, x, t, 4), [int(v) for v in f['shape']], int(T),
+                                 float(alpha), sampler.Streams(0, 0), clamp_a=float(ca), clamp_eps=float(ce),
+                                 get_sample_history=True)
+    want = f['history_every5']
+    got = hist[::5].numpy()
+    scale = np.abs(want).max(axis=(1, 2, 3, 4), keepdims=True) + 1e-6
+    assert np.max(np.abs(got - want) / scale) < 2e-5
+    assert np.abs(x.numpy() - f['final']).max() < 1e-4 * max(1.0, np.abs(f['final']).max())
+
+
+def test_cifar_teacher_forced_steps_oracle_vs_reference():
+    """Single reverse steps of the CIFAR net at T = 1000 (early, mid, late, and the noise-free last step): the oracle's
+    x_t -> x_{t-1} against the reference's p_sample on the stored z."""
+    from test_host_mirror import build_unet
+    from dlpm_amd.weights import state_digest
+    f = golden('f5_step_cifar_teacher_forced')
+    net, _ = build_unet('cifar')
+    assert state_digest(net) == bytes(f['digest']).hex()
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    T, alpha = int(f['meta'][0]), float(f['meta'][1])
+    g, bg, s, bs = P.schedule(T, alpha)
+    Sig = P.sigma_table(torch.from_numpy(f['A']), g, s)
+    for t in f['steps']:
+        t = int(t)
+        x, z = torch.from_numpy(f['x_%d' % t]), torch.from_numpy(f['z_%d' % t])
+        with torch.no_grad():
+            eps = nets.unet_forward(sd, x, torch.full((x.shape[0],), float(t)) * (1.0 / T), 4)
+            out, _, _ = P.dlpm_step(x, eps, t, Sig, g, bs, z)
+        want = f['out_%d' % t]
+        assert np.abs(out.numpy() - want).max() < 2e-5 * max(1.0, np.abs(want).max()), t

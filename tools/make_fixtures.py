@@ -323,6 +323,52 @@ def f5_unet_trajectory():
          digest=np.frombuffer(bytes.fromhex(weight_digest(net)), dtype=np.uint8))
 
 
+def f5_wide_unet_trajectory():
+    # A free-running reference trajectory whose net puts the Winograd F(4x4,3x3) kernel INSIDE the chain: mc = 128 at
+    # 16x16 / 8x8 (every 3x3 stride-1 conv has Cout % 128 == 0 and H, W % 4 == 0).  Full sample() of the reference on
+    # identical seeds, T = 50, B = 4; every 5th state kept.
+    torch.manual_seed(1234)
+    net = make_unet(3, 128, [1, 2], [2], 4, 2).eval()
+    rerandomize(net, 4321)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    T, alpha, shape = 50, 1.7, [4, 3, 16, 16]
+    meth = GenerativeLevyProcess(alpha=alpha, device='cpu', reverse_steps=T, rescale_timesteps=True)
+    x, hist = meth.sample({'default': net}, shape, T, clamp_a=10, clamp_eps=50, get_sample_history=True)
+    save('f5_traj_unet_wide', final=x, history_every5=hist[::5], A=meth.dlpm.A[:, :, 0, 0, 0],
+         meta=np.array([T, alpha, 10, 50]), shape=np.array(shape),
+         digest=np.frombuffer(bytes.fromhex(weight_digest(net)), dtype=np.uint8))
+
+
+def f5_cifar_teacher_forced():
+    # Single reverse steps x_t -> x_{t-1} of the reference (p_sample, GenerativeLevyProcess.py:225-239) with the CIFAR
+    # net (cifar10.yml architecture, weights = f6_unet_cifar's) at T = 1000, alpha = 1.7, B = 2, for steps early, mid and
+    # late in the trajectory.  x_t is a forward-noised synthetic image at that t's scale; z is recorded.
+    torch.manual_seed(1234)
+    net = make_unet(3, 128, [1, 2, 2, 2], [4, 8, 16], 4, 2).eval()
+    rerandomize(net, 4321)
+    T, alpha, shape = 1000, 1.7, [2, 3, 32, 32]
+    np.random.seed(3)
+    torch.manual_seed(3)
+    meth = GenerativeLevyProcess(alpha=alpha, device='cpu', reverse_steps=T, rescale_timesteps=True)
+    meth.dlpm.gen_a.setParams(clamp_a=10)
+    meth.dlpm.gen_eps.setParams(clamp_eps=50)
+    meth.dlpm.sample_A(shape, T)
+    meth.dlpm.compute_Sigmas()
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.rand(shape, generator=g) * 2 - 1
+    arrs = dict(A=meth.dlpm.A[:, :, 0, 0, 0], meta=np.array([T, alpha, 10, 50]), shape=np.array(shape),
+                steps=np.array([999, 750, 500, 250, 2, 1]),
+                digest=np.frombuffer(bytes.fromhex(weight_digest(net)), dtype=np.uint8))
+    for t in arrs['steps']:
+        t = int(t)
+        xt = meth.dlpm.bargammas[t] * x0 + meth.dlpm.barsigmas[t] * meth.dlpm.gen_eps.generate(size=shape)
+        with _Recorder() as rec, torch.inference_mode():
+            out = meth.p_sample(net, xt, torch.tensor([t] * shape[0]))['sample']
+        arrs['x_%d' % t], arrs['z_%d' % t], arrs['out_%d' % t] = xt, rec.z[0], out
+    save('f5_step_cifar_teacher_forced', **arrs)
+
+
 def f6_models():
     # ---- MLP forward
     p = yaml.safe_load(open(os.path.join(REF, 'dlpm/configs/2d_data.yml')))
@@ -343,6 +389,8 @@ def f6_models():
         'tiny2':  dict(in_ch=1, mc=32, mult=[1, 2, 2], attn=[2, 4], heads=4, res=2, hw=16, B=3, store_w=False),
         'mnist':  dict(in_ch=1, mc=32, mult=[1, 2, 2, 2], attn=[2, 4], heads=4, res=2, hw=32, B=2, store_w=False),
         'cifar':  dict(in_ch=3, mc=128, mult=[1, 2, 2, 2], attn=[4, 8, 16], heads=4, res=2, hw=32, B=1, store_w=False),
+        # mc = 128 at 16x16: every ResBlock / Upsample conv qualifies for the Winograd F(4x4,3x3) kernel (see f5w)
+        'wide':   dict(in_ch=3, mc=128, mult=[1, 2], attn=[2], heads=4, res=2, hw=16, B=2, store_w=False),
     }
     for name, c in cfgs.items():
         torch.manual_seed(1234)
@@ -641,8 +689,8 @@ def f10_lim():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f5u', 'f6', 'f7', 'f8', 'f9', 'f10']
-    table = dict(f10=f10_lim, f1=f1_schedule, f2=f2_noise, f3=f3_tables, f4=f4_single_step, f5=f5_trajectories, f5u=f5_unet_trajectory,
+    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f5u', 'f5w', 'f5c', 'f6', 'f7', 'f8', 'f9', 'f10']
+    table = dict(f10=f10_lim, f1=f1_schedule, f2=f2_noise, f3=f3_tables, f4=f4_single_step, f5=f5_trajectories, f5u=f5_unet_trajectory, f5w=f5_wide_unet_trajectory, f5c=f5_cifar_teacher_forced,
                  f6=f6_models, f7=f7_layers, f8=f8_generation_manager, f9=f9_checkpoints)
     with torch.no_grad():
         for w in which:
