@@ -168,9 +168,23 @@ WINO4_CASES = [
 ]
 
 
+# max |F(4x4) kernel - fp64 reference| measured on MI355X (round 2, gpurun_out/r2a/pytest.log)
+F4_MEASURED = {'f4_16x16_block': 4.49e-05,
+               'f4_32x32_four_blocks_gn_silu_res': 1.57e-05,
+               'f4_concat_cout256': 1.7e-05,
+               'f4_8x8_four_images': 9.95e-06,
+               'f4_4x4_sixteen_images': 2.72e-05,
+               'f4_upsample_8to16': 3.65e-05,
+               'f4_upsample_16to32_coef_res': 2.12e-05,
+               'f4_upsample_2to4_multiimage': 2e-05,
+               'f4_64x64': 1.7e-05,
+               'f4_long_k': 2.42e-05}
+
+
 @pytest.mark.parametrize('case', WINO4_CASES, ids=[c[0] for c in WINO4_CASES])
 def test_conv_winograd_f4(case):
-    """F(4x4,3x3): same convolution, larger transform constants -- tolerance 4x the F(2x2) / implicit-GEMM one."""
+    """F(4x4,3x3): same convolution, larger transform constants (|B^T| rows sum to 10, |A^T| to 19).  Bound = twice the
+    error measured on MI355X for each case (F4_MEASURED, O(1) outputs), never above the path's 1e-4 budget."""
     name, B, C0, C1, H, Cout, ups, act, use_res = case
     g = torch.Generator().manual_seed(sum(map(ord, name)))
     Cin = C0 + C1
@@ -186,8 +200,9 @@ def test_conv_winograd_f4(case):
     got2 = run_conv(x0, w, bias, x1, 1, ups, coef, act, res)
     assert got.shape == want.shape
     e4, e2 = (got - want).abs().max().item(), (got2 - want).abs().max().item()
-    print('%s: F(4x4) err %.2e, default path err %.2e, tol %.2e' % (name, e4, e2, 4 * conv_tol(w, Cin)))
-    assert e4 < 4 * conv_tol(w, Cin), name
+    tol = min(1e-4, 2 * F4_MEASURED[name])
+    print('%s: F(4x4) err %.2e, default path err %.2e, tol %.2e' % (name, e4, e2, tol))
+    assert e4 < tol, name
     assert not torch.equal(got, got2), 'the F(4x4) kernel did not run (identical to the default path)'
 
 
@@ -226,7 +241,7 @@ def test_conv_winograd_f4_full_size_batch_independence():
         assert torch.equal(one[0], full[b]), 'image %d depends on its batch' % b
         xb = nchw(x[b:b + 1]).cpu()
         want = ref_conv(xb, w.cpu(), bias.cpu(), coef=(cA[b:b + 1].cpu(), cB[b:b + 1].cpu()), silu=True, res=nchw(res[b:b + 1]).cpu())
-        assert (nchw(full[b:b + 1]).cpu() - want).abs().max().item() < 4 * conv_tol(w, Cc)
+        assert (nchw(full[b:b + 1]).cpu() - want).abs().max().item() < 1e-4   # measured ~2e-5 (f4_32x32 case)
 
 
 def test_conv_boundary_layouts():
