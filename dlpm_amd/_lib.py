@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libdlpm_amd.so')
+LIB_PATH = os.environ.get('DLPM_LIB') or os.path.join(_HERE, 'lib', 'libdlpm_amd.so')   # DLPM_LIB: an instrumented build (dlpm_amd/build.py)
 
 vp, i32, i64, u32, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
 

@@ -19,7 +19,15 @@ SOURCES = ['host.cpp', 'png.cpp', 'images.hip', 'noise.hip', 'conv_igemm.hip', '
            'embed.hip', 'unet.hip', 'mlp.hip', 'sampler.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
-FLAGS += ['-D' + d for d in os.environ.get('DLPM_BUILD_DEFS', '').split()]   # e.g. DLPM_WINO_ABLATIONS (timing experiments)
+# Instrumented / ablation builds (DLPM_BUILD_DEFS="DLPM_PHASE_TIMING F4_X=11 ...") never share objects or the library name
+# with the product build: they go to _obj_<tag>/ and lib/libdlpm_amd_<tag>.so (load one with DLPM_LIB=<path>).
+DEFS = os.environ.get('DLPM_BUILD_DEFS', '').split()
+FLAGS += ['-D' + d.lstrip('-D') if d.startswith('-D') else '-D' + d for d in DEFS]
+if DEFS:
+    import hashlib
+    _tag = hashlib.sha256(' '.join(sorted(DEFS)).encode()).hexdigest()[:8]
+    OBJ = os.path.join(HERE, '_obj_' + _tag)
+    LIB = os.path.join(LIB_DIR, 'libdlpm_amd_%s.so' % _tag)
 
 
 def _stale(target, deps):

@@ -16,8 +16,11 @@
 //     wave w owns output channels 16w..16w+15 for ALL positions: 36 accumulators of the 16x16x4 MFMA (144 registers),
 //     so the output transform never leaves the wave's registers -- no cross-wave exchange as in k_conv3x3_wino_q;
 //   * U (filters in the Winograd domain, fragment order) streams L2 -> registers through a ring, exactly once per wave;
-//   * V = B^T d B is built in LDS per 8-channel phase by waves 0..2 (one row pair of B^T each, lanes = tile x channel
-//     pair) from a raw halo patch that all waves stage with the fused GroupNorm affine + SiLU;
+//   * V = B^T d B is built in LDS per 8-channel phase by waves 0..2 (one row pair of B^T each, lanes = channel pair x tile)
+//     from a raw halo patch that all waves stage with the fused GroupNorm affine + SiLU.  V is kept in A-FRAGMENT order,
+//     V[position pair][k = channel pair][tile][2 positions x 2 channels]: one conflict-free ds_read_b128 per lane feeds the
+//     four MFMAs of a position pair (the tile-major layout it replaces put 16 lanes 32 bytes apart: 4-way bank conflicts on
+//     every A read, the LDS array busy 57 % of the kernel with two thirds of that conflict cycles -- SQ_LDS_BANK_CONFLICT);
 //   * phases are software-pipelined like k_conv3x3_wino_q: S(c+2) raw stores, X(c+1) transform, G(c+3) global loads
 //     ride between the MFMAs of phase c, one barrier per phase;
 //   * epilogue: A^T M A per lane (36 -> 16 values), LDS row image, whole NHWC rows out with bias / residual / fused
@@ -38,8 +41,9 @@ constexpr int F4_RAWPIX = 576;    // halo pixels per phase: one 18x18 patch, 4 x
 constexpr int F4_PRLD = F4_KC + 4;
 constexpr int F4_NT = 512;
 constexpr int F4_QNIT = (F4_RAWPIX * 2 + F4_NT - 1) / F4_NT;   // staging items (pixel, channel quad) per thread: 3
+constexpr int F4_RAWBUF = F4_RAWPIX * F4_PRLD + 16;   // floats per raw buffer, row skew included
 constexpr int F4_CFS = 16 * 2 * F4_KC;   // floats per GroupNorm-coefficient slot: [16 images][A | B][8]
-constexpr int F4_VBUF = 36 * F4_TILES * F4_KC;   // floats per V buffer: [36][16][8]
+constexpr int F4_VBUF = 36 * F4_TILES * F4_KC;   // floats per V buffer: [18 position pairs][4 channel pairs][16 tiles][4]
 constexpr int F4_RING = 6;        // weight fragments (float4 = 2 positions x 2 k-steps) in flight; divides the 18 of a phase
 constexpr int F4_ELD = F4_NQ + 4; // row image pitch
 constexpr int F4_PAD = 8;         // float4 fragments of zero padding behind the weights (ring read-ahead of the last phase)
@@ -71,9 +75,9 @@ __device__ __forceinline__ float2 f2sub(float2 x, float2 y) { return make_float2
 template <bool UPS, int ABL = 0>
 __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh, int bw, int nimg) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
-    float *V = wsm;                               // [2][36][16][8]
-    float *raw = wsm + 2 * F4_VBUF;               // [2][F4_RAWPIX][F4_PRLD]
-    float *Cf = raw + 2 * F4_RAWPIX * F4_PRLD;    // [2][16][2][8]
+    float *V = wsm;                               // [2][18][4][16][4]
+    float *raw = wsm + 2 * F4_VBUF;               // [2][F4_RAWPIX][F4_PRLD] (+ skew)
+    float *Cf = raw + 2 * F4_RAWBUF;              // [2][16][2][8]
 
     DLPM_PHASE_DECL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -106,7 +110,11 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
     //  256, and waves 0..2, which also run the input transform, are the last to get one of those)
     const int squad = tid & 1;
     auto pix_of = [&](int it) { return it == 1 ? (F4_NT / 2) + ((F4_NT - 1 - tid) >> 1) : it * (F4_NT / 2) + (tid >> 1); };
-    int off[F4_QNIT], cfo[F4_QNIT];
+    // Row skew of the raw patch (one image per block, no upsampling): patch row ry starts 4 (ry >> 2) floats late.  The
+    // transform's lanes are 16 tiles x 2 channel pairs per LDS pass; without the skew the four tile rows of a block start
+    // 864 ty floats apart = the same 16-bank group for ty and ty + 2 (2-way to 4-way conflicts on its 84 reads per phase).
+    const bool skewed = !UPS && nimg == 1 && bh <= 4;   // (18 patch rows: the skew stays inside the 16 floats of slack)
+    int off[F4_QNIT], cfo[F4_QNIT], lo[F4_QNIT];
 #pragma unroll
     for (int it = 0; it < F4_QNIT; it++) {
         const int pix = pix_of(it);
@@ -116,6 +124,7 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
         const bool pad = iy < 0 || iy >= Hs || ix < 0 || ix >= Ws || (img0 + img) >= p.B;
         off[it] = pix >= npix ? -2 : (pad ? -1 : (((img0 + img) * Hs + iy) * Ws + ix));
         cfo[it] = img * 2 * F4_KC + squad * 4;
+        lo[it] = pix * F4_PRLD + squad * 4 + (skewed ? 4 * (ry >> 2) : 0);
     }
     const bool has_coef = p.coefA != nullptr;
     const int cf_img = tid >> 2, cf_isb = (tid >> 1) & 1;
@@ -138,7 +147,7 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
     };
     auto store_raw_item = [&](int slot, int it) {
         if (off[it] == -2) return;
-        float *rb = raw + slot * F4_RAWPIX * F4_PRLD;
+        float *rb = raw + slot * F4_RAWBUF;
         float4 x = xr[it];
         if (has_coef) {
             const float4 ca = *reinterpret_cast<const float4 *>(Cf + slot * F4_CFS + cfo[it]);
@@ -155,30 +164,32 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
             x.w = silu_f(x.w);
         }
         if (off[it] < 0) x = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding applies AFTER the activation
-        *reinterpret_cast<float4 *>(rb + pix_of(it) * F4_PRLD + squad * 4) = x;
+        *reinterpret_cast<float4 *>(rb + lo[it]) = x;
     };
     auto store_raw = [&](int slot) {
 #pragma unroll
         for (int it = 0; it < F4_QNIT; it++) store_raw_item(slot, it);
     };
 
-    // ---- input transform V = B^T d B: waves 0..2 take the row pairs (0,5), (1,2), (3,4) of B^T; lane = (tile, channel pair)
+    // ---- input transform V = B^T d B: waves 0..2 take the row pairs (0,5), (1,2), (3,4) of B^T; lane = (channel pair, tile),
+    // tile fastest: the 16 lanes of an LDS pass write 256 contiguous bytes of V
     int rbase, vofs;
     {
-        const int tile = lane >> 2, pair = lane & 3;
+        const int tile = lane & 15, pair = lane >> 4;
         const int timg = tile / (bh * bw), r = tile - timg * (bh * bw);
         const int ty = r / bw, tx = r - ty * bw;
-        rbase = (timg * rpi + (UPS ? 2 : 4) * ty * RW + (UPS ? 2 : 4) * tx) * F4_PRLD + pair * 2;
-        vofs = tile * F4_KC + pair * 2;
+        rbase = (timg * rpi + (UPS ? 2 : 4) * ty * RW + (UPS ? 2 : 4) * tx) * F4_PRLD + pair * 2 + (skewed ? 4 * ty : 0);
+        vofs = (pair * F4_TILES + tile) * 4;
     }
     auto transform = [&](int slot) {
         if (wave >= 3) return;
-        const float *rb = raw + slot * F4_RAWPIX * F4_PRLD + rbase;
+        const float *rb = raw + slot * F4_RAWBUF + rbase;
         float *vb = V + slot * F4_VBUF + vofs;
-        // d(i, c): sample row i, column c of this tile's 6x6 patch (upsampled: source row (i + 1) >> 1 of the 4x4 source patch)
+        // d(i, c): sample row i, column c of this tile's 6x6 patch (upsampled: source row (i + 1) >> 1 of the 4x4 source patch);
+        // rows 4 and 5 of the patch lie in the next skew group
         auto d = [&](int i, int c) {
             const int ri = UPS ? (i + 1) >> 1 : i, ci = UPS ? (c + 1) >> 1 : c;
-            return *reinterpret_cast<const float2 *>(rb + (ri * RW + ci) * F4_PRLD);
+            return *reinterpret_cast<const float2 *>(rb + (ri * RW + ci) * F4_PRLD + ((skewed && i >= 4) ? 4 : 0));
         };
         float2 Ta[6], Tb[6];
         int a0, a1;
@@ -207,17 +218,17 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
             }
             a0 = 3; a1 = 4;
         }
+        // positions (a, 0..5) of row a = position pairs 3 a .. 3 a + 2: one float4 {pos 2 pp: 2 channels, pos 2 pp + 1: 2 channels} each
         auto row_out = [&](const float2 (&T)[6], int a) {
-            float *vr = vb + a * 6 * F4_TILES * F4_KC;
+            float *vr = vb + a * 3 * (4 * F4_TILES * 4);
             const float2 e1 = f2fma(-4.f, T[2], T[4]), o1 = f2fma(-4.f, T[1], T[3]);
             const float2 e2 = f2sub(T[4], T[2]), q2 = f2sub(T[3], T[1]);
             const float2 o2 = make_float2(2.f * q2.x, 2.f * q2.y);
-            *reinterpret_cast<float2 *>(vr + 0 * F4_TILES * F4_KC) = f2fma(4.f, T[0], f2fma(-5.f, T[2], T[4]));
-            *reinterpret_cast<float2 *>(vr + 1 * F4_TILES * F4_KC) = f2add(e1, o1);
-            *reinterpret_cast<float2 *>(vr + 2 * F4_TILES * F4_KC) = f2sub(e1, o1);
-            *reinterpret_cast<float2 *>(vr + 3 * F4_TILES * F4_KC) = f2add(e2, o2);
-            *reinterpret_cast<float2 *>(vr + 4 * F4_TILES * F4_KC) = f2sub(e2, o2);
-            *reinterpret_cast<float2 *>(vr + 5 * F4_TILES * F4_KC) = f2fma(4.f, T[1], f2fma(-5.f, T[3], T[5]));
+            const float2 v0 = f2fma(4.f, T[0], f2fma(-5.f, T[2], T[4])), v1 = f2add(e1, o1), v2 = f2sub(e1, o1);
+            const float2 v3 = f2add(e2, o2), v4 = f2sub(e2, o2), v5 = f2fma(4.f, T[1], f2fma(-5.f, T[3], T[5]));
+            *reinterpret_cast<float4 *>(vr + 0 * (4 * F4_TILES * 4)) = make_float4(v0.x, v0.y, v1.x, v1.y);
+            *reinterpret_cast<float4 *>(vr + 1 * (4 * F4_TILES * 4)) = make_float4(v2.x, v2.y, v3.x, v3.y);
+            *reinterpret_cast<float4 *>(vr + 2 * (4 * F4_TILES * 4)) = make_float4(v4.x, v4.y, v5.x, v5.y);
         };
         row_out(Ta, a0);
         row_out(Tb, a1);
@@ -229,8 +240,9 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
                                     (int64_t)((n0 >> 7) * 8 + __builtin_amdgcn_readfirstlane(wave)) * nch * 18 * 64;
     constexpr int AHEAD = F4_RING - 1;
     float4 bq[F4_RING];
-    // A fragments: lane (li = tile, lk) reads channels 2 lk, 2 lk + 1 of the phase = k index lk of the two k-steps
-    const float *asrc = V + li * F4_KC + 2 * lk;
+    // A fragments: lane (li = tile, lk) reads channels 2 lk, 2 lk + 1 of the phase (= k index lk of the two k-steps) for both
+    // positions of a pair: 16 bytes, consecutive lanes at consecutive addresses
+    const float *asrc = V + lane * 4;
 
     floatx4 acc[36];
 #pragma unroll
@@ -267,17 +279,18 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
     __syncthreads();
     DLPM_PHASE(p, 8);
 
+#ifdef DLPM_PHASE_TIMING
+    long long _wait = 0;      // cycles this wave spends at the phase barrier (developer builds: slots 16 + wave)
+#endif
     for (int chunk = 0; chunk < nch; chunk++) {
         const int cur = chunk & 1, nxt = cur ^ 1;
         const float *ab = asrc + cur * F4_VBUF;
         load_coef(min(chunk + 3, last));
-        float2 aq[F4_AAHEAD + 1][2];
+        float4 aq[F4_AAHEAD + 1];
 #pragma unroll
-        for (int a = 0; a < F4_AAHEAD; a++) {
-            aq[a][0] = (ABL & 64) ? make_float2(1.f, 2.f) : *reinterpret_cast<const float2 *>(ab + (2 * a) * F4_TILES * F4_KC);
-            aq[a][1] = (ABL & 64) ? make_float2(1.f, 2.f) : *reinterpret_cast<const float2 *>(ab + (2 * a + 1) * F4_TILES * F4_KC);
-        }
-        if (ABL & 64) aq[F4_AAHEAD][0] = aq[F4_AAHEAD][1] = make_float2(1.f, 2.f);
+        for (int a = 0; a < F4_AAHEAD; a++)
+            aq[a] = (ABL & 64) ? make_float4(1.f, 2.f, 1.f, 2.f) : *reinterpret_cast<const float4 *>(ab + a * (4 * F4_TILES * 4));
+        if (ABL & 64) aq[F4_AAHEAD] = make_float4(1.f, 2.f, 1.f, 2.f);
 #pragma unroll
         for (int pp = 0; pp < 18; pp++) {
             if (!(ABL & 1) && pp >= F4_S0 && pp < F4_S0 + F4_QNIT) store_raw_item(cur, pp - F4_S0);   // S(chunk+2): raw[cur] was read by X(chunk), a barrier ago
@@ -287,11 +300,10 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
             wp += 64;
             // A fragments are read F4_AAHEAD position pairs ahead (left to the compiler each ds_read sat directly in
             // front of its MFMAs with an s_waitcnt lgkmcnt(0) between them)
-            if (!(ABL & 64) && pp + F4_AAHEAD < 18) {
-                aq[(pp + F4_AAHEAD) % (F4_AAHEAD + 1)][0] = *reinterpret_cast<const float2 *>(ab + (2 * (pp + F4_AAHEAD)) * F4_TILES * F4_KC);
-                aq[(pp + F4_AAHEAD) % (F4_AAHEAD + 1)][1] = *reinterpret_cast<const float2 *>(ab + (2 * (pp + F4_AAHEAD) + 1) * F4_TILES * F4_KC);
-            }
-            const float2 a0 = aq[pp % (F4_AAHEAD + 1)][0], a1 = aq[pp % (F4_AAHEAD + 1)][1];
+            if (!(ABL & 64) && pp + F4_AAHEAD < 18)
+                aq[(pp + F4_AAHEAD) % (F4_AAHEAD + 1)] = *reinterpret_cast<const float4 *>(ab + (pp + F4_AAHEAD) * (4 * F4_TILES * 4));
+            const float4 aa = aq[pp % (F4_AAHEAD + 1)];
+            const float2 a0 = make_float2(aa.x, aa.y), a1 = make_float2(aa.z, aa.w);
             const float4 b = bq[pp % F4_RING];
             // wave priority: everything that is not an MFMA (operand fetch, staging, transform) issues at priority 1, the
             // MFMAs at 0 -- when both waves of a SIMD are ready, the one with side work goes first and the other's MFMAs
@@ -309,11 +321,20 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
             if (F4_PRIO) __builtin_amdgcn_s_setprio(1);
         }
         store_coef(nxt);
+#ifdef DLPM_PHASE_TIMING
+        const long long _w0 = clock64();
+#endif
         if (!(ABL & 8)) __syncthreads();
+#ifdef DLPM_PHASE_TIMING
+        _wait += clock64() - _w0;
+#endif
     }
     if (ABL & 8) __syncthreads();
     if (F4_PRIO) __builtin_amdgcn_s_setprio(0);
     DLPM_PHASE(p, 9);
+#ifdef DLPM_PHASE_TIMING
+    if (p.phase && lane == 0) atomicAdd(p.phase + 16 + wave, (unsigned long long)_wait);
+#endif
 
     // ---- epilogue.  Thread (c4, rg) of the streaming pass owns channel quad c4 and position (i, j) = (rg >> 2, rg & 3)
     // of every tile: 16 rows, one per tile.  The first 8 residual rows are requested before the output transform.
@@ -555,7 +576,7 @@ int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
         for (auto &q : configured)
             if (!q) { q = reinterpret_cast<const void *>(fn); break; }
     }
-    const size_t loop_b = (size_t)(2 * F4_VBUF + 2 * F4_RAWPIX * F4_PRLD + 2 * F4_CFS) * sizeof(float);
+    const size_t loop_b = (size_t)(2 * F4_VBUF + 2 * F4_RAWBUF + 2 * F4_CFS) * sizeof(float);
     const size_t epi_b = (size_t)(16 * F4_TILES * F4_ELD + 64) * sizeof(float);
     const int64_t tiles = (int64_t)c.B * (c.Hout / 4) * (c.Wout / 4);
     const int64_t mblocks = nimg == 1 ? tiles / F4_TILES : ceil_div(c.B, nimg);

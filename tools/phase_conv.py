@@ -25,7 +25,7 @@ L.dlpm_debug_phases.argtypes = [C.POINTER(C.c_ulonglong * 32)]
 DEV = 'cuda'
 
 # name, B, C0, C1, H, Cout, ks, coef+silu, res
-SHAPES = [
+SHAPES = [s for s in [
     ('1x1 skip H32 128+128->128', 1024, 128, 128, 32, 128, 1, False, False),
     ('1x1 skip H32 256+128->128', 1024, 256, 128, 32, 128, 1, False, False),
     ('1x1 skip H16 256+256->256', 1024, 256, 256, 16, 256, 1, False, False),
@@ -34,7 +34,7 @@ SHAPES = [
     ('3x3 wino H32 128->128', 1024, 128, 0, 32, 128, 3, True, True),
     ('3x3 wino H16 256->256', 1024, 256, 0, 16, 256, 3, True, True),
     ('3x3 wino H32 128+128->128', 1024, 128, 128, 32, 128, 3, True, False),
-]
+] if os.environ.get('PHASE_ONLY', '') in s[0]]
 
 
 def run(name, B, C0, C1, H, Cout, ks, coef, res, reps=5):
@@ -81,6 +81,8 @@ def run(name, B, C0, C1, H, Cout, ks, coef, res, reps=5):
     tot = pro + main + epi
     print('%-30s %8.3f ms/call(+relayout)  wgs/launch %6d  cycles/wg: prologue %7.0f (%4.1f%%)  loop %7.0f (%4.1f%%)  epilogue %7.0f (%4.1f%%)'
           % (name, e0.elapsed_time(e1) / reps, n // reps, pro, 100 * pro / tot, main, 100 * main / tot, epi, 100 * epi / tot))
+    if any(ph[16 + w] for w in range(8)):
+        print('    barrier wait cycles per workgroup, by wave: ' + ' '.join('%7.0f' % (ph[16 + w] / max(n, 1)) for w in range(8)))
 
 
 for s in SHAPES:
