@@ -88,6 +88,8 @@ SIGNATURES = {
     'dlpm_unet_finalize': (C.c_int, [vp]),
     'dlpm_unet_workspace_bytes': (i64, [vp, i64]),
     'dlpm_unet_forward': (C.c_int, [vp, vp, vp, vp, i64, vp, i64, vp]),
+    'dlpm_unet_forward_uniform_t': (C.c_int, [vp, vp, vp, vp, i64, vp, i64, vp]),
+    'dlpm_unet_keep_features': (C.c_int, [vp, C.c_int]),
     'dlpm_unet_num_features': (C.c_int, [vp]),
     'dlpm_unet_feature_shape': (C.c_int, [vp, C.c_int, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     'dlpm_unet_get_feature': (C.c_int, [vp, C.c_int, vp, i64, vp]),

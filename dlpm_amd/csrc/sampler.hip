@@ -85,7 +85,7 @@ int model_forward(dlpm_sampler *s, hipStream_t st) {
         xin = s->xin;
     }
     if (s->cfg.unet)
-        return dlpm_unet_forward(s->cfg.unet, xin, s->tvec, s->eps, s->cfg.B, s->ws, s->ws_bytes, st);
+        return dlpm_unet_forward_uniform_t(s->cfg.unet, xin, s->tvec, s->eps, s->cfg.B, s->ws, s->ws_bytes, st);   // t = [i] * B
     return dlpm_mlp_forward(s->cfg.mlp, xin, s->tvec, s->eps, s->cfg.B, st);
 }
 

@@ -5,9 +5,10 @@
 // dims=2, no class conditioning, conv_resample=True).  Weights arrive under the reference's
 // state_dict keys, so reference checkpoints load unchanged.
 //
-// Data layout in HBM: activations NHWC fp32 in a caller-provided workspace carved by a bump
-// allocator (no reuse: at B = 1024 the CIFAR net needs ~45 GB of the 288 GB); the (B,C,H,W)
-// boundary tensors are read/written in place by the stem/head kernels.  Fusions:
+// Data layout in HBM: activations NHWC fp32 in a caller-provided workspace, handed out by an arena
+// that recycles every buffer after its last consumer has been enqueued (skip-connection tensors live
+// until their output block); the (B,C,H,W) boundary tensors are read/written in place by the
+// stem/head kernels.  Fusions:
 //   GroupNorm(+scale-shift)+SiLU  -> coefficient kernel + the consumer conv's tile staging
 //   cat([h, skip])                -> two-pointer reads in the conv / GroupNorm kernels
 //   nearest upsample              -> index arithmetic in the conv
@@ -17,6 +18,7 @@
 #include <cstdlib>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "conv.h"
@@ -64,16 +66,52 @@ struct Tensor4 {
     int stats_px = 0;         // pixels per tile of `stats` (128: implicit-GEMM kernels, 256: Winograd kernel)
 };
 
+// Activation arena: a first-fit free list over the caller's workspace.  Launches are stream-ordered, so a buffer can be
+// handed out again as soon as every launch that touches it has been ENQUEUED; the plan releases each tensor right after
+// its last consumer (skip-connection tensors when their output block pops them).  A dry run (no base pointer: offsets
+// from a fake base, never dereferenced) replays the same alloc / release sequence to size the workspace = the peak.
 struct Bump {
     char *base = nullptr;
-    int64_t cap = 0, off = 0;
-    bool dry = false, overflow = false;
+    int64_t cap = 0, off = 0, peak = 0;
+    bool dry = false, overflow = false, reuse = true;
+    std::vector<std::pair<int64_t, int64_t>> holes;     // (offset, bytes), sorted by offset, coalesced
+    std::map<int64_t, int64_t> live;                    // offset -> bytes
+    char *origin() const { return dry ? reinterpret_cast<char *>(uintptr_t(1) << 20) : base; }
     float *alloc(int64_t nfloats) {
-        int64_t bytes = (nfloats * 4 + 255) / 256 * 256;
-        float *r = dry ? nullptr : reinterpret_cast<float *>(base + off);
-        off += bytes;
-        if (!dry && off > cap) overflow = true;
-        return r;
+        const int64_t bytes = (nfloats * 4 + 255) / 256 * 256;
+        int64_t at = -1;
+        if (reuse) {
+            size_t best = holes.size();                  // best fit: the smallest hole that holds the request
+            for (size_t i = 0; i < holes.size(); i++)
+                if (holes[i].second >= bytes && (best == holes.size() || holes[i].second < holes[best].second)) best = i;
+            if (best != holes.size()) {
+                at = holes[best].first;
+                if (holes[best].second == bytes) holes.erase(holes.begin() + best);
+                else { holes[best].first += bytes; holes[best].second -= bytes; }
+            }
+        }
+        if (at < 0) {
+            at = off;
+            off += bytes;
+            if (off > peak) peak = off;
+            if (!dry && off > cap) overflow = true;
+        }
+        live[at] = bytes;
+        return reinterpret_cast<float *>(origin() + at);
+    }
+    void release(const void *p) {
+        if (!p || !reuse) return;
+        const int64_t at = reinterpret_cast<const char *>(p) - origin();
+        auto it = live.find(at);
+        if (it == live.end()) return;
+        int64_t lo = at, n = it->second;
+        live.erase(it);
+        size_t i = 0;
+        while (i < holes.size() && holes[i].first < lo) i++;
+        if (i > 0 && holes[i - 1].first + holes[i - 1].second == lo) { lo = holes[i - 1].first; n += holes[i - 1].second; holes.erase(holes.begin() + --i); }
+        if (i < holes.size() && lo + n == holes[i].first) { n += holes[i].second; holes.erase(holes.begin() + i); }
+        if (lo + n == off) { off = lo; return; }         // the top of the arena shrinks back
+        holes.insert(holes.begin() + i, std::make_pair(lo, n));
     }
 };
 
@@ -110,6 +148,13 @@ int gn_any(Tensor4 x0, Tensor4 x1, int B, int groups, const float *gamma, const 
 }
 
 
+void drop(Bump &ws, Tensor4 &t) {   // release a tensor and the statistics that ride with it
+    ws.release(t.p);
+    ws.release(t.stats);
+    t.p = nullptr;
+    t.stats = nullptr;
+}
+
 }  // namespace
 
 struct dlpm_unet {
@@ -126,6 +171,7 @@ struct dlpm_unet {
     bool finalized = false;
     std::vector<Tensor4> feats;      // block outputs of the last forward
     int64_t flops = 0;
+    bool keep_feats = false;         // dlpm_unet_keep_features: block outputs stay valid after the forward (no arena reuse)
     int gen = DLPM_CONV_AUTO;        // dlpm_unet_set_conv_policy
     int64_t dispatch_B = 0;
     int64_t plan_version = 0;
@@ -324,8 +370,18 @@ struct Ctx {
     Bump ws;
     hipStream_t st;
     float *embout = nullptr;
+    bool uniform_t = false;      // every sample has the same timestep: the time MLP and the emb linears run on ONE row
     bool dry() const { return ws.dry; }
 };
+
+void release_res_temps(Ctx &cx, float *cA1, float *cB1, Tensor4 &h1, float *cA2, float *cB2, float *sk) {
+    cx.ws.release(cA1);
+    cx.ws.release(cB1);
+    drop(cx.ws, h1);
+    cx.ws.release(cA2);
+    cx.ws.release(cB2);
+    cx.ws.release(sk);
+}
 
 int run_res(Ctx &cx, const Layer &L, Tensor4 x0, Tensor4 x1, Tensor4 *out) {
     dlpm_unet *u = cx.u;
@@ -341,15 +397,18 @@ int run_res(Ctx &cx, const Layer &L, Tensor4 x0, Tensor4 x1, Tensor4 *out) {
     float *o = cx.ws.alloc((int64_t)B * HW * Co);
     out->p = o; out->C = Co; out->H = H; out->W = W;
     plan_stats(cx.u, cx.ws, *out, L.c2, B, Co, 1, 0);
-    if (cx.dry()) return DLPM_OK;
+    if (cx.dry()) {
+        release_res_temps(cx, cA1, cB1, h1, cA2, cB2, sk);
+        return DLPM_OK;
+    }
     const int G1 = Cin < 32 ? Cin : 32, G2 = Co < 32 ? Co : 32;
     TRY(gn_any(x0, x1, B, G1, u->params[L.p_gn1_w].dev, u->params[L.p_gn1_b].dev, nullptr, 0, 0, cA1, cB1, cx.st));
     ConvLaunch a;
     a.src0 = x0.p; a.src1 = x1.p; a.C0 = C0; a.C1 = C1; a.B = B; a.Hin = a.Hout = H; a.Win = a.Wout = W;
     a.bias = u->params[L.c1.p_b].dev; a.coefA = cA1; a.coefB = cB1; a.act_silu = 1; a.out = h1.p; a.stats_out = h1.stats;
     TRY(run_conv(u, L.c1, a, cx.st));
-    TRY(gn_any(h1, Tensor4(), B, G2, u->params[L.p_gn2_w].dev, u->params[L.p_gn2_b].dev, cx.embout, u->emb_total, L.emb_off,
-               cA2, cB2, cx.st));
+    TRY(gn_any(h1, Tensor4(), B, G2, u->params[L.p_gn2_w].dev, u->params[L.p_gn2_b].dev, cx.embout,
+               cx.uniform_t ? 0 : u->emb_total, L.emb_off, cA2, cB2, cx.st));   // row pitch 0: all samples read the one emb row
     ConvLaunch b;
     b.src0 = h1.p; b.C0 = Co; b.B = B; b.Hin = b.Hout = H; b.Win = b.Wout = W;
     b.bias = u->params[L.c2.p_b].dev; b.coefA = cA2; b.coefB = cB2; b.act_silu = 1; b.out = o; b.stats_out = out->stats;
@@ -362,7 +421,9 @@ int run_res(Ctx &cx, const Layer &L, Tensor4 x0, Tensor4 x1, Tensor4 *out) {
     } else {
         b.res0 = x0.p; b.res1 = x1.p; b.R0 = C0;
     }
-    return run_conv(u, L.c2, b, cx.st);
+    TRY(run_conv(u, L.c2, b, cx.st));
+    release_res_temps(cx, cA1, cB1, h1, cA2, cB2, sk);
+    return DLPM_OK;
 }
 
 int run_attn(Ctx &cx, const Layer &L, Tensor4 x, Tensor4 *out) {
@@ -376,7 +437,11 @@ int run_attn(Ctx &cx, const Layer &L, Tensor4 x, Tensor4 *out) {
     *out = x;
     out->p = o;
     plan_stats(cx.u, cx.ws, *out, L.c2, B, C, 1, 0);
-    if (cx.dry()) return DLPM_OK;
+    auto done = [&]() { cx.ws.release(cA); cx.ws.release(cB); cx.ws.release(qkv); cx.ws.release(av); };
+    if (cx.dry()) {
+        done();
+        return DLPM_OK;
+    }
     TRY(gn_any(xin, Tensor4(), B, C < 32 ? C : 32, u->params[L.p_gn1_w].dev, u->params[L.p_gn1_b].dev, nullptr, 0, 0, cA, cB,
                cx.st));
     ConvLaunch q;
@@ -387,10 +452,14 @@ int run_attn(Ctx &cx, const Layer &L, Tensor4 x, Tensor4 *out) {
     ConvLaunch p;
     p.src0 = av; p.C0 = C; p.B = B; p.Hin = p.Hout = x.H; p.Win = p.Wout = x.W;
     p.bias = u->params[L.c2.p_b].dev; p.res0 = x.p; p.R0 = C; p.out = o; p.stats_out = out->stats;
-    return run_conv(u, L.c2, p, cx.st);
+    TRY(run_conv(u, L.c2, p, cx.st));
+    done();
+    return DLPM_OK;
 }
 
-int run_seq(Ctx &cx, const std::vector<Layer> &seq, Tensor4 x0, Tensor4 x1, const float *x_nchw, Tensor4 *out) {
+// free0 / free1: the sequence is the last consumer of x0 / x1 (released once its first layer has been enqueued)
+int run_seq(Ctx &cx, const std::vector<Layer> &seq, Tensor4 x0, Tensor4 x1, const float *x_nchw, Tensor4 *out, bool free0 = false,
+            bool free1 = false) {
     dlpm_unet *u = cx.u;
     const int B = cx.B;
     Tensor4 h = x0;
@@ -435,6 +504,12 @@ int run_seq(Ctx &cx, const std::vector<Layer> &seq, Tensor4 x0, Tensor4 x1, cons
                 break;
             }
         }
+        if (i == 0) {
+            if (free0) drop(cx.ws, x0);
+            if (free1) drop(cx.ws, x1);
+        } else {
+            drop(cx.ws, h);      // an intermediate of this sequence: the layer just enqueued was its only reader
+        }
         h = o;
     }
     *out = h;
@@ -443,12 +518,16 @@ int run_seq(Ctx &cx, const std::vector<Layer> &seq, Tensor4 x0, Tensor4 x1, cons
 
 int walk(dlpm_unet *u, Ctx &cx, const float *x, const float *t, float *eps) {
     const int B = cx.B, mc = u->cfg.model_channels, ted = u->ted;
+    // time embedding -> time MLP -> the per-ResBlock emb linears (unet.py:147-150, 336-338, 470).  In the sampling loop t is
+    // the same for the whole batch (GenerativeLevyProcess.py:319), so these run for one row instead of B identical ones
+    // (a row's dot products do not depend on how many rows the GEMM has: bit-identical to the batched form)
+    const int Bt = cx.uniform_t ? 1 : B;
     float *e0 = cx.ws.alloc((int64_t)B * mc), *e1 = cx.ws.alloc((int64_t)B * ted), *e2 = cx.ws.alloc((int64_t)B * ted);
     cx.embout = cx.ws.alloc((int64_t)B * u->emb_total);
     if (!cx.dry()) {
-        TRY(launch_timestep_embedding(t, e0, B, mc, cx.st));
+        TRY(launch_timestep_embedding(t, e0, Bt, mc, cx.st));
         ConvLaunch g;
-        g.B = B; g.Hin = g.Win = g.Hout = g.Wout = 1;
+        g.B = Bt; g.Hin = g.Win = g.Hout = g.Wout = 1;
         g.src0 = e0; g.C0 = mc; g.bias = u->params[u->te0.p_b].dev; g.out = e1;
         TRY(run_conv(u, u->te0, g, cx.st));
         g.src0 = e1; g.C0 = ted; g.bias = u->params[u->te2.p_b].dev; g.out = e2; g.act_silu = 1;
@@ -456,9 +535,13 @@ int walk(dlpm_unet *u, Ctx &cx, const float *x, const float *t, float *eps) {
         g.src0 = e2; g.bias = u->embcat_b; g.out = cx.embout;
         TRY(run_conv(u, u->embcat, g, cx.st));
     }
+    cx.ws.release(e0);
+    cx.ws.release(e1);
+    cx.ws.release(e2);
     u->feats.clear();
     std::vector<Tensor4> hs;
     Tensor4 h;
+    // every input-block output waits on the skip stack for its output block; the middle block's input is the last of them
     for (auto &seq : u->in_blocks) {
         TRY(run_seq(cx, seq, h, Tensor4(), x, &h));
         hs.push_back(h);
@@ -474,7 +557,7 @@ int walk(dlpm_unet *u, Ctx &cx, const float *x, const float *t, float *eps) {
                       skip.H, skip.W, h.H, h.W);
             return DLPM_ERR_ARG;
         }
-        TRY(run_seq(cx, seq, h, skip, nullptr, &h));
+        TRY(run_seq(cx, seq, h, skip, nullptr, &h, true, true));   // last readers of the previous output and of the skip tensor
         u->feats.push_back(h);
     }
     float *cA = cx.ws.alloc((int64_t)B * h.C), *cB = cx.ws.alloc((int64_t)B * h.C);
@@ -486,6 +569,8 @@ int walk(dlpm_unet *u, Ctx &cx, const float *x, const float *t, float *eps) {
         a.bias = u->params[u->head.p_b].dev; a.coefA = cA; a.coefB = cB; a.act_silu = 1; a.out = eps; a.out_nchw = 1;
         TRY(run_conv(u, u->head, a, cx.st));
     }
+    if (!cx.ws.reuse) return DLPM_OK;
+    for (auto &f : u->feats) f.p = nullptr;     // the arena has recycled them: dlpm_unet_get_feature needs dlpm_unet_keep_features
     return DLPM_OK;
 }
 
@@ -684,15 +769,29 @@ extern "C" int64_t dlpm_unet_workspace_bytes(const dlpm_unet *net, int64_t B) {
     cx.u = const_cast<dlpm_unet *>(net);
     cx.B = (int)B;
     cx.ws.dry = true;
+    cx.ws.reuse = !net->keep_feats;
     cx.st = nullptr;
     std::vector<Tensor4> keep = net->feats;
     int r = walk(cx.u, cx, nullptr, nullptr, nullptr);
     cx.u->feats = keep;
-    return r == DLPM_OK ? cx.ws.off : -1;
+    return r == DLPM_OK ? cx.ws.peak : -1;
 }
+
+static int unet_forward(dlpm_unet *net, const float *x_dev, const float *t_dev, float *eps_dev, int64_t B, void *workspace_dev,
+                        int64_t workspace_bytes, dlpm_stream_t stream, bool uniform_t);
 
 extern "C" int dlpm_unet_forward(dlpm_unet *net, const float *x_dev, const float *t_dev, float *eps_dev, int64_t B,
                                  void *workspace_dev, int64_t workspace_bytes, dlpm_stream_t stream) {
+    return unet_forward(net, x_dev, t_dev, eps_dev, B, workspace_dev, workspace_bytes, stream, false);
+}
+
+extern "C" int dlpm_unet_forward_uniform_t(dlpm_unet *net, const float *x_dev, const float *t_dev, float *eps_dev, int64_t B,
+                                           void *workspace_dev, int64_t workspace_bytes, dlpm_stream_t stream) {
+    return unet_forward(net, x_dev, t_dev, eps_dev, B, workspace_dev, workspace_bytes, stream, true);
+}
+
+static int unet_forward(dlpm_unet *net, const float *x_dev, const float *t_dev, float *eps_dev, int64_t B, void *workspace_dev,
+                        int64_t workspace_bytes, dlpm_stream_t stream, bool uniform_t) {
     DLPM_CHECK_ARG(net && x_dev && t_dev && eps_dev && workspace_dev, "dlpm_unet_forward: null argument");
     DLPM_CHECK_ARG(B > 0 && B < (1 << 24), "dlpm_unet_forward: bad batch %lld", (long long)B);
     if (!net->finalized) {
@@ -710,8 +809,17 @@ extern "C" int dlpm_unet_forward(dlpm_unet *net, const float *x_dev, const float
     cx.B = (int)B;
     cx.ws.base = static_cast<char *>(workspace_dev);
     cx.ws.cap = workspace_bytes;
+    cx.ws.reuse = !net->keep_feats;
     cx.st = as_stream(stream);
+    cx.uniform_t = uniform_t;
     return walk(net, cx, x_dev, t_dev, eps_dev);
+}
+
+extern "C" int dlpm_unet_keep_features(dlpm_unet *net, int on) {
+    DLPM_CHECK_ARG(net, "dlpm_unet_keep_features: null handle");
+    net->keep_feats = on != 0;
+    net->plan_version++;       // the workspace size changes with it
+    return DLPM_OK;
 }
 
 extern "C" int dlpm_unet_num_features(const dlpm_unet *net) {
@@ -728,7 +836,7 @@ extern "C" int dlpm_unet_feature_shape(const dlpm_unet *net, int i, int32_t *C, 
 
 extern "C" int dlpm_unet_get_feature(dlpm_unet *net, int i, float *out_nchw_dev, int64_t B, dlpm_stream_t stream) {
     DLPM_CHECK_ARG(net && out_nchw_dev && i >= 0 && i < (int)net->feats.size() && net->feats[i].p,
-                   "dlpm_unet_get_feature: no such feature (run a forward first)");
+                   "dlpm_unet_get_feature: no such feature (call dlpm_unet_keep_features(net, 1), then run a forward)");
     const Tensor4 &f = net->feats[i];
     return dlpm_nhwc_to_nchw_f32(f.p, out_nchw_dev, (int32_t)B, f.C, f.H, f.W, stream);
 }

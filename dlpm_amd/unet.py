@@ -208,7 +208,15 @@ class UNetModel(nn.Module):
     def get_feature_vectors(self, x, timesteps, y=None):
         """Block outputs of a forward as NCHW tensors: {'down': [...], 'middle': t, 'up': [...]}
         (same structure as the reference's UNetModel.get_feature_vectors, unet.py:494-524)."""
-        self.forward(x, timesteps)
+        L = _lib.lib()
+        _lib.check(L.dlpm_unet_keep_features(self.native_handle(x.shape[2]), 1))   # no arena recycling for this forward
+        try:
+            self.forward(x, timesteps)
+            return self._collect_features(x)
+        finally:
+            _lib.check(L.dlpm_unet_keep_features(self._handle, 0))
+
+    def _collect_features(self, x):
         L, h = _lib.lib(), self._handle
         B = x.shape[0]
         feats = []

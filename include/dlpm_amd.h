@@ -273,8 +273,16 @@ int64_t dlpm_unet_workspace_bytes(const dlpm_unet *net, int64_t B);
  * with t already scaled (i/T floats).  Activations live in workspace_dev (NHWC, fp32). */
 int dlpm_unet_forward(dlpm_unet *net, const float *x_dev, const float *t_dev, float *eps_dev, int64_t B,
                       void *workspace_dev, int64_t workspace_bytes, dlpm_stream_t stream);
+/* The same forward for a batch that shares ONE timestep (what every step of the sampling loop is: t = [i] * B,
+ * GenerativeLevyProcess.py:319): only t_dev[0] is read, and the time-embedding MLP and the per-ResBlock emb linears
+ * (unet.py:147-150, 336-338) are evaluated for one row instead of B identical ones.  Same bits as dlpm_unet_forward. */
+int dlpm_unet_forward_uniform_t(dlpm_unet *net, const float *x_dev, const float *t_dev, float *eps_dev, int64_t B,
+                                void *workspace_dev, int64_t workspace_bytes, dlpm_stream_t stream);
 /* After a forward: copy block output `index` (0..n_in-1 down, then middle, then up blocks) to a
  * device buffer as NCHW for bisecting against UNetModel.get_feature_vectors (unet.py:494-524). */
+/* Block outputs are only kept when asked for: by default the activation arena recycles each buffer after its last
+ * consumer (the workspace is the PEAK, not the sum).  on = 1: no recycling, features stay readable after a forward. */
+int dlpm_unet_keep_features(dlpm_unet *net, int on);
 int dlpm_unet_num_features(const dlpm_unet *net);
 int dlpm_unet_feature_shape(const dlpm_unet *net, int index, int32_t *C, int32_t *H, int32_t *W);
 int dlpm_unet_get_feature(dlpm_unet *net, int index, float *out_nchw_dev, int64_t B, dlpm_stream_t stream);

@@ -93,6 +93,30 @@ def test_unet_batch_tail_and_repeatability():
     assert (c.cpu() - a.cpu()[3:4]).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize('name', ['tiny2', 'cifar'])
+def test_unet_uniform_t_forward_is_bit_identical(name):
+    """dlpm_unet_forward_uniform_t (the sampling loop's call: one shared timestep, time MLP + emb linears on one row,
+    unet.py:147-150,336-338) against the general forward fed B equal timesteps, and against the reference output."""
+    import ctypes as C
+    from dlpm_amd import _lib
+    f = golden('f6_unet_' + name)
+    net, _ = build_unet(name)
+    x = torch.from_numpy(f['x']).to(DEV)
+    if x.shape[0] < 3:
+        x = torch.cat([x, x.flip(0) * 0.5, x * 0.25])[:3].contiguous()
+    B = x.shape[0]
+    t = torch.full((B,), float(f['t_same'][0]), device=DEV)
+    want = net(x, t)
+    L, h = _lib.lib(), net.native_handle(x.shape[2])
+    ws = net.workspace(B, x.device)
+    got = torch.empty_like(want)
+    _lib.check(L.dlpm_unet_forward_uniform_t(h, x.data_ptr(), t[:1].contiguous().data_ptr(), got.data_ptr(), B, ws.data_ptr(),
+                                            ws.numel(), _lib.stream_ptr()))
+    assert torch.equal(got, want)
+    nb = f['x'].shape[0]
+    assert np.abs(got[:nb].cpu().numpy() - f['y_same_t']).max() < 1e-4
+
+
 def test_unet_zero_init_outputs_zero_and_state_dict_roundtrip():
     """Reference default init (zero_module) gives eps == 0 exactly; load_state_dict re-uploads."""
     torch.manual_seed(0)
@@ -145,3 +169,21 @@ def test_unet_64x64_against_oracle():
         want = nets.unet_forward(sd, x, t, 4)
     got = net(x.to(DEV), t.to(DEV)).cpu()
     assert (got - want).abs().max().item() < 1e-4
+
+
+def test_celeba64_unet_at_its_own_width_against_oracle():
+    """BASELINE configs[4] net as configured (dlpm_amd/configs/celeba64.yml: the CIFAR architecture, mc = 128, at 64x64:
+    attention over 256 and 64 tokens, F(4x4) Winograd layers at 64/32/16/8 pixels) against the CPU oracle, B = 2."""
+    p = dlpm_amd.load_config('celeba64')
+    torch.manual_seed(21)
+    net = dlpm_amd.rerandomize_(dlpm_amd.init_model_by_parameter(p), 22)
+    assert net.model_channels == 128
+    g = torch.Generator().manual_seed(23)
+    x, t = torch.randn(2, 3, 64, 64, generator=g), torch.rand(2, generator=g)
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        want = nets.unet_forward(sd, x, t, p['model']['num_heads'])
+    got = net(x.to(DEV), t.to(DEV)).cpu()
+    err = (got - want).abs().max().item()
+    print('celeba64 net (mc=128, 64x64): max |hip - oracle| = %.3g (|y| max %.3g)' % (err, want.abs().max().item()))
+    assert err < 1e-4

@@ -238,3 +238,32 @@ def test_unsupported_paths_fail_loudly():
     m = dlpm_amd.GenerativeLevyProcess(1.7, 'cpu', 10, rescale_timesteps=False)
     with pytest.raises(AssertionError, match='Rescaling only works'):
         m.sample({'default': lambda x, t: x}, [1, 1, 2], 20)
+
+
+def test_activation_arena_recycles_buffers():
+    """dlpm_unet_workspace_bytes is a host-side dry run of the launch plan: with liveness-based reuse the CIFAR net's
+    activations at B = 8192 (BASELINE config 4 on ONE GPU) must fit the 288 GB of an MI355X with room to spare, and
+    the footprint must be well under the no-reuse sum (what dlpm_unet_keep_features(1) allocates)."""
+    L = _lib.lib()
+    c = UNETS['cifar']
+    cfg = _lib.UNetConfig()
+    cfg.in_channels, cfg.model_channels, cfg.out_channels = c['in_ch'], c['mc'], c['in_ch']
+    cfg.num_res_blocks, cfg.num_heads, cfg.image_size = c['res'], c['heads'], 32
+    cfg.n_mult, cfg.n_attn = len(c['mult']), len(c['attn'])
+    for i, m in enumerate(c['mult']):
+        cfg.channel_mult[i] = m
+    for i, a in enumerate(c['attn']):
+        cfg.attention_resolutions[i] = a
+    h = C.c_void_p()
+    _lib.check(L.dlpm_unet_create(C.byref(cfg), C.byref(h)))
+    try:
+        need = L.dlpm_unet_workspace_bytes(h, 8192)
+        assert 0 < need < 200e9, need
+        _lib.check(L.dlpm_unet_keep_features(h, 1))
+        total = L.dlpm_unet_workspace_bytes(h, 8192)
+        _lib.check(L.dlpm_unet_keep_features(h, 0))
+        assert total > 2.5 * need, (need, total)
+        assert L.dlpm_unet_workspace_bytes(h, 8192) == need            # deterministic
+        assert abs(L.dlpm_unet_workspace_bytes(h, 1024) * 8 - need) < 0.01 * need
+    finally:
+        L.dlpm_unet_destroy(h)
