@@ -104,11 +104,9 @@ template <int CH, int NT>
 int launch_t(const float *qkv, float *out, int B, int T, int C, int heads, hipStream_t st) {
     const int nw = (T / 16) < 4 ? (T / 16) : 4;
     const size_t shmem = (size_t)2 * T * (CH + 4) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && shmem > 64 * 1024) {
-        DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attention<CH, NT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        attr_set = true;
+    if (shmem > 64 * 1024) {
+        int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_attention<CH, NT>), (int)shmem);
+        if (r != DLPM_OK) return r;
     }
     const float scale = (float)(1.0 / std::sqrt(std::sqrt((double)CH)));
     dim3 grid((unsigned)(B * heads), (unsigned)ceil_div(T / 16, nw));

@@ -36,6 +36,10 @@ inline hipStream_t as_stream(dlpm_stream_t s) { return reinterpret_cast<hipStrea
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: set it once per (device, kernel), under a lock
+// (a process may drive several GPUs, and two host threads may launch a kernel for the first time together).
+int ensure_dynamic_lds(const void *kernel, int bytes);
+
 // Optional per-launch timing (dlpm_prof_enable): brackets one launch with HIP events on its stream.
 bool prof_enabled();
 bool prof_detail();   // DLPM_PROF_DETAIL=1: one class per distinct launch shape

@@ -26,7 +26,7 @@ struct ConvLaunch {
     int Cout = 0;
     int in_nchw = 0, out_nchw = 0;  // boundary layouts
     int ws_gemm = 0;                // 1x1 only: use the weight-streaming kernel (TAPS = 1) instead of k_conv_igemm
-    int abl = 0;                    // timing-only ablation bits (DLPM_ABL env; results are wrong when set)
+    int abl = 0;                    // timing-only ablation bits (DLPM_ABL env, only in builds with -DDLPM_IGEMM_ABLATIONS; results are wrong when set)
     // Which kernel generation a 3x3 stride-1 launch takes is a function of the LAYER (geometry + this policy), never of the
     // batch the launch happens to carry: the generations round differently, and a sample must not depend on how its batch
     // was sharded or chunked.  gen = DLPM_CONV_AUTO / _F4 / _F2 / _IGEMM (include/dlpm_amd.h); dispatch_B > 0 lets AUTO

@@ -181,10 +181,9 @@ int launch_conv_head(const ConvLaunch &c, hipStream_t st) {
     const size_t shmem = (size_t)(hp * HEAD_LD + 64 + 9 * 32 * 4) * sizeof(float);
     const int64_t M = (int64_t)c.B * H * W;
     ProfScope ps("conv3x3_head", 2.0 * M * c.Cout * 9.0 * c.C0, 4.0 * ((double)M * c.C0 + (double)M * c.Cout), st);
-    static bool attr = false;
-    if (!attr) {
-        DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_head), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        attr = true;
+    {
+        int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_conv3x3_head), 64 * 1024);
+        if (r != DLPM_OK) return r;
     }
     k_conv3x3_head<<<(unsigned)(c.B * (H / TH)), 256, shmem, st>>>(c);
     DLPM_LAUNCH_CHECK();

@@ -1043,11 +1043,9 @@ static int launch_halo_ws_r(const ConvLaunch &c, int th, int nimg, int64_t grid,
     const size_t stats = (size_t)(256 / (BN / 4)) * BN * 2 * sizeof(float);
     if (shmem < epi) shmem = epi;
     if (shmem < stats) shmem = stats;
-    static bool attr = false;
-    if (!attr) {
-        DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo_ws<BN, WAVES_M, WAVES_N, RM, RN, RING, UPS, TAPS>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        attr = true;
+    {
+        int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_conv3x3_halo_ws<BN, WAVES_M, WAVES_N, RM, RN, RING, UPS, TAPS>), 64 * 1024);
+        if (r != DLPM_OK) return r;
     }
     k_conv3x3_halo_ws<BN, WAVES_M, WAVES_N, RM, RN, RING, UPS, TAPS><<<(unsigned)grid, 256, shmem, st>>>(c, th, nimg);
     return DLPM_OK;
@@ -1090,11 +1088,9 @@ template <int BN, int WAVES_M, int WAVES_N, int RM, int RN>
 static int launch_halo(const ConvLaunch &c, int th, int nimg, int64_t grid, hipStream_t st) {
     const int hp = nimg * (th + 2) * (c.Wout + 2);
     const size_t shmem = (size_t)(((hp + 3) & ~3) + 2 * BN) * LDS_LD * sizeof(float) + (size_t)nimg * 64 * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3_halo<BN, WAVES_M, WAVES_N, RM, RN>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-        attr = true;
+    {
+        int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_conv3x3_halo<BN, WAVES_M, WAVES_N, RM, RN>), 100 * 1024);
+        if (r != DLPM_OK) return r;
     }
     k_conv3x3_halo<BN, WAVES_M, WAVES_N, RM, RN><<<(unsigned)grid, 256, shmem, st>>>(c, th, nimg);
     return DLPM_OK;
@@ -1169,9 +1165,11 @@ int launch_conv_igemm(const ConvLaunch &c, hipStream_t st) {
         }
     }
     ProfScope ps(pname, 2.0 * M * c.Cout * K, bytes, st);
+#ifdef DLPM_IGEMM_ABLATIONS   // developer builds only (DLPM_BUILD_DEFS): timing ablations, results are WRONG when set
     static int abl = -1;
     if (abl < 0) { const char *e = getenv("DLPM_ABL"); abl = e ? atoi(e) : 0; }
     if (abl) const_cast<ConvLaunch &>(c).abl = abl;
+#endif
 #ifdef DLPM_PHASE_TIMING
     const_cast<ConvLaunch &>(c).phase = phase_buffer();
 #endif

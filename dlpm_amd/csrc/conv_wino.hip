@@ -531,13 +531,9 @@ int launch_conv_wino(const ConvLaunch &c, hipStream_t st) {
         }
     }
 #endif
-    static const void *configured[24] = {nullptr};   // (not during graph capture: the first launch of each kernel is eager)
-    bool seen = false;
-    for (const void *q : configured) seen = seen || q == reinterpret_cast<const void *>(fn);
-    if (!seen) {
-        DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        for (auto &q : configured)
-            if (!q) { q = reinterpret_cast<const void *>(fn); break; }
+    {
+        int r = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), 160 * 1024);
+        if (r != DLPM_OK) return r;
     }
     const int nq = nw == 8 ? 4096 / mt : 64;
     size_t shmem = (size_t)(2 * 16 * mt * (kc + 4) + 2 * (mt == 64 ? RAW_MAXPIX : RAW_MAXPIX / 2) * (kc + 4) + 2 * 16 * 2 * kc) * sizeof(float);

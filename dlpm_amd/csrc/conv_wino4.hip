@@ -568,13 +568,9 @@ int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
         }
     }
 #endif
-    static const void *configured[16] = {nullptr};   // (the first launch of each kernel is eager, never inside a graph capture)
-    bool seen = false;
-    for (const void *q : configured) seen = seen || q == reinterpret_cast<const void *>(fn);
-    if (!seen) {
-        DLPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        for (auto &q : configured)
-            if (!q) { q = reinterpret_cast<const void *>(fn); break; }
+    {
+        int r = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), 160 * 1024);
+        if (r != DLPM_OK) return r;
     }
     const size_t loop_b = (size_t)(2 * F4_VBUF + 2 * F4_RAWBUF + 2 * F4_CFS) * sizeof(float);
     const size_t epi_b = (size_t)(16 * F4_TILES * F4_ELD + 64) * sizeof(float);

@@ -1,5 +1,8 @@
 // host.cpp -- host-side pieces of the sampling path: error channel, noise schedule and the
 // reference-compatible MT19937 streams used for "identical seeds" parity with the CPU reference.
+#include <mutex>
+#include <set>
+#include <utility>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -30,6 +33,18 @@ bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 }  // namespace
 bool prof_enabled() { return g_prof_on; }
+
+int ensure_dynamic_lds(const void *kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void *>> done;
+    int dev = 0;
+    DLPM_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count(std::make_pair(dev, kernel))) return DLPM_OK;
+    DLPM_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert(std::make_pair(dev, kernel));
+    return DLPM_OK;
+}
 #ifdef DLPM_PHASE_TIMING
 unsigned long long *phase_buffer() {
     static unsigned long long *buf = nullptr;

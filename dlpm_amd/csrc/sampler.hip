@@ -34,6 +34,7 @@ struct dlpm_sampler {
     int64_t ws_bytes = 0;
     int32_t t_host = 0;
     int64_t plan_version = 0;      // dlpm_unet_plan_version at capture / workspace sizing time
+    bool key_dirty = false;        // dlpm_sampler_reseed happened: key_dev is rewritten by the next begin*()
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     // Graph capture is illegal on the legacy default stream (which is what torch hands out by
@@ -47,6 +48,12 @@ namespace {
 
 __global__ void k_set_t(int32_t *t, int32_t v) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *t = v;
+}
+__global__ void k_set_key(uint64_t *key, uint64_t seed, uint64_t offset) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { key[0] = seed; key[1] = offset; }
+}
+__global__ void k_set_ptr(float **cell, float *v) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cell = v;
 }
 
 #define TRY(expr)                     \
@@ -119,7 +126,16 @@ int one_step(dlpm_sampler *s, const float *z, bool advance, hipStream_t st) {
     return dlpm_update_f32(&a, st);
 }
 
+int flush_key(dlpm_sampler *s, hipStream_t st) {
+    if (!s->key_dirty) return DLPM_OK;
+    k_set_key<<<1, 64, 0, st>>>(s->key_dev, s->cfg.seed, (uint64_t)s->cfg.sample_offset);
+    DLPM_LAUNCH_CHECK();
+    s->key_dirty = false;
+    return DLPM_OK;
+}
+
 int build_tables(dlpm_sampler *s, hipStream_t st) {
+    TRY(flush_key(s, st));
     if (!s->lim)
         TRY(dlpm_coeff_tables_f32(s->A, s->g, s->s, s->bs, s->cfg.T, s->cols, s->c_eps, s->c_noise, nullptr, st));
     if (s->hist)   // row 0 of the history is x_T (GenerativeLevyProcess.py:314)
@@ -251,11 +267,10 @@ extern "C" int dlpm_sampler_reseed(dlpm_sampler *s, uint64_t seed, int64_t sampl
     if (seed == s->cfg.seed && sample_offset == s->cfg.sample_offset) return DLPM_OK;
     s->cfg.seed = seed;
     s->cfg.sample_offset = sample_offset;
-    // the key is read from device memory by the captured update node: no recapture needed.  The copy
-    // is synchronous: it must not race with a replay still in flight on the private stream.
-    DLPM_HIP(hipDeviceSynchronize());
-    uint64_t key[2] = {seed, (uint64_t)sample_offset};
-    DLPM_HIP(hipMemcpy(s->key_dev, key, sizeof(key), hipMemcpyHostToDevice));
+    // The key is read from device memory by the captured update node: no recapture needed.  It is written by a
+    // one-thread kernel on the stream of the next begin*() -- stream order puts it behind every replay of the previous
+    // trajectory (dlpm_sampler_steps fences its private stream back into the caller's), so nothing synchronises here.
+    s->key_dirty = true;
     return DLPM_OK;
 }
 
@@ -383,11 +398,10 @@ extern "C" int dlpm_sampler_steps(dlpm_sampler *s, int32_t nsteps, dlpm_stream_t
 extern "C" int dlpm_sampler_set_history(dlpm_sampler *s, float *hist_dev, dlpm_stream_t stream) {
     DLPM_CHECK_ARG(s, "dlpm_sampler_set_history: null handle");
     if (hist_dev == s->hist) return DLPM_OK;
-    // the captured update node reads the base from a device cell, so the graph follows the new buffer; the
-    // write must not overtake a replay still running on the private stream
-    if (s->own) DLPM_HIP(hipStreamSynchronize(s->own));
-    DLPM_HIP(hipStreamSynchronize(as_stream(stream)));
-    DLPM_HIP(hipMemcpy(s->hist_cell, &hist_dev, sizeof(float *), hipMemcpyHostToDevice));
+    // the captured update node reads the base from a device cell, so the graph follows the new buffer; the cell is
+    // written in stream order (earlier replays were fenced back into the caller's stream), no host synchronisation
+    k_set_ptr<<<1, 64, 0, as_stream(stream)>>>(s->hist_cell, hist_dev);
+    DLPM_LAUNCH_CHECK();
     s->hist = hist_dev;
     return DLPM_OK;
 }

@@ -6,8 +6,10 @@ vendored under /root/reference, is not pinned by it (bem/requirements.txt lists 
 installed in this image, so this restates its published algorithm (torchvision/utils.py, unchanged across
 0.9 ... 0.2x): make_grid turns a single 1-channel image into 3 equal channels, then
     ndarr = grid.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8).numpy()
-is handed to PIL.  PARITY UNPINNED for this function: no reference test or golden vector covers it; the tests
-anchor on this restatement and on an independent PNG decoder.
+is handed to PIL.  Pinning: torchvision cannot produce vectors here, so the anchor is the library it delegates to --
+tests/golden/f11_pil_quantise.npz holds PIL's own float -> 8-bit conversion (mode "F" -> "L") of 255 x + 0.5 at every
+rounding boundary plus a PIL-encoded PNG (tools/make_fixtures.py f11); to_rgb8 and png_decode_rgb8 are checked against
+both.  What stays unpinned by any reference run: that save_image is this op sequence (its published source).
 """
 import struct
 import zlib

@@ -83,6 +83,29 @@ def test_oracle_quantisation_matches_torchvision_formula_known_answers():
     assert np.array_equal(got[0, :, :, 0].ravel(), want) and np.array_equal(got[..., 0], got[..., 2])
 
 
+def test_oracle_quantisation_and_decoder_against_pil_vectors():
+    """tests/golden/f11_pil_quantise.npz was produced by PIL (the library torchvision.utils.save_image hands its array
+    to; torchvision itself is absent from the build image): PIL's own float -> 8-bit conversion of 255 x + 0.5 at every
+    rounding boundary, and a PIL-encoded PNG.  The oracle's quantisation and its PNG decoder must agree with both."""
+    from conftest import golden
+    f = golden('f11_pil_quantise')
+    x = torch.from_numpy(f['x']).view(1, 1, 64, 64)
+    got = oimg.to_rgb8(x)
+    assert np.array_equal(got[0, :, :, 0], f['q']) and np.array_equal(got[0, :, :, 1], f['q'])
+    assert np.array_equal(oimg.png_decode_rgb8(bytes(f['png_bytes'])), f['png_rgb'])
+
+
+@pytest.mark.gpu
+def test_images_to_rgb8_against_pil_vectors():
+    from conftest import golden
+    f = golden('f11_pil_quantise')
+    xd = torch.from_numpy(f['x']).view(1, 1, 64, 64).cuda()
+    out = torch.empty((1, 64, 64, 3), dtype=torch.uint8, device='cuda')
+    _lib.check(_lib.lib().dlpm_images_to_rgb8(xd.data_ptr(), out.data_ptr(), 1, 1, 64, 64, _lib.stream_ptr()))
+    o = out.cpu().numpy()
+    assert np.array_equal(o[0, :, :, 0], f['q']) and np.array_equal(o[0, :, :, 2], f['q'])
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(5, 3, 32, 32), (3, 1, 32, 32), (2, 3, 64, 64), (1, 1, 1, 1), (7, 3, 5, 9)])

@@ -18,6 +18,7 @@ Fixture families:
   F7 layers              GroupNorm32, QKVAttention, embedding...  dlpm/models/unet.py, nn.py
   F8 generation manager  clamp + inverse affine                   bem/GenerationManager.py:29-63
   F10 LIM sampler        VPSDE, LIM_sampler sde/ode updates        dlpm/methods/LIM/functions/{sde,sampler}.py
+  F11 image quantisation PIL's float -> 8-bit path (torchvision absent)  bem/evaluate/EvaluationManager.py:188-190
   F9 checkpoints         TrainingManager.save/load, EMAHelper,    bem/TrainingManager.py:240-285, bem/utils_ema.py,
                          FileHandler path hashing                 bem/utils_exp.py:52-151, dlpm/dlpm_experiment.py:11-19
 """
@@ -369,6 +370,29 @@ def f5_cifar_teacher_forced():
     save('f5_step_cifar_teacher_forced', **arrs)
 
 
+def f11_image_quantise():
+    # torchvision (save_image, bem/evaluate/EvaluationManager.py:188-190) is not installed here, so the image dump cannot
+    # be generated by the reference itself.  The independent anchor available in this image is PIL, the library save_image
+    # hands its array to: PIL's own float -> 8-bit path (mode "F" -> "L": clip to [0, 255], truncate) applied to
+    # 255 x + 0.5 is the arithmetic torchvision publishes (mul(255).add_(0.5).clamp_(0, 255).to(uint8)).  Inputs cover
+    # every rounding boundary (k + 0.5) / 255 and its fp32 neighbours, out-of-range values, and random images.
+    from PIL import Image
+    import io
+    ks = np.arange(0, 256, dtype=np.float64)
+    edges = ((ks + 0.5) / 255.0).astype(np.float32)
+    xs = np.concatenate([edges, np.nextafter(edges, np.float32(0)), np.nextafter(edges, np.float32(2)),
+                         (ks / 255.0).astype(np.float32), np.array([-0.25, -1e-7, 0.0, 1.0, 1.0 + 1e-7, 1.5, 7.0], np.float32)])
+    rng = np.random.RandomState(5)
+    xs = np.concatenate([xs, rng.rand(4096 - xs.size).astype(np.float32)]).reshape(64, 64)
+    scaled = (xs * np.float32(255.0) + np.float32(0.5)).astype(np.float32)          # fp32 mul, fp32 add: torch's op sequence
+    q = np.asarray(Image.fromarray(scaled, mode='F').convert('L'))
+    # a PIL-encoded PNG of a small RGB image, for the decoders
+    img = rng.randint(0, 256, size=(12, 10, 3)).astype(np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, format='PNG')
+    save('f11_pil_quantise', x=xs, q=q, png_rgb=img, png_bytes=np.frombuffer(buf.getvalue(), dtype=np.uint8))
+
+
 def f6_models():
     # ---- MLP forward
     p = yaml.safe_load(open(os.path.join(REF, 'dlpm/configs/2d_data.yml')))
@@ -689,8 +713,8 @@ def f10_lim():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f5u', 'f5w', 'f5c', 'f6', 'f7', 'f8', 'f9', 'f10']
-    table = dict(f10=f10_lim, f1=f1_schedule, f2=f2_noise, f3=f3_tables, f4=f4_single_step, f5=f5_trajectories, f5u=f5_unet_trajectory, f5w=f5_wide_unet_trajectory, f5c=f5_cifar_teacher_forced,
+    which = sys.argv[1:] or ['f11', 'f1', 'f2', 'f3', 'f4', 'f5', 'f5u', 'f5w', 'f5c', 'f6', 'f7', 'f8', 'f9', 'f10']
+    table = dict(f11=f11_image_quantise, f10=f10_lim, f1=f1_schedule, f2=f2_noise, f3=f3_tables, f4=f4_single_step, f5=f5_trajectories, f5u=f5_unet_trajectory, f5w=f5_wide_unet_trajectory, f5c=f5_cifar_teacher_forced,
                  f6=f6_models, f7=f7_layers, f8=f8_generation_manager, f9=f9_checkpoints)
     with torch.no_grad():
         for w in which:
