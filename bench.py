@@ -144,8 +144,9 @@ class NativeRunner:
         p = dlpm_amd.load_config(cfg_name)
         torch.manual_seed(1234)
         self.net = dlpm_amd.rerandomize_(dlpm_amd.init_model_by_parameter(p), 4321)
-        if args.conv != 'auto' or args.dispatch_batch:
-            self.net.set_conv_policy(args.conv, args.dispatch_batch)
+        # the per-GPU batch of the BASELINE configuration is a declared property of the workload (the same on every rank and
+        # for every chunk), so the dispatch policy may weigh grid occupancy for it (dlpm_unet_set_conv_policy)
+        self.net.set_conv_policy(args.conv, args.dispatch_batch if args.dispatch_batch >= 0 else WORKLOADS[args.workload][1])
         self.shape = [B, p['data']['channels'], p['data']['image_size'], p['data']['image_size']]
         ev = p['eval']['dlpm']
         self.meth = dlpm_amd.GenerativeLevyProcess(alpha, str(dev), T, rescale_timesteps=True, seed=0, sample_offset=rank * B,
@@ -252,7 +253,8 @@ def main():
     ap.add_argument('--no-full-trajectory', action='store_true',
                     help='do not time a whole T-step trajectory; value = init + (T-1) * ms_per_step + gather')
     ap.add_argument('--conv', default='auto', choices=['auto', 'f4', 'f2', 'igemm'], help='convolution generation (A/B runs)')
-    ap.add_argument('--dispatch-batch', type=int, default=0, help='dlpm_unet_set_conv_policy dispatch batch (A/B runs)')
+    ap.add_argument('--dispatch-batch', type=int, default=-1,
+                    help='dlpm_unet_set_conv_policy dispatch batch (default: the per-GPU batch of the workload\'s BASELINE config; 0: geometry only)')
     ap.add_argument('--non-iso', action='store_true',
                     help='non-isotropic noise variant (--non_iso of the reference): [T,B,D] tables; not the headline config')
     ap.add_argument('--lim', action='store_true',
@@ -409,7 +411,7 @@ def main():
                        'net': 'reference cifar10.yml UNet (mc=128, 39.6M params), random init + re-drawn zero tensors'
                        if cfg_name == 'cifar10' else cfg_name,
                        'rng': 'philox (device, keyed by global sample index)', 'hip_graph': not args.no_graph,
-                       'conv_generation': args.conv,
+                       'conv_generation': args.conv, 'conv_dispatch_batch': args.dispatch_batch if args.dispatch_batch >= 0 else WORKLOADS[args.workload][1],
                        'parallelism': ('batch-sharded x%d, one RCCL all-gather at the end' % world) if world > 1 else 'single GPU (no collective)'},
             'value_source': value_source,
             'full_trajectory_s': None if full_s is None else round(full_s, 4),

@@ -5,12 +5,16 @@
 // on qkv laid out NHWC [B, T, 3C] whose channel axis is head-major [head][q | k | v][ch] -- the
 // layout the reference's reshape(b*heads, 3*ch, T) + split produces (unet.py:224,243-244).
 //
-// One workgroup per (sample, head, block of 64 queries); K (pre-scaled) and V of the head are
-// staged once in LDS.  Each wave owns 16 queries and computes S^T = K Q^T tile by tile, which
-// leaves the query on the lane and the keys in registers: the row softmax is an in-register
-// reduction plus two cross-lane steps, and -- because the MFMA's k index may be permuted freely
-// as long as A and B agree -- the normalised probabilities are ALREADY in the A-operand layout of
-// the P V product.  No score matrix is ever written to LDS or HBM.
+// One workgroup per (sample, head): K (pre-scaled) and V of the head are staged ONCE in LDS and up to 8 waves walk the
+// query tiles (16 queries each).  A wave computes S^T = K Q^T tile by tile, which leaves the query on the lane and the
+// keys in registers: the row softmax is an in-register reduction plus two cross-lane steps, and -- because the MFMA's k
+// index may be permuted freely as long as A and B agree -- the normalised probabilities are ALREADY in the A-operand
+// layout of the P V product.  No score matrix is ever written to LDS or HBM.
+// The same freedom picks the operand layouts for wide LDS reads: in Q K^T the contraction slot lk of MFMA kk is channel
+// lk CH/4 + kk, so a lane reads CH/4 CONTIGUOUS floats of its K row (ds_read_b128s instead of one ds_read_b32 per MFMA);
+// in P V output column li of tile ct is channel li CH/16 + ct, so one read of CH/16 contiguous floats of a V row feeds
+// the CH/16 independent accumulators (which also removes the 40-cycle dependent-accumulator stall of a single chain),
+// and the result leaves as whole float4s.
 #include "conv.h"
 
 namespace dlpm {
@@ -19,10 +23,12 @@ namespace {
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 template <int CH, int NT>
-__global__ void __launch_bounds__(256) k_attention(const float *__restrict__ qkv, float *__restrict__ out, int T, int C,
+__global__ void __launch_bounds__(512) k_attention(const float *__restrict__ qkv, float *__restrict__ out, int T, int C,
                                                    int heads, float scale) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int LD = CH + 4;
+    constexpr int KQ = CH / 4;      // channels per contraction slot in Q K^T
+    constexpr int NCT = CH / 16;    // output-channel tiles in P V
     float *Ks = lds, *Vs = lds + (size_t)T * LD;
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
@@ -39,78 +45,106 @@ __global__ void __launch_bounds__(256) k_attention(const float *__restrict__ qkv
     }
     __syncthreads();
 
-    const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    const int t0 = (blockIdx.y * (nthreads >> 6) + wave) * 16;
-    if (t0 >= T) return;
-
-    float qf[CH / 4];
+    const int wave = tid >> 6, nw = nthreads >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    for (int t0 = wave * 16; t0 < T; t0 += nw * 16) {
+        float qf[KQ];
+        {
+            const float *qrow = base + (int64_t)(t0 + li) * rs + lk * KQ;
 #pragma unroll
-    for (int kk = 0; kk < CH / 4; kk++) qf[kk] = base[(int64_t)(t0 + li) * rs + 4 * kk + lk] * scale;
-
-    // S^T tiles: acc[j][r] = S[t0 + li][16 j + 4 lk + r]
-    floatx4 acc[NT];
-#pragma unroll
-    for (int j = 0; j < NT; j++) {
-        acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < CH / 4; kk++) {
-            const float a = Ks[(16 * j + li) * LD + 4 * kk + lk];
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qf[kk], acc[j], 0, 0, 0);
+            for (int q = 0; q < KQ / 4; q++) {
+                const float4 v = *reinterpret_cast<const float4 *>(qrow + 4 * q);
+                qf[4 * q] = v.x * scale; qf[4 * q + 1] = v.y * scale; qf[4 * q + 2] = v.z * scale; qf[4 * q + 3] = v.w * scale;
+            }
         }
-    }
-
-    // softmax over the key axis (registers j, r and the 4 lane groups lk)
-    float mx = -INFINITY;
+        // S^T tiles: acc[j][r] = S[t0 + li][16 j + 4 lk + r]
+        floatx4 acc[NT];
+        // (two key tiles at a time: their accumulator chains interleave, so no MFMA waits on the 40-cycle latency of its predecessor)
 #pragma unroll
-    for (int j = 0; j < NT; j++)
+        for (int j = 0; j < NT; j += 2) {
+            constexpr int J2 = NT > 1 ? 2 : 1;
+            float kf[J2][KQ];
 #pragma unroll
-        for (int r = 0; r < 4; r++) mx = fmaxf(mx, acc[j][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
+            for (int u = 0; u < J2; u++) {
+                acc[j + u] = floatx4{0.f, 0.f, 0.f, 0.f};
+                const float *krow = Ks + (16 * (j + u) + li) * LD + lk * KQ;
 #pragma unroll
-    for (int j = 0; j < NT; j++)
+                for (int q = 0; q < KQ / 4; q++) *reinterpret_cast<float4 *>(kf[u] + 4 * q) = *reinterpret_cast<const float4 *>(krow + 4 * q);
+            }
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            acc[j][r] = expf(acc[j][r] - mx);
-            sum += acc[j][r];
+            for (int kk = 0; kk < KQ; kk++)
+#pragma unroll
+                for (int u = 0; u < J2; u++) acc[j + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u][kk], qf[kk], acc[j + u], 0, 0, 0);
         }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-#pragma unroll
-    for (int j = 0; j < NT; j++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) acc[j][r] = acc[j][r] / sum;
 
-    // O = P V: MFMA step (j, r) contracts the keys s = 16 j + 4 lk + r over the 4 lane groups
-    float *orow = out + ((int64_t)b * T + t0) * C + (int64_t)h * CH;
+        // softmax over the key axis (registers j, r and the 4 lane groups lk)
+        float mx = -INFINITY;
 #pragma unroll
-    for (int ct = 0; ct < CH / 16; ct++) {
-        floatx4 o = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) mx = fmaxf(mx, acc[j][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
 #pragma unroll
         for (int j = 0; j < NT; j++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float vb = Vs[(16 * j + 4 * lk + r) * LD + 16 * ct + li];
-                o = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[j][r], vb, o, 0, 0, 0);
+                acc[j][r] = __expf(acc[j][r] - mx);      // v_exp_f32 on (x - max) log2 e: <= 0, relative error ~1e-7 (|x - max| < 90)
+                sum += acc[j][r];
             }
-        // D layout: row = 4 lk + r (query), col = li (channel)
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float rsum = 1.0f / sum;                   // one IEEE division per row, 4 NT multiplies (<= 1 ulp from dividing each)
 #pragma unroll
-        for (int r = 0; r < 4; r++) orow[(int64_t)(4 * lk + r) * C + 16 * ct + li] = o[r];
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[j][r] = acc[j][r] * rsum;
+
+        // O = P V: MFMA step (j, r) contracts the keys s = 16 j + 4 lk + r over the 4 lane groups; tile ct, column li = channel li NCT + ct
+        floatx4 o[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++) o[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float *vrow = Vs + (16 * j + 4 * lk + r) * LD + li * NCT;
+                float vf[NCT];
+                if (NCT == 1) vf[0] = vrow[0];
+                else if (NCT == 2) *reinterpret_cast<float2 *>(vf) = *reinterpret_cast<const float2 *>(vrow);
+                else {
+#pragma unroll
+                    for (int q = 0; q < NCT / 4; q++) *reinterpret_cast<float4 *>(vf + 4 * q) = *reinterpret_cast<const float4 *>(vrow + 4 * q);
+                }
+#pragma unroll
+                for (int ct = 0; ct < NCT; ct++) o[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[j][r], vf[ct], o[ct], 0, 0, 0);
+            }
+        // D layout: row = 4 lk + r (query), col = li -> channels li NCT .. li NCT + NCT - 1: contiguous per lane
+        float *orow = out + ((int64_t)b * T + t0) * C + (int64_t)h * CH + li * NCT;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float *dst = orow + (int64_t)(4 * lk + r) * C;
+            if (NCT == 1) dst[0] = o[0][r];
+            else if (NCT == 2) *reinterpret_cast<float2 *>(dst) = make_float2(o[0][r], o[1][r]);
+            else {
+#pragma unroll
+                for (int q = 0; q < NCT / 4; q++)
+                    *reinterpret_cast<float4 *>(dst + 4 * q) = make_float4(o[4 * q][r], o[4 * q + 1][r], o[4 * q + 2][r], o[4 * q + 3][r]);
+            }
+        }
     }
 }
 
 template <int CH, int NT>
 int launch_t(const float *qkv, float *out, int B, int T, int C, int heads, hipStream_t st) {
-    const int nw = (T / 16) < 4 ? (T / 16) : 4;
+    const int nw = (T / 16) < 8 ? (T / 16) : 8;
     const size_t shmem = (size_t)2 * T * (CH + 4) * sizeof(float);
     if (shmem > 64 * 1024) {
         int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_attention<CH, NT>), (int)shmem);
         if (r != DLPM_OK) return r;
     }
     const float scale = (float)(1.0 / std::sqrt(std::sqrt((double)CH)));
-    dim3 grid((unsigned)(B * heads), (unsigned)ceil_div(T / 16, nw));
-    k_attention<CH, NT><<<grid, 64 * nw, shmem, st>>>(qkv, out, T, C, heads, scale);
+    k_attention<CH, NT><<<(unsigned)(B * heads), 64 * nw, shmem, st>>>(qkv, out, T, C, heads, scale);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }
