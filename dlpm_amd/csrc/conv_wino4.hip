@@ -44,7 +44,10 @@ constexpr int F4_QNIT = (F4_RAWPIX * 2 + F4_NT - 1) / F4_NT;   // staging items 
 constexpr int F4_RAWBUF = F4_RAWPIX * F4_PRLD + 16;   // floats per raw buffer, row skew included
 constexpr int F4_CFS = 16 * 2 * F4_KC;   // floats per GroupNorm-coefficient slot: [16 images][A | B][8]
 constexpr int F4_VBUF = 36 * F4_TILES * F4_KC;   // floats per V buffer: [18 position pairs][4 channel pairs][16 tiles][4]
-constexpr int F4_RING = 6;        // weight fragments (float4 = 2 positions x 2 k-steps) in flight; divides the 18 of a phase
+#ifndef F4_RING_DEPTH
+#define F4_RING_DEPTH 6
+#endif
+constexpr int F4_RING = F4_RING_DEPTH;   // weight fragments (float4 = 2 positions x 2 k-steps) in flight; divides the 18 of a phase
 constexpr int F4_ELD = F4_NQ + 4; // row image pitch
 constexpr int F4_PAD = 8;         // float4 fragments of zero padding behind the weights (ring read-ahead of the last phase)
 
