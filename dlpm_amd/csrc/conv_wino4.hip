@@ -83,6 +83,9 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
     float *Cf = raw + 2 * F4_RAWBUF;              // [2][16][2][8]
 
     DLPM_PHASE_DECL;
+#ifdef DLPM_PHASE_TIMING
+    const long long _c0 = clock64(), _r0 = wall_clock64();   // shader cycles and 100-MHz ticks: their ratio is the clock the chip holds
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int W = p.Wout, H = p.Hout, TW = W >> 2, TH = H >> 2;
@@ -454,7 +457,11 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
     }
     DLPM_PHASE(p, 10);
 #ifdef DLPM_PHASE_TIMING
-    if (p.phase && tid == 0) atomicAdd(p.phase + 11, 1ull);
+    if (p.phase && tid == 0) {
+        atomicAdd(p.phase + 11, 1ull);
+        atomicAdd(p.phase + 12, (unsigned long long)(clock64() - _c0));
+        atomicAdd(p.phase + 13, (unsigned long long)(wall_clock64() - _r0));
+    }
 #endif
 }
 

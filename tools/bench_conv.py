@@ -31,12 +31,17 @@ SHAPES = [
 ]
 
 
-def run(name, B, C0, C1, H, Cout, ups, coef, res, gen, reps):
+def run(name, B, C0, C1, H, Cout, ups, coef, res, gen, reps, zeros=False):
     Cin = C0 + C1
     g = torch.Generator(device=DEV).manual_seed(1)
     x0 = torch.randn(B, H, H, C0, device=DEV, generator=g)
     x1 = torch.randn(B, H, H, C1, device=DEV, generator=g) if C1 else None
     w = torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g) * 0.05
+    if zeros:
+        x0.zero_()
+        w.zero_()
+        if x1 is not None:
+            x1.zero_()
     bias = torch.randn(Cout, device=DEV, generator=g)
     Ho = H * 2 if ups else H
     out = torch.empty(B, Ho, Ho, Cout, device=DEV)
@@ -85,10 +90,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--gen', default='f4')
 ap.add_argument('--reps', type=int, default=10)
 ap.add_argument('--only', type=int, default=-1)
+ap.add_argument('--zeros', action='store_true', help='all-zero operands: the same instruction stream at the clock the chip holds without data toggling (DVFS check)')
 args = ap.parse_args()
 tot = 0.0
 for i, s in enumerate(SHAPES):
     if args.only >= 0 and i != args.only:
         continue
-    tot += run(*s, gen=args.gen, reps=args.reps)
+    tot += run(*s, gen=args.gen, reps=args.reps, zeros=args.zeros)
 print('sum %.4f ms' % tot)
