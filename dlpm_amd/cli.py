@@ -42,6 +42,10 @@ def main(argv=None):
     ap.add_argument('--synthetic_weights', type=int, default=None, metavar='SEED',
                     help='random init with the zero-initialised tensors re-drawn (benchmarks; NOT the reference init)')
     ap.add_argument('--rng', default='philox', choices=['philox', 'reference'])
+    ap.add_argument('--conv', default='auto', choices=['auto', 'f4', 'f2', 'igemm'],
+                    help='3x3 convolution generation of the UNet (UNetModel.set_conv_policy): auto = fastest per layer '
+                         '(Winograd F(4x4,3x3) where it applies, 1.6e-5 of the reference per forward), f2 / igemm = 3e-6 / '
+                         '4e-6 at 1.33x / 2.2x the time; never a function of the batch, so chunking does not change a pixel')
     ap.add_argument('--out', default=None, help='.npy file for the generated samples')
     ap.add_argument('--gen_data_path', default=None,
                     help='directory for <i>.png files (EvaluationManager image dump); images only')
@@ -89,6 +93,10 @@ def main(argv=None):
               file=sys.stderr)
     elif a.synthetic_weights is not None:
         dlpm_amd.rerandomize_(model, a.synthetic_weights)
+    if a.conv != 'auto':
+        if not hasattr(model, 'set_conv_policy'):
+            raise SystemExit('--conv applies to the UNet score networks')
+        model.set_conv_policy(a.conv)
     method = dlpm_amd.init_method_by_parameter(p, rng=a.rng, seed=seed or 0)
     is_image = dlpm_amd.is_image_dataset(p['data']['dataset'])
     gm = dlpm_amd.GenerationManager(method, dlpm_amd.ShapeProbe(sample_shape(p)), is_image, **p['eval'][m])

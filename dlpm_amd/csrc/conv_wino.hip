@@ -456,6 +456,20 @@ static int wino_kc_for(int Cout) {
     }
     return (pref == 16 && nw != 4 && mtp == 32 && Cout % 128 == 0) ? 16 : 8;
 }
+// Small launches of 64-channel-multiple layers (the MNIST-width nets): when a 64-tile block would hold SEVERAL whole
+// images (8x8 / 4x4-pixel tensors) and the grid of 64-tile x 64-channel blocks would leave most CUs empty, the 4-wave
+// 32-tile x 64-channel shape is used instead: twice the workgroups, two per CU.  Per (tile, channel) the arithmetic is the
+// same in both shapes (same position split, same fixed-order exchange), and multi-image blocks emit no GroupNorm
+// statistics in either, so the choice may follow the batch of the call without changing a bit
+// (test_conv_winograd_f2_small_launch_shape_is_bit_identical).
+static bool wino_small_launch(const ConvLaunch &c) {
+    if (c.Cout % 128 == 0) return false;                       // those layers already run 32-tile blocks
+    const int tpi = (c.Hout / 2) * (c.Wout / 2);               // tiles per image
+    if (tpi >= 64 || 64 % tpi != 0) return false;              // only blocks of whole small images
+    const int64_t wgs64 = ceil_div((int64_t)c.B, 64 / tpi) * (c.Cout / 64);
+    return wgs64 < 256;
+}
+
 // tiles per workgroup: 32 (x 128 output channels) for the 8-wave kernel when Cout allows it, else 64 (x 64 channels)
 int wino_tiles(const ConvLaunch &c) {
     static int pref = -1;
@@ -468,7 +482,7 @@ int wino_tiles(const ConvLaunch &c) {
 int wino_waves(const ConvLaunch &c) {
     static int pref = -1;
     if (pref < 0) { const char *e = getenv("DLPM_WINO_NW"); pref = e ? atoi(e) : 8; }
-    return pref == 4 ? 4 : 8;
+    return (pref == 4 || wino_small_launch(c)) ? 4 : 8;
 }
 
 bool wino_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg) {

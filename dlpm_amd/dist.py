@@ -4,7 +4,8 @@ The reverse loop has no cross-sample operation (GroupNorm and attention are per 
 batch is cut into contiguous shards, each rank runs the whole T-step loop on its shard with Philox
 noise keyed by the GLOBAL sample index (`sample_offset`), and ONE all-gather of the finished
 [B/W, C, H, W] fp32 shards assembles the batch.  Results are bit-identical for every
-world size.
+world size: Philox is keyed by the global sample index and no kernel choice depends on the shard size
+(dlpm_unet_set_conv_policy).
 """
 import torch
 import torch.distributed as dist
@@ -17,10 +18,11 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def all_gather_samples(local, total, group=None):
+def all_gather_samples(local, total, group=None, always_collective=False):
     """Gather contiguous shards (possibly of unequal length) into the full [total, ...] tensor on
-    every rank with a single collective."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    every rank with a single collective.  A one-rank group needs none and returns `local`, unless
+    `always_collective` asks for the collective to be issued anyway (exercises the RCCL path on one GPU)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not always_collective):
         assert local.shape[0] == total
         return local
     world = dist.get_world_size(group)

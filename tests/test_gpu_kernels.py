@@ -244,6 +244,40 @@ def test_conv_winograd_f4_full_size_batch_independence():
         assert (nchw(full[b:b + 1]).cpu() - want).abs().max().item() < 1e-4   # measured ~2e-5 (f4_32x32 case)
 
 
+@pytest.mark.parametrize('H', [8, 4])
+def test_conv_winograd_f2_small_launch_shape_is_bit_identical(H):
+    """64-channel F(2x2) layers on 8x8 / 4x4 tensors: small batches take the 4-wave 32-tile x 64-channel workgroup shape,
+    large ones the 8-wave 64-tile shape (wino_small_launch).  Same arithmetic per output: the first images of a large
+    batch must equal, bit for bit, the same images convolved as a small batch -- and match the fp64 reference."""
+    Cc, Bbig, Bsmall = 64, 2048, 6
+    g = torch.Generator(device=DEV).manual_seed(H)
+    x = torch.randn(Bbig, H, H, Cc, device=DEV, generator=g)
+    w = torch.randn(Cc, Cc, 3, 3, device=DEV, generator=g) / math.sqrt(Cc * 9)
+    bias = torch.randn(Cc, device=DEV, generator=g)
+    cA = 1 + 0.3 * torch.randn(Bbig, Cc, device=DEV, generator=g)
+    cB = 0.3 * torch.randn(Bbig, Cc, device=DEV, generator=g)
+    res = torch.randn(Bbig, H, H, Cc, device=DEV, generator=g)
+    scratch = torch.empty(90 * w.numel() + 64 * 1024 * (1 + Cc // 32), device=DEV)
+
+    def conv(n):
+        out = torch.empty(n, H, H, Cc, device=DEV)
+        a = _lib.ConvArgs()
+        xs, As, Bs, rs = x[:n].contiguous(), cA[:n].contiguous(), cB[:n].contiguous(), res[:n].contiguous()
+        a.src0, a.C0, a.B, a.Hin, a.Win, a.Hout, a.Wout = xs.data_ptr(), Cc, n, H, H, H, H
+        a.ksize, a.stride, a.weight, a.bias = 3, 1, w.data_ptr(), bias.data_ptr()
+        a.coefA, a.coefB, a.act_silu = As.data_ptr(), Bs.data_ptr(), 1
+        a.res0, a.R0, a.out, a.Cout = rs.data_ptr(), Cc, out.data_ptr(), Cc
+        a.force_direct, a.scratch_floats = 0, scratch.numel()
+        _lib.check(L().dlpm_conv2d_f32(C.byref(a), scratch.data_ptr(), st()))
+        torch.cuda.synchronize()
+        return out
+    big, small = conv(Bbig), conv(Bsmall)
+    assert torch.equal(small, big[:Bsmall])
+    want = ref_conv(nchw(x[:Bsmall]).cpu(), w.cpu(), bias.cpu(), coef=(cA[:Bsmall].cpu(), cB[:Bsmall].cpu()), silu=True,
+                    res=nchw(res[:Bsmall]).cpu())
+    assert (nchw(small).cpu() - want).abs().max().item() < conv_tol(w, Cc)
+
+
 def test_conv_boundary_layouts():
     g = torch.Generator().manual_seed(4)
     x = torch.randn(2, 3, 8, 8, generator=g)
