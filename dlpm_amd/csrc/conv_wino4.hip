@@ -23,8 +23,8 @@
 //     every A read, the LDS array busy 57 % of the kernel with two thirds of that conflict cycles -- SQ_LDS_BANK_CONFLICT);
 //   * phases are software-pipelined like k_conv3x3_wino_q: S(c+2) raw stores, X(c+1) transform, G(c+3) global loads
 //     ride between the MFMAs of phase c, one barrier per phase;
-//   * epilogue: A^T M A per lane (36 -> 16 values), LDS row image, whole NHWC rows out with bias / residual / fused
-//     GroupNorm statistics.
+//   * epilogue: A^T M A per lane (36 -> 16 values), then bias / residual / fused GroupNorm statistics / stores straight
+//     from the registers (a lane owns 64 outputs of one channel): no LDS, no barrier.
 #include <cstdlib>
 
 #include "conv.h"
@@ -48,7 +48,6 @@ constexpr int F4_VBUF = 36 * F4_TILES * F4_KC;   // floats per V buffer: [18 pos
 #define F4_RING_DEPTH 6
 #endif
 constexpr int F4_RING = F4_RING_DEPTH;   // weight fragments (float4 = 2 positions x 2 k-steps) in flight; divides the 18 of a phase
-constexpr int F4_ELD = F4_NQ + 4; // row image pitch
 constexpr int F4_PAD = 8;         // float4 fragments of zero padding behind the weights (ring read-ahead of the last phase)
 
 #ifndef F4_AAHEAD
@@ -342,43 +341,39 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
     if (p.phase && lane == 0) atomicAdd(p.phase + 16 + wave, (unsigned long long)_wait);
 #endif
 
-    // ---- epilogue.  Thread (c4, rg) of the streaming pass owns channel quad c4 and position (i, j) = (rg >> 2, rg & 3)
-    // of every tile: 16 rows, one per tile.  The first 8 residual rows are requested before the output transform.
-    const int c4 = tid & 31, rg = tid >> 5;
-    const int n = n0 + c4 * 4;
-    const int R1 = p.Cout - p.R0;
-    const bool has_res = p.res0 != nullptr;
-    int64_t mrow[F4_TILES];
-    float4 resq[F4_TILES];
-#pragma unroll
-    for (int t = 0; t < F4_TILES; t++) {
-        const int timg = t / (bh * bw), r = t - timg * (bh * bw);
-        const int ty = r / bw, tx = r - ty * bw;
-        const bool ok = img0 + timg < p.B;
-        const int64_t m = ((int64_t)min(img0 + timg, p.B - 1) * H + 4 * (ty0 + ty) + (rg >> 2)) * W + 4 * (tx0 + tx) + (rg & 3);
-        mrow[t] = ok ? m : -1;
-    }
-    auto load_res = [&](int t) {
-        const int64_t m = mrow[t] < 0 ? 0 : mrow[t];
-        resq[t] = (n < p.R0) ? *reinterpret_cast<const float4 *>(p.res0 + m * p.R0 + n)
-                             : *reinterpret_cast<const float4 *>(p.res1 + m * R1 + (n - p.R0));
-    };
-    if (has_res) {
-#pragma unroll
-        for (int t = 0; t < 8; t++) load_res(t);
-    }
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias) bias = *reinterpret_cast<const float4 *>(p.bias + n);
-
-    // output transform Y = A^T M A in registers: lane holds M_pos[tile 4 lk + r][cout 16 wave + li] in acc[pos][r]
-    //   y0 = m0 + (m1 + m2) + (m3 + m4)      y1 = (m1 - m2) + 2 (m3 - m4)
-    //   y2 = (m1 + m2) + 4 (m3 + m4)         y3 = (m1 - m2) + 8 (m3 - m4) + m5
-    // image rows of tile group lk are skewed by 16 lk floats: the four lane groups of a ds_write hit different banks
-    float *img = wsm;   // [256 rows][F4_ELD] (+ skew)
     {
-        float *dst = img + lk * 16 + wave * 16 + li;
+        // ---- epilogue from registers: no LDS, no barrier.  A lane holds 64 outputs of ONE channel (4 tiles x 16 pixels:
+        // M_pos[tile 4 lk + r][channel 16 wave + li] in acc[pos][r]), so the output transform, bias, residual, the fused
+        // GroupNorm statistics (per-lane shifted sums, then the four 16-lane groups merged in a fixed order) and the stores
+        // all happen where the values are; a 16-lane group writes 64 contiguous bytes of an NHWC row.  (The round-1
+        // epilogue staged the block through a 135-KB LDS row image for whole-row stores: 3 % slower once the loop's own LDS
+        // traffic had been cut, profiles/r02/conv_layers_register_epilogue*.txt.)
+        const int64_t pix0 = ((int64_t)img0 * H + 4 * ty0) * W + 4 * tx0;      // wave-uniform
+        const int ch = n0 + 16 * wave + li;
+        const float bias_v = p.bias ? p.bias[ch] : 0.f;
+        const bool has_res = p.res0 != nullptr;
+        const bool res_first = __builtin_amdgcn_readfirstlane(n0 + 16 * wave) < p.R0;   // R0 % 16 == 0 (wino4_geometry)
+        const float *res_u = has_res ? (res_first ? p.res0 : p.res1 - p.R0) : nullptr;
+        const int res_ld = res_first ? p.R0 : p.Cout - p.R0;
+        const int lbw = 31 - __builtin_clz(bw), lbhw = 31 - __builtin_clz(bh * bw);      // block shapes are powers of two
+        float *__restrict__ out_blk = p.out + pix0 * p.Cout;
+        const float *__restrict__ res_blk = has_res ? res_u + pix0 * res_ld : nullptr;
+        const bool do_stats = p.stats_out != nullptr && nimg == 1;
+        float K = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
+            const int tile = 4 * lk + r;
+            const int timg = tile >> lbhw, ty = (tile & (bh * bw - 1)) >> lbw, tx = tile & (bw - 1);
+            const int tpix = (timg * H + 4 * ty) * W + 4 * tx;
+            const bool ok = img0 + timg < p.B;
+            float rs[16];
+            const uint32_t lo_o = (uint32_t)(tpix * p.Cout + ch), lo_r = (uint32_t)(tpix * res_ld + ch);
+            if (has_res && ok) {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) rs[i * 4 + j] = (res_blk + (i * W + j) * res_ld)[lo_r];
+            }
             float Z[4][6];
 #pragma unroll
             for (int b = 0; b < 6; b++) {
@@ -390,69 +385,42 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
                 Z[2][b] = fmaf(4.f, s34, s12);
                 Z[3][b] = fmaf(8.f, d34, d12) + m5;
             }
-            const int tile = 4 * lk + r;
+            if (!ok) continue;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const float s12 = Z[i][1] + Z[i][2], d12 = Z[i][1] - Z[i][2], s34 = Z[i][3] + Z[i][4], d34 = Z[i][3] - Z[i][4];
-                float *row = dst + (tile * 16 + i * 4) * F4_ELD;
-                row[0 * F4_ELD] = Z[i][0] + s12 + s34;
-                row[1 * F4_ELD] = fmaf(2.f, d34, d12);
-                row[2 * F4_ELD] = fmaf(4.f, s34, s12);
-                row[3 * F4_ELD] = fmaf(8.f, d34, d12) + Z[i][5];
+                float y[4];
+                y[0] = Z[i][0] + s12 + s34;
+                y[1] = fmaf(2.f, d34, d12);
+                y[2] = fmaf(4.f, s34, s12);
+                y[3] = fmaf(8.f, d34, d12) + Z[i][5];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float v = y[j] + bias_v;
+                    if (has_res) v += rs[i * 4 + j];
+                    if (do_stats) {
+                        if (r == 0 && i == 0 && j == 0) K = v;
+                        const float dd = v - K;
+                        s1 += dd;
+                        s2 = fmaf(dd, dd, s2);
+                    }
+                    (out_blk + (i * W + j) * p.Cout)[lo_o] = v;
+                }
             }
-        }
-    }
-    if (has_res) {
-#pragma unroll
-        for (int t = 8; t < F4_TILES; t++) load_res(t);
-    }
-    __syncthreads();
-    const bool do_stats = p.stats_out != nullptr && nimg == 1;
-    float4 K = make_float4(0.f, 0.f, 0.f, 0.f), s1 = K, s2 = K;
-    int cnt = 0;
-#pragma unroll
-    for (int t = 0; t < F4_TILES; t++) {
-        const int64_t m = mrow[t];
-        if (m < 0) continue;
-        float4 v = *reinterpret_cast<const float4 *>(img + (t * 16 + rg) * F4_ELD + (t >> 2) * 16 + c4 * 4);
-        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-        if (has_res) {
-            const float4 q = resq[t];
-            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
         }
         if (do_stats) {
-            if (cnt == 0) K = v;
-            float dd;
-            dd = v.x - K.x; s1.x += dd; s2.x = fmaf(dd, dd, s2.x);
-            dd = v.y - K.y; s1.y += dd; s2.y = fmaf(dd, dd, s2.y);
-            dd = v.z - K.z; s1.z += dd; s2.z = fmaf(dd, dd, s2.z);
-            dd = v.w - K.w; s1.w += dd; s2.w = fmaf(dd, dd, s2.w);
-            cnt++;
-        }
-        *reinterpret_cast<float4 *>(p.out + m * p.Cout + n) = v;
-    }
-    if (do_stats) {
-        __syncthreads();
-        float2 *part = reinterpret_cast<float2 *>(wsm);   // [16 row groups][128]
-        const float fc = (float)(cnt > 0 ? cnt : 1);
-        const float mx = s1.x / fc, my = s1.y / fc, mz = s1.z / fc, mw = s1.w / fc;
-        part[rg * F4_NQ + c4 * 4 + 0] = make_float2(K.x + mx, fmaxf(s2.x - s1.x * mx, 0.f));
-        part[rg * F4_NQ + c4 * 4 + 1] = make_float2(K.y + my, fmaxf(s2.y - s1.y * my, 0.f));
-        part[rg * F4_NQ + c4 * 4 + 2] = make_float2(K.z + mz, fmaxf(s2.z - s1.z * mz, 0.f));
-        part[rg * F4_NQ + c4 * 4 + 3] = make_float2(K.w + mw, fmaxf(s2.w - s1.w * mw, 0.f));
-        __syncthreads();
-        if (tid < F4_NQ) {
-            const float npart = (float)F4_TILES;   // rows behind each partial
-            float mean = part[tid].x, M2 = part[tid].y, na = npart;
-            for (int g = 1; g < 16; g++) {
-                const float2 q = part[g * F4_NQ + tid];
-                const float dd = q.x - mean, N = na + npart;
-                mean += dd * (npart / N);
-                M2 += q.y + dd * dd * (na * npart / N);
-                na = N;
+            float mean = K + s1 * (1.f / 64.f), M2 = fmaxf(s2 - s1 * s1 * (1.f / 64.f), 0.f), na = 64.f;
+#pragma unroll
+            for (int sft = 16; sft <= 32; sft <<= 1) {
+                const float om = __shfl_xor(mean, sft), oM2 = __shfl_xor(M2, sft);
+                const float lo_m = (lane & sft) ? om : mean, hi_m = (lane & sft) ? mean : om;
+                const float lo_M = (lane & sft) ? oM2 : M2, hi_M = (lane & sft) ? M2 : oM2;
+                const float dd = hi_m - lo_m;
+                mean = lo_m + dd * 0.5f;
+                M2 = lo_M + hi_M + dd * dd * (na * 0.5f);
+                na *= 2.f;
             }
-            const int nt = (H * W) / 256;
-            p.stats_out[((int64_t)img0 * nt + blk_in_img) * p.Cout + n0 + tid] = make_float2(mean, M2);
+            if (lk == 0) p.stats_out[((int64_t)img0 * ((H * W) / 256) + blk_in_img) * p.Cout + ch] = make_float2(mean, M2);
         }
     }
     DLPM_PHASE(p, 10);
@@ -509,7 +477,7 @@ bool wino4_enabled() { return f4_mode() != 0; }
 bool wino4_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
     if (!c.w_wino4 || c.ks != 3 || c.stride != 1 || c.in_nchw || c.out_nchw || c.abl) return false;
     if ((c.Hout & 3) || (c.Wout & 3) || c.Cout % F4_NQ != 0 || (c.C0 + c.C1) % F4_KC != 0 || c.C0 % F4_KC != 0) return false;
-    if ((c.R0 & 3) != 0) return false;
+    if ((c.R0 & 15) != 0) return false;   // a wave's 16 output channels stay on one side of a residual concat
     const int TH = c.Hout / 4, TW = c.Wout / 4;
     int h, w, n;
     if (TH * TW >= F4_TILES) {       // a block inside one image
@@ -559,6 +527,7 @@ int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
 #endif
     using KFn = void (*)(ConvLaunch, int, int, int);
     KFn fn = c.ups ? &k_conv3x3_wino4<true> : &k_conv3x3_wino4<false>;
+
 #ifdef DLPM_WINO_ABLATIONS
     static int abl = -1;
     if (abl < 0) { const char *e = getenv("DLPM_WABL"); abl = e ? atoi(e) : 0; }
@@ -583,10 +552,9 @@ int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
         if (r != DLPM_OK) return r;
     }
     const size_t loop_b = (size_t)(2 * F4_VBUF + 2 * F4_RAWBUF + 2 * F4_CFS) * sizeof(float);
-    const size_t epi_b = (size_t)(16 * F4_TILES * F4_ELD + 64) * sizeof(float);
     const int64_t tiles = (int64_t)c.B * (c.Hout / 4) * (c.Wout / 4);
     const int64_t mblocks = nimg == 1 ? tiles / F4_TILES : ceil_div(c.B, nimg);
-    fn<<<(unsigned)(mblocks * (c.Cout / F4_NQ)), F4_NT, loop_b > epi_b ? loop_b : epi_b, st>>>(c, bh, bw, nimg);
+    fn<<<(unsigned)(mblocks * (c.Cout / F4_NQ)), F4_NT, loop_b, st>>>(c, bh, bw, nimg);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }
