@@ -367,12 +367,14 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
             const int tpix = (timg * H + 4 * ty) * W + 4 * tx;
             const bool ok = img0 + timg < p.B;
             float rs[16];
-            const uint32_t lo_o = (uint32_t)(tpix * p.Cout + ch), lo_r = (uint32_t)(tpix * res_ld + ch);
+            // addresses = wave-uniform base (block origin + pixel (i, j) of the tile) + a 32-bit per-lane byte offset
+            const uint32_t bo_o = (uint32_t)(tpix * p.Cout + ch) * 4u, bo_r = (uint32_t)(tpix * res_ld + ch) * 4u;
             if (has_res && ok) {
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++) rs[i * 4 + j] = (res_blk + (i * W + j) * res_ld)[lo_r];
+                    for (int j = 0; j < 4; j++)
+                        rs[i * 4 + j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(res_blk + (i * W + j) * res_ld) + bo_r);
             }
             float Z[4][6];
 #pragma unroll
@@ -404,7 +406,7 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
                         s1 += dd;
                         s2 = fmaf(dd, dd, s2);
                     }
-                    (out_blk + (i * W + j) * p.Cout)[lo_o] = v;
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(out_blk + (i * W + j) * p.Cout) + bo_o) = v;
                 }
             }
         }
