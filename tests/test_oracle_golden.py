@@ -271,3 +271,21 @@ def test_cifar_teacher_forced_steps_oracle_vs_reference():
             out, _, _ = P.dlpm_step(x, eps, t, Sig, g, bs, z)
         want = f['out_%d' % t]
         assert np.abs(out.numpy() - want).max() < 2e-5 * max(1.0, np.abs(want).max()), t
+
+
+def test_tiny_unet_trajectory_T1000_oracle_vs_reference():
+    """The oracle over the headline step count: T = 1000 with the tiny UNet in the loop against the reference run."""
+    from test_host_mirror import build_unet
+    f = golden('f5_traj_unet_tiny_T1000')
+    net, _ = build_unet('tiny')
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    T, alpha, ca, ce = f['meta']
+    with torch.no_grad():
+        x, hist = sampler.sample(lambda x, t: nets.unet_forward(sd, x, t, 4), [int(v) for v in f['shape']], int(T),
+                                 float(alpha), sampler.Streams(0, 0), clamp_a=float(ca), clamp_eps=float(ce),
+                                 get_sample_history=True)
+    want = f['history_every100']
+    got = hist[::100].numpy()
+    scale = np.abs(want).max(axis=(1, 2, 3, 4), keepdims=True) + 1e-6
+    assert np.max(np.abs(got - want) / scale) < 1e-4
+    assert np.abs(x.numpy() - f['final']).max() < 1e-4 * max(1.0, np.abs(f['final']).max())

@@ -341,6 +341,23 @@ def f5_wide_unet_trajectory():
          digest=np.frombuffer(bytes.fromhex(weight_digest(net)), dtype=np.uint8))
 
 
+def f5_unet_trajectories_T1000():
+    # The headline step count: full reference sample() calls at T = 1000 on identical seeds with a UNet in the loop --
+    # the tiny net (mc = 32: F(2x2) / implicit-GEMM layers on the GPU) and the wide one (mc = 128: every 3x3 stride-1
+    # convolution takes the F(4x4) kernel).  B = 2, 16x16, CIFAR clamps; every 100th state and the final one are kept.
+    for tag, mc, mult, res in (('tiny', 32, [1, 2], 1), ('wide', 128, [1, 2], 2)):
+        torch.manual_seed(1234)
+        net = make_unet(3, mc, mult, [2], 4, res).eval()
+        rerandomize(net, 4321)
+        np.random.seed(0)
+        torch.manual_seed(0)
+        T, alpha, shape = 1000, 1.7, [2, 3, 16, 16]
+        meth = GenerativeLevyProcess(alpha=alpha, device='cpu', reverse_steps=T, rescale_timesteps=True)
+        x, hist = meth.sample({'default': net}, shape, T, clamp_a=10, clamp_eps=50, get_sample_history=True)
+        save('f5_traj_unet_%s_T1000' % tag, final=x, history_every100=hist[::100], meta=np.array([T, alpha, 10, 50]),
+             shape=np.array(shape), digest=np.frombuffer(bytes.fromhex(weight_digest(net)), dtype=np.uint8))
+
+
 def f5_cifar_teacher_forced():
     # Single reverse steps x_t -> x_{t-1} of the reference (p_sample, GenerativeLevyProcess.py:225-239) with the CIFAR
     # net (cifar10.yml architecture, weights = f6_unet_cifar's) at T = 1000, alpha = 1.7, B = 2, for steps early, mid and
@@ -713,8 +730,8 @@ def f10_lim():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f11', 'f1', 'f2', 'f3', 'f4', 'f5', 'f5u', 'f5w', 'f5c', 'f6', 'f7', 'f8', 'f9', 'f10']
-    table = dict(f11=f11_image_quantise, f10=f10_lim, f1=f1_schedule, f2=f2_noise, f3=f3_tables, f4=f4_single_step, f5=f5_trajectories, f5u=f5_unet_trajectory, f5w=f5_wide_unet_trajectory, f5c=f5_cifar_teacher_forced,
+    which = sys.argv[1:] or ['f11', 'f1', 'f2', 'f3', 'f4', 'f5', 'f5u', 'f5w', 'f5k', 'f5c', 'f6', 'f7', 'f8', 'f9', 'f10']
+    table = dict(f11=f11_image_quantise, f10=f10_lim, f1=f1_schedule, f2=f2_noise, f3=f3_tables, f4=f4_single_step, f5=f5_trajectories, f5u=f5_unet_trajectory, f5w=f5_wide_unet_trajectory, f5k=f5_unet_trajectories_T1000, f5c=f5_cifar_teacher_forced,
                  f6=f6_models, f7=f7_layers, f8=f8_generation_manager, f9=f9_checkpoints)
     with torch.no_grad():
         for w in which:
