@@ -12,9 +12,10 @@ LIB_PATH = os.environ.get('DLPM_LIB') or os.path.join(_HERE, 'lib', 'libdlpm_amd
 
 vp, i32, i64, u32, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
 
-ABI_VERSION = 3   # must equal dlpm_abi_version(): struct layouts below mirror include/dlpm_amd.h at this version
+ABI_VERSION = 4   # must equal dlpm_abi_version(): struct layouts below mirror include/dlpm_amd.h at this version
 UPD_DLIM, UPD_CLIP, UPD_ADVANCE, SMP_NO_FUSED_MLP, UPD_ELEMENTWISE, SMP_LIM = 1, 2, 4, 8, 16, 32
 CONV_AUTO, CONV_F4, CONV_F2, CONV_IGEMM = 0, 1, 2, 3
+GEMM_AUTO, GEMM_F32, GEMM_BF16X3 = 0, 1, 2
 
 
 class MT19937(C.Structure):
@@ -95,6 +96,7 @@ SIGNATURES = {
     'dlpm_unet_get_feature': (C.c_int, [vp, C.c_int, vp, i64, vp]),
     'dlpm_unet_flops_per_sample': (i64, [vp]),
     'dlpm_unet_set_conv_policy': (C.c_int, [vp, i32, i64]),
+    'dlpm_unet_set_gemm_policy': (C.c_int, [vp, i32]),
     'dlpm_unet_plan_version': (i64, [vp]),
     'dlpm_unet_destroy': (None, [vp]),
     'dlpm_mlp_create': (C.c_int, [i32, i32, i32, i32, C.POINTER(vp)]),

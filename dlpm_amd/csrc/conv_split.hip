@@ -1,0 +1,356 @@
+// conv_split.hip -- the 1x1 convolutions (qkv, proj, skip connections: conv1d(k=1) / 1x1 conv2d, unet.py:157,213,215)
+// as an fp32 GEMM on the bf16 matrix pipe of gfx950.
+//
+// Every fp32 operand is cut EXACTLY into three bf16 planes, x = x0 + x1 + x2 (8 + 8 + 8 significand bits: x0 = the top
+// half of the fp32 word, x1 = the top half of x - x0, x2 = x - x0 - x1 -- each subtraction is exact), and a product is
+// the six partial products whose weight is at least 2^-16 of it,
+//     a b  ~=  a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0),
+// each exact in fp32 (8 x 8 bits), accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  What is dropped (a1 b2 + a2 b1 +
+// a2 b2) is below 2^-23 |a b|, the size of one fp32 rounding of the product; tests/test_gpu_kernels.py measures the
+// result against float64 next to the fp32 MFMA kernel's.  Six bf16 MFMAs cost 6/16 of the fp32 MFMA's pipe time
+// (tools/mb/mfma_bf16.hip: 2.1 PFLOP/s executed from LDS-fed 64x64 wave tiles = 354 fp32-equivalent TFLOP/s, against
+// the fp32 pipe's 157 peak), which turns these launches from matrix-pipe bound (95-115 TFLOP/s) into HBM bound.
+//
+// Tile: 128 pixels x 128 channels per workgroup, 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles; K in steps of 32.
+// LDS holds ONE stage (the next one waits in registers): per operand 3 planes x [k-step 2][k-half 2][row 128] x 16 B in
+// MFMA fragment order, so a fragment load is one ds_read_b128 on consecutive lanes (conflict-free) and two workgroups
+// fit a CU (48 KB each) -- one covers the other's prologue / epilogue.  Weights are split once, at plan time, into
+// exactly this stage image (k_relayout_weight_split): staging them is a 16-byte-per-lane copy.  Activations are split
+// on the way into LDS, after the fused GroupNorm affine (+ SiLU): ~6 VALU operations per element, half of which the
+// bf16 MFMAs hide (same microbenchmark: VALU work co-issues with the bf16 pipe, unlike the fp32 MFMAs).
+#include "conv.h"
+#include "igemm_epilogue.h"
+
+#ifndef SPLIT_ABL   // developer builds only (DLPM_BUILD_DEFS): 1 no re-load after stage 0, 2 no split arithmetic, 4 no MFMAs
+#define SPLIT_ABL 0   // (results are wrong when set)
+#endif
+
+#ifndef SPLIT_WGS
+#define SPLIT_WGS 2   // workgroups per CU the register budget is set for
+#endif
+
+namespace dlpm {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SKC = 32;                       // channels per stage
+constexpr int SPLANE = 128 * SKC * 2;         // bytes of one plane of one operand stage (8 KB)
+constexpr int SOPER = 3 * SPLANE;             // one operand stage (24 KB)
+constexpr int SCHUNKS = SOPER / 16;           // 16-byte chunks per operand stage (1536)
+
+// fp32 pair -> the packed bf16 pairs of the three planes.  __builtin_amdgcn_perm(hi, lo, 0x07060302) = {hi[31:16], lo[31:16]}.
+__device__ __forceinline__ void split2(float lo, float hi, uint32_t &p0, uint32_t &p1, uint32_t &p2) {
+    const uint32_t ul = __float_as_uint(lo), uh = __float_as_uint(hi);
+    p0 = __builtin_amdgcn_perm(uh, ul, 0x07060302u);
+    const float rl = lo - __uint_as_float(ul & 0xffff0000u), rh = hi - __uint_as_float(uh & 0xffff0000u);
+    const uint32_t vl = __float_as_uint(rl), vh = __float_as_uint(rh);
+    p1 = __builtin_amdgcn_perm(vh, vl, 0x07060302u);
+    const float sl = rl - __uint_as_float(vl & 0xffff0000u), sh = rh - __uint_as_float(vh & 0xffff0000u);
+    p2 = __builtin_amdgcn_perm(__float_as_uint(sh), __float_as_uint(sl), 0x07060302u);
+}
+
+// OIHW (1x1: [Cout][Cin]) -> [Cout/128][Cin/32][plane 3][k-step 2][k-half 2][row 128][8 bf16]
+__global__ void k_relayout_weight_split(const float *w, uint4 *dst, int Cout, int Cin) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (n, group of 8 k)
+    const int kg = Cin / 8;
+    if (i >= (int64_t)Cout * kg) return;
+    const int n = (int)(i / kg), g = (int)(i - (int64_t)n * kg);
+    const float *src = w + (int64_t)n * Cin + g * 8;
+    uint32_t P[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) split2(src[2 * e], src[2 * e + 1], P[0][e], P[1][e], P[2][e]);
+    const int nt = n >> 7, row = n & 127, kc = g >> 2, q = g & 3;   // q = k-step * 2 + k-half
+    uint4 *tile = dst + ((int64_t)nt * (Cin / SKC) + kc) * SCHUNKS;
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) tile[pl * (SPLANE / 16) + q * 128 + row] = make_uint4(P[pl][0], P[pl][1], P[pl][2], P[pl][3]);
+}
+
+// Epilogue of k_conv1x1_split without fused statistics.  MASKED: the tile's last rows lie beyond M (ragged last tile).
+template <bool MASKED>
+__device__ __forceinline__ void store_from_registers(const ConvLaunch &p, floatx16 (&acc)[2][2], int64_t m0, int n0, int wm, int wn,
+                                                     int l31, int kh, int mrem) {
+    const int R1 = p.Cout - p.R0;
+    const int rlim = mrem - 1 - (wm * 64 + 4 * kh);   // last valid row, counted from this lane's first row
+    const int64_t row0 = m0 + wm * 64 + 4 * kh;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        float *op = p.out + row0 * p.Cout + n;
+        float q[2][16];
+        if (p.res0) {
+            const bool r0 = n < p.R0;                    // uniform per (wave, j): R0 % 32 == 0 (gemm_split_ok)
+            const float *rp = r0 ? p.res0 + row0 * p.R0 + n : p.res1 + row0 * R1 + (n - p.R0);
+            const int rs = r0 ? p.R0 : R1;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                    q[i][r] = rp[(MASKED ? max(min(row, rlim), 0) : row) * rs];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] + bias;
+                if (p.res0) v += q[i][r];
+                if (!MASKED || row <= rlim) op[(int64_t)row * p.Cout] = v;
+            }
+    }
+}
+
+__global__ void __launch_bounds__(256, SPLIT_WGS) k_conv1x1_split(ConvLaunch p, int nsamp, int xcd_map) {
+    // [A stage 24 KB][B stage 24 KB] (the epilogue's row image afterwards) [GroupNorm coefficients of the tile's samples]
+    extern __shared__ __align__(16) unsigned char smem[];
+    DLPM_PHASE_DECL;
+#ifdef DLPM_PHASE_TIMING   // loop sub-phases accumulate in registers (one atomic per counter per workgroup: atomics inside the loop
+    long long lp[4] = {0, 0, 0, 0};   // queue behind each other at L2 and distort the very waits being measured)
+#define SPLIT_LP(i) do { if (p.phase && threadIdx.x == 0) { const long long _n = clock64(); lp[i] += _n - _pt; _pt = _n; } } while (0)
+#else
+#define SPLIT_LP(i)
+#endif
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int Cin = p.C0 + p.C1;
+    const int ntile_n = p.Cout >> 7;
+    // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8), each with its own L2.  The ntile_n channel tiles of one
+    // pixel tile read the same activations: they go to ONE XCD, back to back (xcd_map: pixel tiles % 8 == 0).
+    int mt_i, nt;
+    if (xcd_map) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        mt_i = (slot / ntile_n) * 8 + xcd;
+        nt = slot % ntile_n;
+    } else {
+        mt_i = blockIdx.x / ntile_n;
+        nt = blockIdx.x % ntile_n;
+    }
+    const int64_t m0 = (int64_t)mt_i * BM;
+    const int n0 = nt << 7;
+    const int HWo = p.Hout * p.Wout;
+
+    // A staging: 8 consecutive lanes read one pixel's 32 channels (a whole 128-byte line), a wave instruction 8 pixels;
+    // a thread owns channels 4q..4q+3 of pixels rb, rb+32, rb+64, rb+96
+    const int q = tid & 7, rb = tid >> 3;
+    const int ksh = q >> 1;                       // k-step * 2 + k-half of this thread's channels; q & 1 = which 8 bytes of the chunk
+    // a ragged last tile (B * HW not a multiple of 128: small batches of 8x8 / 4x4 tensors) re-reads its last valid pixel
+    // for the rows beyond M and never stores them: the kernel a layer takes must not depend on the batch
+    const int64_t M = (int64_t)p.B * HWo;
+    const int mrem = (int)min((int64_t)BM, M - m0);
+    const float *a0 = p.src0 + m0 * p.C0 + 4 * q;
+    const float *a1 = p.src1 ? p.src1 + m0 * p.C1 + 4 * q - p.C0 : a0;
+    int rcl[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) rcl[v] = min(rb + 32 * v, mrem - 1);
+    const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(p.w_split) + (int64_t)nt * (Cin / SKC) * SCHUNKS + tid;
+    const bool has_coef = p.coefA != nullptr;
+
+    auto load_step = [&](float4 (&xa)[4], u32x4 (&wb)[6], int s) {
+        const int c0 = s * SKC;
+        const bool first = c0 < p.C0;             // uniform: C0 % 32 == 0
+        const float *src = first ? a0 + c0 : a1 + c0;
+        const int rs = first ? p.C0 : p.C1;
+#pragma unroll
+        for (int v = 0; v < 4; v++) xa[v] = *reinterpret_cast<const float4 *>(src + rcl[v] * rs);
+#pragma unroll
+        for (int v = 0; v < 6; v++) wb[v] = wsrc[(int64_t)s * SCHUNKS + v * 256];
+    };
+    // LDS chunk (16 B = 8 channels of one row of one plane) of (ksh, row): ksh * 128 + (row ^ 8 ksh) -- the XOR spreads the
+    // 8-byte staging writes of a wave (4 ksh x 8 rows) over the banks and leaves a fragment read (32 consecutive rows) contiguous
+    uint2 *As = reinterpret_cast<uint2 *>(smem);
+    u32x4 *Bs = reinterpret_cast<u32x4 *>(smem + SOPER);
+    const float *cf = reinterpret_cast<const float *>(smem + 2 * SOPER);
+    int cfo[4];                                   // this thread's rows' coefficient rows in the LDS table
+#pragma unroll
+    for (int v = 0; v < 4; v++) cfo[v] = (nsamp > 1 ? (rb + 32 * v) / HWo : 0) * Cin + 4 * q;
+    const int wofs = (ksh * 128 + (rb ^ (ksh * 8))) * 2 + (q & 1);
+    auto store_step = [&](float4 (&xa)[4], u32x4 (&wb)[6], int s) {
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            float4 x = xa[v];
+            if (has_coef) {
+                const float4 ca = *reinterpret_cast<const float4 *>(cf + cfo[v] + s * SKC);
+                const float4 cb = *reinterpret_cast<const float4 *>(cf + nsamp * Cin + cfo[v] + s * SKC);
+                x.x = fmaf(x.x, ca.x, cb.x);
+                x.y = fmaf(x.y, ca.y, cb.y);
+                x.z = fmaf(x.z, ca.z, cb.z);
+                x.w = fmaf(x.w, ca.w, cb.w);
+            }
+            if (p.act_silu) {
+                x.x = silu_f(x.x);
+                x.y = silu_f(x.y);
+                x.z = silu_f(x.z);
+                x.w = silu_f(x.w);
+            }
+            uint32_t P[3][2];
+            if (SPLIT_ABL & 2) {
+                for (int pl = 0; pl < 3; pl++) { P[pl][0] = __float_as_uint(x.x + x.y); P[pl][1] = __float_as_uint(x.z + x.w); }
+            } else {
+                split2(x.x, x.y, P[0][0], P[1][0], P[2][0]);
+                split2(x.z, x.w, P[0][1], P[1][1], P[2][1]);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) As[pl * (SPLANE / 8) + wofs + v * 64] = make_uint2(P[pl][0], P[pl][1]);   // row + 32 v: 64 uint2 on
+        }
+#pragma unroll
+        for (int v = 0; v < 6; v++) Bs[v * 256 + tid] = wb[v];
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const bf16x8 *af = reinterpret_cast<const bf16x8 *>(smem) + kh * 128 + wm * 64;
+    const bf16x8 *bf = reinterpret_cast<const bf16x8 *>(smem + SOPER) + kh * 128 + wn * 64 + l31;
+    const int ax0 = l31 ^ (kh * 8), ax1 = l31 ^ ((2 + kh) * 8);   // swizzled row of this lane for k-step 0 / 1
+    auto mfma_step = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < ((SPLIT_ABL & 4) ? 0 : 2); ks++) {
+            bf16x8 A[2][3], B[2][3];
+            const int ax = ks ? ax1 : ax0;
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    A[i][pl] = af[pl * (SPLANE / 16) + ks * 256 + i * 32 + ax];
+                    B[i][pl] = bf[pl * (SPLANE / 16) + ks * 256 + i * 32];
+                }
+            // smallest terms first within a (tile, k-step)
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][2], B[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], B[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], B[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    const int nsteps = Cin / SKC;
+    float4 xa0[4], xa1[4];
+    u32x4 wb0[6], wb1[6];
+    // GroupNorm coefficients of the tile's samples -> LDS [A | B][nsamp][Cin] (read by every stage).  Their loads go out
+    // FIRST: loads retire in order, so the table's LDS writes wait for nothing but themselves.
+    f32x4 cq[2][2] = {};
+    const int n4 = has_coef ? nsamp * Cin / 4 : 0;   // float4 per array (<= 1024, gemm_split_ok); the first 512 ride in registers
+    const int nv4 = has_coef ? (int)min((int64_t)n4, (p.B - m0 / HWo) * (int64_t)(Cin / 4)) : 0;   // the batch may end inside the tile
+    if (has_coef) {
+        const int64_t pb0 = m0 / HWo;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int i = min(tid + r * 256, nv4 - 1);
+            cq[0][r] = reinterpret_cast<const f32x4 *>(p.coefA + pb0 * Cin)[i];
+            cq[1][r] = reinterpret_cast<const f32x4 *>(p.coefB + pb0 * Cin)[i];
+        }
+    }
+    load_step(xa0, wb0, 0);
+    if (nsteps > 1) load_step(xa1, wb1, 1);
+    if (has_coef) {
+        f32x4 *dst = reinterpret_cast<f32x4 *>(smem + 2 * SOPER);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int i = tid + r * 256;
+            if (i < n4) { dst[i] = cq[0][r]; dst[n4 + i] = cq[1][r]; }
+        }
+        const int64_t pb0 = m0 / HWo;
+        for (int i = tid + 512; i < nv4; i += 256) {   // tables beyond 512 float4 (8 samples x 512 channels): the slow way
+            dst[i] = reinterpret_cast<const f32x4 *>(p.coefA + pb0 * Cin)[i];
+            dst[n4 + i] = reinterpret_cast<const f32x4 *>(p.coefB + pb0 * Cin)[i];
+        }
+        __syncthreads();
+    }
+    DLPM_PHASE(p, 0);
+    // two register sets: the loads of stage s + 2 are issued as soon as stage s has left its registers, and have the MFMAs of
+    // two stages (this workgroup's and, on the shared SIMDs, its neighbour's) to land
+    for (int s = 0; s < nsteps; s += 2) {
+        store_step(xa0, wb0, s);
+        SPLIT_LP(0);   // developer counters 4..7: stage (incl. the wait for its loads) / barrier / MFMAs / barrier
+        __syncthreads();
+        SPLIT_LP(1);
+        if (s + 2 < nsteps && !(SPLIT_ABL & 1)) load_step(xa0, wb0, s + 2);
+        mfma_step();
+        SPLIT_LP(2);
+        __syncthreads();   // the stage is dead: the next store_step (or the epilogue's row image) may overwrite it
+        SPLIT_LP(3);
+        if (s + 1 < nsteps) {
+            store_step(xa1, wb1, s + 1);
+            SPLIT_LP(0);
+            __syncthreads();
+            SPLIT_LP(1);
+            if (s + 3 < nsteps && !(SPLIT_ABL & 1)) load_step(xa1, wb1, s + 3);
+            mfma_step();
+            SPLIT_LP(2);
+            __syncthreads();
+            SPLIT_LP(3);
+        }
+    }
+    if (p.stats_out) {   // fused GroupNorm statistics of the output: the row epilogue through LDS carries them
+        epilogue_rows_full<128, 2, 2, 2, 2>(p, acc, reinterpret_cast<float *>(smem), m0, n0, tid, wm, wn, l31, kh);
+    } else {
+        // Straight from the accumulators: lane = channel (lane & 31), registers = rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5), so one
+        // store instruction writes 32 consecutive channels of 2 pixels = two whole 128-byte lines.  No LDS, no barrier, all four
+        // waves busy; the residual's loads are issued before the first add.
+        if (mrem == BM) store_from_registers<false>(p, acc, m0, n0, wm, wn, l31, kh, BM);
+        else store_from_registers<true>(p, acc, m0, n0, wm, wn, l31, kh, mrem);
+    }
+    DLPM_PHASE(p, 2);
+#ifdef DLPM_PHASE_TIMING
+    if (p.phase && tid == 0) {
+        atomicAdd(p.phase + 3, 1ull);
+        for (int i = 0; i < 4; i++) atomicAdd(p.phase + 4 + i, (unsigned long long)lp[i]);
+    }
+#endif
+}
+
+}  // namespace
+
+int64_t split_weight_floats(int Cout, int Cin) { return ((int64_t)Cout * Cin * 6 + 3) / 4; }   // 3 bf16 planes
+
+int relayout_weight_split(const float *oihw_dev, void *dst_dev, int Cout, int Cin, hipStream_t st) {
+    if (Cout % 128 != 0 || Cin % SKC != 0) {
+        set_error("relayout_weight_split: Cout %d %% 128 or Cin %d %% 32", Cout, Cin);
+        return DLPM_ERR_UNSUPPORTED;
+    }
+    const int64_t n = (int64_t)Cout * (Cin / 8);
+    k_relayout_weight_split<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, reinterpret_cast<uint4 *>(dst_dev), Cout, Cin);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+// The shapes k_conv_igemm's MODE 2 covers, at the 128-channel tile: 1x1 / stride 1 / NHWC, full tiles.
+bool gemm_split_ok(const ConvLaunch &c) {
+    const int HW = c.Hout * c.Wout;
+    return c.w_split && c.gemm != DLPM_GEMM_F32 && c.ks == 1 && c.stride == 1 && !c.ups && !c.in_nchw && !c.out_nchw &&
+           c.Cout % 128 == 0 && c.C0 % SKC == 0 && (c.C0 + c.C1) % SKC == 0 && (c.R0 & 31) == 0 &&
+           (HW >= BM ? HW % BM == 0 : (BM % HW == 0 && (!c.coefA || (BM / HW) * (c.C0 + c.C1) * 8 <= 32 * 1024)));   // tiles hold whole samples
+}
+
+int launch_conv1x1_split(const ConvLaunch &c, hipStream_t st) {
+    const int64_t M = (int64_t)c.B * c.Hout * c.Wout;
+    static_assert(2 * SOPER >= 64 * 132 * 4, "epilogue image must fit the stage buffers");
+    const int HW = c.Hout * c.Wout;
+    const int nsamp = HW >= BM ? 1 : BM / HW;     // samples a 128-pixel tile spans
+    const int lds = 2 * SOPER + (c.coefA ? nsamp * (c.C0 + c.C1) * 8 : 0);
+    const int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_conv1x1_split), 2 * SOPER + 32 * 1024);
+    if (r != DLPM_OK) return r;
+    const int64_t mt = ceil_div(M, BM);
+    k_conv1x1_split<<<(unsigned)(mt * (c.Cout / 128)), 256, lds, st>>>(c, nsamp, (c.Cout > 128 && mt % 8 == 0) ? 1 : 0);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+}  // namespace dlpm

@@ -45,6 +45,7 @@ struct ConvW {            // one convolution's weights
     float *w_wino = nullptr; // 3x3 only: Winograd-domain weights in fragment order (conv_wino.hip)
     float *w_wino4 = nullptr;// 3x3 only: F(4x4,3x3) Winograd-domain weights (conv_wino4.hip), when DLPM_WINO_F4 is on
     float *w_small = nullptr;// 3x3 with cout <= 4 (head): [tap][cin][4]
+    void *w_split = nullptr; // 1x1 with cout % 128 == 0, cin % 32 == 0: three bf16 planes in stage-tile order (conv_split.hip)
     bool owns = false;
 };
 
@@ -174,6 +175,7 @@ struct dlpm_unet {
     bool keep_feats = false;         // dlpm_unet_keep_features: block outputs stay valid after the forward (no arena reuse)
     int gen = DLPM_CONV_AUTO;        // dlpm_unet_set_conv_policy
     int64_t dispatch_B = 0;
+    int gemm = DLPM_GEMM_AUTO;       // dlpm_unet_set_gemm_policy
     int64_t plan_version = 0;
 
     int add(const std::string &key, int64_t numel) {
@@ -229,6 +231,7 @@ namespace {
 void policy_of(const dlpm_unet *u, ConvLaunch &L) {
     L.gen = u->gen;
     L.dispatch_B = u->dispatch_B;
+    L.gemm = u->gemm;
 }
 
 // The block structure the reference constructor produces (unet.py:334-436).
@@ -305,7 +308,7 @@ bool ws_gemm_enabled() {   // DLPM_WS1X1=1: route the UNet's 1x1 convolutions th
     return v == 1;
 }
 
-int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 none, 1 NCHW input (stem), 2 NCHW output (head)
+int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 none, 1 NCHW input (stem), 2 NCHW output (head), 3 time MLP
     ConvLaunch probe;
     probe.C0 = C0; probe.C1 = c.cin - C0; probe.Cout = c.cout; probe.ks = c.ks;
     probe.in_nchw = boundary == 1; probe.out_nchw = boundary == 2;
@@ -313,6 +316,11 @@ int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 no
     const float *src = u->params[c.p_w].dev;
     if (c.use_igemm && c.ks == 1) {  // [O][I] row-major is already the igemm layout
         c.w_dev = const_cast<float *>(src);
+        if (c.cout % 128 == 0 && c.cin % 32 == 0 && boundary == 0) {
+            DLPM_HIP(hipMalloc(&c.w_split, (size_t)split_weight_floats(c.cout, c.cin) * sizeof(float)));
+            int r = relayout_weight_split(src, c.w_split, c.cout, c.cin, nullptr);
+            if (r != DLPM_OK) return r;
+        }
         if (ws_gemm_enabled() && c.cin % 32 == 0 && boundary == 0) {   // fragment order for the weight-streaming GEMM (TAPS = 1)
             DLPM_HIP(hipMalloc(&c.w_frag, (size_t)frag_weight_floats(c.cout, c.cin, 1) * sizeof(float)));
             return relayout_weight_frag(src, c.w_frag, c.cout, c.cin, nullptr, 1);
@@ -351,6 +359,7 @@ int run_conv(const dlpm_unet *u, const ConvW &c, ConvLaunch L, hipStream_t st) {
     L.w_wino = c.w_wino;
     L.w_wino4 = c.w_wino4;
     L.w_small = c.w_small;
+    L.w_split = c.w_split;
     L.ws_gemm = (c.ks == 1 && c.w_frag) ? 1 : 0;
     L.ks = c.ks;
     L.Cout = c.cout;
@@ -658,6 +667,8 @@ static void free_conv(ConvW &c) {
     c.w_wino4 = nullptr;
     if (c.w_small) (void)hipFree(c.w_small);
     c.w_small = nullptr;
+    if (c.w_split) (void)hipFree(c.w_split);
+    c.w_split = nullptr;
     c.w_dev = nullptr;
     c.owns = false;
 }
@@ -708,8 +719,8 @@ extern "C" int dlpm_unet_finalize(dlpm_unet *u) {
             ch = s[0].cout;
         }
     }
-    TRY(prep_conv(u, u->te0, u->te0.cin, 0));
-    TRY(prep_conv(u, u->te2, u->te2.cin, 0));
+    TRY(prep_conv(u, u->te0, u->te0.cin, 3));   // 3: the time path stays on the fp32 pipe whatever its row count
+    TRY(prep_conv(u, u->te2, u->te2.cin, 3));
     TRY(prep_conv(u, u->head, u->head.cin, 2));
     // fused emb GEMM: rows of every emb_layers.1.weight stacked in ResBlock order
     if (u->embcat_w) (void)hipFree(u->embcat_w);
@@ -757,6 +768,15 @@ extern "C" int dlpm_unet_set_conv_policy(dlpm_unet *u, int32_t generation, int64
     if (u->gen == generation && u->dispatch_B == dispatch_batch) return DLPM_OK;
     u->gen = generation;
     u->dispatch_B = dispatch_batch;
+    u->plan_version++;
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_unet_set_gemm_policy(dlpm_unet *u, int32_t mode) {
+    DLPM_CHECK_ARG(u, "dlpm_unet_set_gemm_policy: null handle");
+    DLPM_CHECK_ARG(mode >= DLPM_GEMM_AUTO && mode <= DLPM_GEMM_BF16X3, "dlpm_unet_set_gemm_policy: unknown mode %d", mode);
+    if (u->gemm == mode) return DLPM_OK;
+    u->gemm = mode;
     u->plan_version++;
     return DLPM_OK;
 }
@@ -883,6 +903,14 @@ extern "C" int dlpm_conv2d_f32(const dlpm_conv_args *a, float *scratch_dev, dlpm
         TRY(relayout_weight_frag(a->weight, wf, a->Cout, a->C0 + a->C1, st, 1));
         L.w_frag = wf;
         L.ws_gemm = 1;
+    }
+    L.gemm = DLPM_GEMM_F32;
+    if (ig && a->ksize == 1 && (a->force_direct & 16) && a->Cout % 128 == 0 && (a->C0 + a->C1) % 32 == 0 &&
+        a->scratch_floats >= (int64_t)a->Cout * (a->C0 + a->C1) + split_weight_floats(a->Cout, a->C0 + a->C1)) {
+        float *wsp = scratch_dev + (int64_t)a->Cout * (a->C0 + a->C1);
+        TRY(relayout_weight_split(a->weight, wsp, a->Cout, a->C0 + a->C1, st));
+        L.w_split = wsp;
+        L.gemm = DLPM_GEMM_BF16X3;
     }
     if (ig && a->ksize == 3 && (a->C0 + a->C1) % 32 == 0 &&
         a->scratch_floats >= (int64_t)a->Cout * (a->C0 + a->C1) * 9 + frag_weight_floats(a->Cout, a->C0 + a->C1)) {

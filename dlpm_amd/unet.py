@@ -110,6 +110,7 @@ class UNetModel(nn.Module):
         self._handle_size = None
         self._ws = None
         self._conv_policy = (_lib.CONV_AUTO, 0)
+        self._gemm_policy = _lib.GEMM_AUTO
         self.handle_generation = 0          # bumped whenever the native handle is destroyed (sampler cache keys carry it)
         self._dependents = weakref.WeakSet()  # method objects holding native samplers built on this handle
 
@@ -133,6 +134,15 @@ class UNetModel(nn.Module):
         self._conv_policy = (gen, int(dispatch_batch))
         if self._handle is not None:
             _lib.check(_lib.lib().dlpm_unet_set_conv_policy(self._handle, gen, int(dispatch_batch)))
+
+    def set_gemm_policy(self, mode='auto'):
+        """Which matrix pipe the 1x1 convolutions take (dlpm_unet_set_gemm_policy): 'bf16x3' (fp32 operands cut exactly
+        into three bf16 planes, six partial products accumulated in fp32: fp32-grade results at 6/16 of the pipe time),
+        'f32' (the fp32 MFMA), 'auto' = 'bf16x3' where the shape admits it.  Never a function of the batch."""
+        mode = {'auto': _lib.GEMM_AUTO, 'f32': _lib.GEMM_F32, 'bf16x3': _lib.GEMM_BF16X3}[mode]
+        self._gemm_policy = mode
+        if self._handle is not None:
+            _lib.check(_lib.lib().dlpm_unet_set_gemm_policy(self._handle, mode))
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
@@ -172,6 +182,7 @@ class UNetModel(nn.Module):
             _lib.check(L.dlpm_unet_set_param(h, k.encode(), w.data_ptr(), w.numel()))
         _lib.check(L.dlpm_unet_finalize(h))
         _lib.check(L.dlpm_unet_set_conv_policy(h, self._conv_policy[0], self._conv_policy[1]))
+        _lib.check(L.dlpm_unet_set_gemm_policy(h, self._gemm_policy))
         self._handle, self._handle_size = h, image_size
         return h
 

@@ -633,3 +633,54 @@ def test_groupnorm_large_offset_is_stable():
     y = (x.double() * cA.cpu().double()[:, :, None, None] + cB.cpu().double()[:, :, None, None]).float()
     # x*A + B with |x| = 100, A ~ 3: the affine form itself carries ~100*3*6e-8 = 2e-5 of rounding in B
     assert (y - want).abs().max().item() < 2e-4
+
+
+SPLIT_CASES = [
+    # name, B, C0, C1, H, Cout, coef, silu, res     (shapes of the UNet's 1x1 convolutions, small batches)
+    ('qkv_8x8', 4, 256, 0, 8, 768, True, False, False),
+    ('proj_res_8x8', 4, 256, 0, 8, 256, False, False, True),
+    ('skip_concat_32x32', 1, 128, 128, 32, 128, False, False, False),
+    ('skip_concat_256_128', 2, 256, 128, 16, 256, False, False, False),
+    ('gn_silu_128', 2, 128, 0, 8, 128, True, True, False),
+    ('long_k_512', 2, 256, 256, 8, 256, False, False, True),
+    ('ragged_qkv_4x4_b3', 3, 256, 0, 4, 768, True, False, False),       # M = 48: one partial tile, 3 samples of 8 in its table
+    ('ragged_proj_res_8x8_b3', 3, 256, 0, 8, 256, False, False, True),  # M = 192: a full and a half tile
+    ('xcd_mapped_qkv_8x8_b16', 16, 256, 0, 8, 384, True, False, False),  # 8 pixel tiles x 3 channel tiles
+]
+
+
+@pytest.mark.parametrize('case', SPLIT_CASES, ids=[c[0] for c in SPLIT_CASES])
+def test_conv1x1_bf16_split_gemm_is_fp32_grade(case):
+    """conv_split.hip (force_direct bit 4): fp32 operands cut exactly into three bf16 planes, six partial products per
+    multiply, fp32 accumulation on the bf16 matrix pipe.  Judged against float64 next to the fp32 MFMA kernel on the same
+    inputs: its error may not exceed 1.5x the fp32 kernel's (+ one ulp of slack), and both stay inside the fp32
+    accumulation bound.  Operands span 12 binades, with exact zeros and tiny (1e-30) magnitudes mixed in."""
+    name, B, C0, C1, H, Cout, use_coef, silu, use_res = case
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    Cin = C0 + C1
+    scale = lambda *s: torch.exp2(torch.randint(-6, 7, s, generator=g).float())
+    x0 = torch.randn(B, C0, H, H, generator=g) * scale(B, C0, H, H)
+    x0[0, :8, 0, 0] = 0.0
+    x0[0, 8:16, 0, 0] = 1e-30
+    x1 = torch.randn(B, C1, H, H, generator=g) if C1 else None
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / math.sqrt(Cin) * scale(Cout, Cin, 1, 1) / 8
+    w[0, :4] = 0.0
+    bias = torch.randn(Cout, generator=g)
+    coef = (1 + 0.3 * torch.randn(B, Cin, generator=g), 0.3 * torch.randn(B, Cin, generator=g)) if use_coef else None
+    res = torch.randn(B, Cout, H, H, generator=g) if use_res else None
+    x = x0 if x1 is None else torch.cat([x0, x1], 1)
+    if coef is not None:
+        x = x * coef[0][:, :, None, None] + coef[1][:, :, None, None]
+    if silu:
+        x = nets.silu(x)
+    want = F.conv2d(x.double(), w.double(), bias.double())
+    if res is not None:
+        want = want + res.double()
+    mag = F.conv2d(x.double().abs(), w.double().abs()).max().item()   # sum |a||b|: what fp32 accumulation errors scale with
+    got32 = run_conv(x0, w, bias, x1, 1, 0, coef, silu, res).double()
+    got16 = run_conv(x0, w, bias, x1, 1, 0, coef, silu, res, force_direct=16).double()
+    e32, e16 = (got32 - want).abs().max().item(), (got16 - want).abs().max().item()
+    print('%s: fp32 MFMA err %.2e, bf16x3 err %.2e (sum|a||b| max %.1f, Cin %d)' % (name, e32, e16, mag, Cin))
+    assert e16 <= 1.5 * e32 + 1.2e-7 * mag, name
+    assert e16 < 3e-7 * math.sqrt(Cin) * mag, name
+    assert not torch.equal(got16, got32) or e16 == 0.0   # the split kernel really ran (different rounding order)

@@ -81,6 +81,8 @@ def run(name, B, C0, C1, H, Cout, ks, coef, res, reps=5):
     tot = pro + main + epi
     print('%-30s %8.3f ms/call(+relayout)  wgs/launch %6d  cycles/wg: prologue %7.0f (%4.1f%%)  loop %7.0f (%4.1f%%)  epilogue %7.0f (%4.1f%%)'
           % (name, e0.elapsed_time(e1) / reps, n // reps, pro, 100 * pro / tot, main, 100 * main / tot, epi, 100 * epi / tot))
+    if any(ph[4 + i] for i in range(4)):
+        print('    loop, per workgroup: stage+wait %7.0f  barrier %7.0f  MFMAs %7.0f  barrier %7.0f' % tuple(ph[4 + i] / max(n, 1) for i in range(4)))
     if ph[13]:
         print('    in-kernel clock: %.0f MHz (shader cycles / 100-MHz ticks over each workgroup\'s life)' % (100.0 * ph[12] / ph[13]))
     if any(ph[16 + w] for w in range(8)):
