@@ -1093,6 +1093,9 @@ int launch_conv_igemm(const ConvLaunch &c, hipStream_t st) {
 #ifdef DLPM_PHASE_TIMING
         const_cast<ConvLaunch &>(c).phase = phase_buffer();
 #endif
+#ifdef DLPM_IGEMM_ABLATIONS
+        { const char *e = getenv("DLPM_ABL"); if (e) const_cast<ConvLaunch &>(c).abl = atoi(e); }
+#endif
         return launch_conv1x1_split(c, st);
     }
     ProfScope ps(pname, 2.0 * M * c.Cout * K, bytes, st);

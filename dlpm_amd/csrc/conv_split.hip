@@ -25,6 +25,12 @@
 #define SPLIT_ABL 0   // (results are wrong when set)
 #endif
 
+#ifdef DLPM_IGEMM_ABLATIONS   // developer builds only: DLPM_ABL bits at run time (results are wrong when set): 1 no output stores,
+#define SABL(b) (p.abl & (b))  // 2 no activation re-loads, 4 no weight re-loads, 8 no MFMAs, 16 no activation staging, 32 no weight staging
+#else
+#define SABL(b) 0
+#endif
+
 #ifndef SPLIT_WGS
 #define SPLIT_WGS 2   // workgroups per CU the register budget is set for
 #endif
@@ -68,16 +74,19 @@ __global__ void k_relayout_weight_split(const float *w, uint4 *dst, int Cout, in
     for (int pl = 0; pl < 3; pl++) tile[pl * (SPLANE / 16) + q * 128 + row] = make_uint4(P[pl][0], P[pl][1], P[pl][2], P[pl][3]);
 }
 
-// Epilogue of k_conv1x1_split without fused statistics.  MASKED: the tile's last rows lie beyond M (ragged last tile).
-template <bool MASKED>
-__device__ __forceinline__ void store_from_registers(const ConvLaunch &p, floatx16 (&acc)[2][2], int64_t m0, int n0, int wm, int wn,
+// Epilogue of k_conv1x1_split without fused statistics, straight from the accumulators: lane = channel (lane & 31), registers =
+// rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5), so one store instruction writes 32 consecutive channels of 2 pixels = two whole
+// 128-byte lines.  No LDS, no barrier, every wave busy; the residual's loads are issued before the first add.
+// MASKED: the tile's last rows lie beyond M (ragged last tile).
+template <bool MASKED, int RN>
+__device__ __forceinline__ void store_from_registers(const ConvLaunch &p, floatx16 (&acc)[2][RN], int64_t m0, int nw0, int wm,
                                                      int l31, int kh, int mrem) {
     const int R1 = p.Cout - p.R0;
     const int rlim = mrem - 1 - (wm * 64 + 4 * kh);   // last valid row, counted from this lane's first row
     const int64_t row0 = m0 + wm * 64 + 4 * kh;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int n = n0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < RN; j++) {
+        const int n = nw0 + j * 32 + l31;
         const float bias = p.bias ? p.bias[n] : 0.f;
         float *op = p.out + row0 * p.Cout + n;
         float q[2][16];
@@ -100,13 +109,20 @@ __device__ __forceinline__ void store_from_registers(const ConvLaunch &p, floatx
                 const int row = i * 32 + (r & 3) + 8 * (r >> 2);
                 float v = acc[i][j][r] + bias;
                 if (p.res0) v += q[i][r];
+                if (SABL(1) && v == v) continue;
                 if (!MASKED || row <= rlim) op[(int64_t)row * p.Cout] = v;
             }
     }
 }
 
-__global__ void __launch_bounds__(256, SPLIT_WGS) k_conv1x1_split(ConvLaunch p, int nsamp, int xcd_map) {
-    // [A stage 24 KB][B stage 24 KB] (the epilogue's row image afterwards) [GroupNorm coefficients of the tile's samples]
+// NW waves: 4 = 2 x 2 waves of 64 x 64 (2 workgroups per CU); 8 = 2 x 4 waves of 64 x 32 (2 workgroups = 4 waves per SIMD).
+// (Also measured: 8 waves with two register stages -- 138 registers, one workgroup per CU -- 19 % slower.)
+// DIST: stages of operands waiting in registers.
+template <int NW, int DIST>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv1x1_split(ConvLaunch p, int nsamp, int xcd_map) {
+    constexpr int NT = NW * 64, RN = NW == 4 ? 2 : 1, WN = 4 / RN;   // threads, MFMA column tiles per wave, waves across N
+    constexpr int RSTEP = NT / 8, NV = 128 / RSTEP, NWV = SCHUNKS / NT;   // staging: rows per pass, passes, weight chunks per thread
+    // [A stage 24 KB][B stage 24 KB] (the statistics epilogue's row image afterwards) [GroupNorm coefficients of the tile's samples]
     extern __shared__ __align__(16) unsigned char smem[];
     DLPM_PHASE_DECL;
 #ifdef DLPM_PHASE_TIMING   // loop sub-phases accumulate in registers (one atomic per counter per workgroup: atomics inside the loop
@@ -117,7 +133,7 @@ __global__ void __launch_bounds__(256, SPLIT_WGS) k_conv1x1_split(ConvLaunch p, 
 #endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int Cin = p.C0 + p.C1;
     const int ntile_n = p.Cout >> 7;
     // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8), each with its own L2.  The ntile_n channel tiles of one
@@ -136,7 +152,7 @@ __global__ void __launch_bounds__(256, SPLIT_WGS) k_conv1x1_split(ConvLaunch p, 
     const int HWo = p.Hout * p.Wout;
 
     // A staging: 8 consecutive lanes read one pixel's 32 channels (a whole 128-byte line), a wave instruction 8 pixels;
-    // a thread owns channels 4q..4q+3 of pixels rb, rb+32, rb+64, rb+96
+    // a thread owns channels 4q..4q+3 of pixels rb, rb + RSTEP, ...
     const int q = tid & 7, rb = tid >> 3;
     const int ksh = q >> 1;                       // k-step * 2 + k-half of this thread's channels; q & 1 = which 8 bytes of the chunk
     // a ragged last tile (B * HW not a multiple of 128: small batches of 8x8 / 4x4 tensors) re-reads its last valid pixel
@@ -145,34 +161,39 @@ __global__ void __launch_bounds__(256, SPLIT_WGS) k_conv1x1_split(ConvLaunch p, 
     const int mrem = (int)min((int64_t)BM, M - m0);
     const float *a0 = p.src0 + m0 * p.C0 + 4 * q;
     const float *a1 = p.src1 ? p.src1 + m0 * p.C1 + 4 * q - p.C0 : a0;
-    int rcl[4];
+    int rcl[NV];
 #pragma unroll
-    for (int v = 0; v < 4; v++) rcl[v] = min(rb + 32 * v, mrem - 1);
+    for (int v = 0; v < NV; v++) rcl[v] = min(rb + RSTEP * v, mrem - 1);
     const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(p.w_split) + (int64_t)nt * (Cin / SKC) * SCHUNKS + tid;
     const bool has_coef = p.coefA != nullptr;
 
-    auto load_step = [&](float4 (&xa)[4], u32x4 (&wb)[6], int s) {
+    auto load_step = [&](float4 (&xa)[NV], u32x4 (&wb)[NWV], int s) {
         const int c0 = s * SKC;
         const bool first = c0 < p.C0;             // uniform: C0 % 32 == 0
         const float *src = first ? a0 + c0 : a1 + c0;
         const int rs = first ? p.C0 : p.C1;
+        if (!(SABL(2) && s >= 2)) {
 #pragma unroll
-        for (int v = 0; v < 4; v++) xa[v] = *reinterpret_cast<const float4 *>(src + rcl[v] * rs);
+            for (int v = 0; v < NV; v++) xa[v] = *reinterpret_cast<const float4 *>(src + rcl[v] * rs);
+        }
+        if (!(SABL(4) && s >= 2)) {
 #pragma unroll
-        for (int v = 0; v < 6; v++) wb[v] = wsrc[(int64_t)s * SCHUNKS + v * 256];
+            for (int v = 0; v < NWV; v++) wb[v] = wsrc[(int64_t)s * SCHUNKS + v * NT];
+        }
     };
     // LDS chunk (16 B = 8 channels of one row of one plane) of (ksh, row): ksh * 128 + (row ^ 8 ksh) -- the XOR spreads the
     // 8-byte staging writes of a wave (4 ksh x 8 rows) over the banks and leaves a fragment read (32 consecutive rows) contiguous
     uint2 *As = reinterpret_cast<uint2 *>(smem);
     u32x4 *Bs = reinterpret_cast<u32x4 *>(smem + SOPER);
     const float *cf = reinterpret_cast<const float *>(smem + 2 * SOPER);
-    int cfo[4];                                   // this thread's rows' coefficient rows in the LDS table
+    int cfo[NV];                                  // this thread's rows' coefficient rows in the LDS table
 #pragma unroll
-    for (int v = 0; v < 4; v++) cfo[v] = (nsamp > 1 ? (rb + 32 * v) / HWo : 0) * Cin + 4 * q;
+    for (int v = 0; v < NV; v++) cfo[v] = (nsamp > 1 ? (rb + RSTEP * v) / HWo : 0) * Cin + 4 * q;
     const int wofs = (ksh * 128 + (rb ^ (ksh * 8))) * 2 + (q & 1);
-    auto store_step = [&](float4 (&xa)[4], u32x4 (&wb)[6], int s) {
+    auto store_step = [&](float4 (&xa)[NV], u32x4 (&wb)[NWV], int s) {
 #pragma unroll
-        for (int v = 0; v < 4; v++) {
+        for (int v = 0; v < NV; v++) {
+            if (SABL(16) && s >= 2) break;
             float4 x = xa[v];
             if (has_coef) {
                 const float4 ca = *reinterpret_cast<const float4 *>(cf + cfo[v] + s * SKC);
@@ -196,40 +217,43 @@ __global__ void __launch_bounds__(256, SPLIT_WGS) k_conv1x1_split(ConvLaunch p, 
                 split2(x.z, x.w, P[0][1], P[1][1], P[2][1]);
             }
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) As[pl * (SPLANE / 8) + wofs + v * 64] = make_uint2(P[pl][0], P[pl][1]);   // row + 32 v: 64 uint2 on
+            for (int pl = 0; pl < 3; pl++) As[pl * (SPLANE / 8) + wofs + v * (RSTEP * 2)] = make_uint2(P[pl][0], P[pl][1]);
         }
+        if (!(SABL(32) && s >= 2)) {
 #pragma unroll
-        for (int v = 0; v < 6; v++) Bs[v * 256 + tid] = wb[v];
+            for (int v = 0; v < NWV; v++) Bs[v * NT + tid] = wb[v];
+        }
     };
 
-    floatx16 acc[2][2];
+    floatx16 acc[2][RN];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < RN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
     const bf16x8 *af = reinterpret_cast<const bf16x8 *>(smem) + kh * 128 + wm * 64;
-    const bf16x8 *bf = reinterpret_cast<const bf16x8 *>(smem + SOPER) + kh * 128 + wn * 64 + l31;
+    const bf16x8 *bf = reinterpret_cast<const bf16x8 *>(smem + SOPER) + kh * 128 + wn * (RN * 32) + l31;
     const int ax0 = l31 ^ (kh * 8), ax1 = l31 ^ ((2 + kh) * 8);   // swizzled row of this lane for k-step 0 / 1
     auto mfma_step = [&]() {
+        if (SABL(8)) return;
 #pragma unroll
         for (int ks = 0; ks < ((SPLIT_ABL & 4) ? 0 : 2); ks++) {
-            bf16x8 A[2][3], B[2][3];
+            bf16x8 A[2][3], B[RN][3];
             const int ax = ks ? ax1 : ax0;
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++)
+            for (int pl = 0; pl < 3; pl++) {
 #pragma unroll
-                for (int i = 0; i < 2; i++) {
-                    A[i][pl] = af[pl * (SPLANE / 16) + ks * 256 + i * 32 + ax];
-                    B[i][pl] = bf[pl * (SPLANE / 16) + ks * 256 + i * 32];
-                }
+                for (int i = 0; i < 2; i++) A[i][pl] = af[pl * (SPLANE / 16) + ks * 256 + i * 32 + ax];
+#pragma unroll
+                for (int j = 0; j < RN; j++) B[j][pl] = bf[pl * (SPLANE / 16) + ks * 256 + j * 32];
+            }
             // smallest terms first within a (tile, k-step)
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int j = 0; j < 2; j++) {
+                for (int j = 0; j < RN; j++) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][2], B[j][0], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], B[j][1], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][2], acc[i][j], 0, 0, 0);
@@ -241,72 +265,86 @@ __global__ void __launch_bounds__(256, SPLIT_WGS) k_conv1x1_split(ConvLaunch p, 
     };
 
     const int nsteps = Cin / SKC;
-    float4 xa0[4], xa1[4];
-    u32x4 wb0[6], wb1[6];
+    float4 xa0[NV], xa1[NV];
+    u32x4 wb0[NWV], wb1[NWV];
     // GroupNorm coefficients of the tile's samples -> LDS [A | B][nsamp][Cin] (read by every stage).  Their loads go out
     // FIRST: loads retire in order, so the table's LDS writes wait for nothing but themselves.
-    f32x4 cq[2][2] = {};
-    const int n4 = has_coef ? nsamp * Cin / 4 : 0;   // float4 per array (<= 1024, gemm_split_ok); the first 512 ride in registers
+    constexpr int CR = 512 / NT;                  // rounds of NT float4 that ride in registers (the first 512)
+    f32x4 cq[2][CR] = {};
+    const int n4 = has_coef ? nsamp * Cin / 4 : 0;   // float4 per array (<= 1024, gemm_split_ok)
     const int nv4 = has_coef ? (int)min((int64_t)n4, (p.B - m0 / HWo) * (int64_t)(Cin / 4)) : 0;   // the batch may end inside the tile
     if (has_coef) {
         const int64_t pb0 = m0 / HWo;
 #pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const int i = min(tid + r * 256, nv4 - 1);
+        for (int r = 0; r < CR; r++) {
+            const int i = min(tid + r * NT, nv4 - 1);
             cq[0][r] = reinterpret_cast<const f32x4 *>(p.coefA + pb0 * Cin)[i];
             cq[1][r] = reinterpret_cast<const f32x4 *>(p.coefB + pb0 * Cin)[i];
         }
     }
     load_step(xa0, wb0, 0);
-    if (nsteps > 1) load_step(xa1, wb1, 1);
+    if (DIST == 2 && nsteps > 1) load_step(xa1, wb1, 1);
     if (has_coef) {
         f32x4 *dst = reinterpret_cast<f32x4 *>(smem + 2 * SOPER);
 #pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const int i = tid + r * 256;
+        for (int r = 0; r < CR; r++) {
+            const int i = tid + r * NT;
             if (i < n4) { dst[i] = cq[0][r]; dst[n4 + i] = cq[1][r]; }
         }
         const int64_t pb0 = m0 / HWo;
-        for (int i = tid + 512; i < nv4; i += 256) {   // tables beyond 512 float4 (8 samples x 512 channels): the slow way
+        for (int i = tid + 512; i < nv4; i += NT) {   // tables beyond 512 float4 (8 samples x 512 channels): the slow way
             dst[i] = reinterpret_cast<const f32x4 *>(p.coefA + pb0 * Cin)[i];
             dst[n4 + i] = reinterpret_cast<const f32x4 *>(p.coefB + pb0 * Cin)[i];
         }
         __syncthreads();
     }
     DLPM_PHASE(p, 0);
-    // two register sets: the loads of stage s + 2 are issued as soon as stage s has left its registers, and have the MFMAs of
-    // two stages (this workgroup's and, on the shared SIMDs, its neighbour's) to land
-    for (int s = 0; s < nsteps; s += 2) {
-        store_step(xa0, wb0, s);
-        SPLIT_LP(0);   // developer counters 4..7: stage (incl. the wait for its loads) / barrier / MFMAs / barrier
-        __syncthreads();
-        SPLIT_LP(1);
-        if (s + 2 < nsteps && !(SPLIT_ABL & 1)) load_step(xa0, wb0, s + 2);
-        mfma_step();
-        SPLIT_LP(2);
-        __syncthreads();   // the stage is dead: the next store_step (or the epilogue's row image) may overwrite it
-        SPLIT_LP(3);
-        if (s + 1 < nsteps) {
-            store_step(xa1, wb1, s + 1);
+    if constexpr (DIST == 2) {
+        // two register sets: the loads of stage s + 2 are issued as soon as stage s has left its registers
+        for (int s = 0; s < nsteps; s += 2) {
+            store_step(xa0, wb0, s);
+            SPLIT_LP(0);   // developer counters 4..7: stage (incl. the wait for its loads) / barrier / MFMAs / barrier
+            __syncthreads();
+            SPLIT_LP(1);
+            if (s + 2 < nsteps && !(SPLIT_ABL & 1)) load_step(xa0, wb0, s + 2);
+            mfma_step();
+            SPLIT_LP(2);
+            __syncthreads();   // the stage is dead: the next store_step may overwrite it
+            SPLIT_LP(3);
+            if (s + 1 < nsteps) {
+                store_step(xa1, wb1, s + 1);
+                SPLIT_LP(0);
+                __syncthreads();
+                SPLIT_LP(1);
+                if (s + 3 < nsteps && !(SPLIT_ABL & 1)) load_step(xa1, wb1, s + 3);
+                mfma_step();
+                SPLIT_LP(2);
+                __syncthreads();
+                SPLIT_LP(3);
+            }
+        }
+    } else {
+        for (int s = 0; s < nsteps; s++) {
+            store_step(xa0, wb0, s);
             SPLIT_LP(0);
             __syncthreads();
             SPLIT_LP(1);
-            if (s + 3 < nsteps && !(SPLIT_ABL & 1)) load_step(xa1, wb1, s + 3);
+            if (s + 1 < nsteps && !(SPLIT_ABL & 1)) load_step(xa0, wb0, s + 1);   // in flight under the MFMAs below
             mfma_step();
             SPLIT_LP(2);
             __syncthreads();
             SPLIT_LP(3);
         }
     }
-    if (p.stats_out) {   // fused GroupNorm statistics of the output: the row epilogue through LDS carries them
-        epilogue_rows_full<128, 2, 2, 2, 2>(p, acc, reinterpret_cast<float *>(smem), m0, n0, tid, wm, wn, l31, kh);
-    } else {
-        // Straight from the accumulators: lane = channel (lane & 31), registers = rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5), so one
-        // store instruction writes 32 consecutive channels of 2 pixels = two whole 128-byte lines.  No LDS, no barrier, all four
-        // waves busy; the residual's loads are issued before the first add.
-        if (mrem == BM) store_from_registers<false>(p, acc, m0, n0, wm, wn, l31, kh, BM);
-        else store_from_registers<true>(p, acc, m0, n0, wm, wn, l31, kh, mrem);
+    if constexpr (NW == 4) {
+        if (p.stats_out) {   // fused GroupNorm statistics of the output: the row epilogue through LDS carries them
+            epilogue_rows_full<128, 2, 2, 2, 2>(p, acc, reinterpret_cast<float *>(smem), m0, n0, tid, wm, wn, l31, kh);
+            DLPM_PHASE(p, 2);
+            return;
+        }
     }
+    if (mrem == BM) store_from_registers<false, RN>(p, acc, m0, n0 + wn * (RN * 32), wm, l31, kh, BM);
+    else store_from_registers<true, RN>(p, acc, m0, n0 + wn * (RN * 32), wm, l31, kh, mrem);
     DLPM_PHASE(p, 2);
 #ifdef DLPM_PHASE_TIMING
     if (p.phase && tid == 0) {
@@ -345,10 +383,21 @@ int launch_conv1x1_split(const ConvLaunch &c, hipStream_t st) {
     const int HW = c.Hout * c.Wout;
     const int nsamp = HW >= BM ? 1 : BM / HW;     // samples a 128-pixel tile spans
     const int lds = 2 * SOPER + (c.coefA ? nsamp * (c.C0 + c.C1) * 8 : 0);
-    const int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_conv1x1_split), 2 * SOPER + 32 * 1024);
-    if (r != DLPM_OK) return r;
     const int64_t mt = ceil_div(M, BM);
-    k_conv1x1_split<<<(unsigned)(mt * (c.Cout / 128)), 256, lds, st>>>(c, nsamp, (c.Cout > 128 && mt % 8 == 0) ? 1 : 0);
+    const unsigned grid = (unsigned)(mt * (c.Cout / 128));
+    const int xcd_map = (c.Cout > 128 && mt % 8 == 0) ? 1 : 0;
+#define DLPM_SPLIT_LAUNCH(NW_, DIST_)                                                                              \
+    do {                                                                                                           \
+        const int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_conv1x1_split<NW_, DIST_>), 2 * SOPER + 32 * 1024); \
+        if (r != DLPM_OK) return r;                                                                                \
+        k_conv1x1_split<NW_, DIST_><<<grid, NW_ * 64, lds, st>>>(c, nsamp, xcd_map);                               \
+    } while (0)
+    // 8 waves (four per SIMD with two workgroups on a CU) measured 5 % faster than 4 waves with two register stages
+    // (profiles/r02/gemm_1x1_bf16x3_variants.txt); the 4-wave shape carries the row epilogue with the fused statistics.
+    // Both accumulate every output in the same order: which one runs does not change a bit of the result.
+    if (c.stats_out) DLPM_SPLIT_LAUNCH(4, 2);
+    else DLPM_SPLIT_LAUNCH(8, 1);
+#undef DLPM_SPLIT_LAUNCH
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }
