@@ -16,7 +16,8 @@ struct ConvLaunch {
     const float *w_wino = nullptr; // optional, 3x3 s1 only: Winograd-domain weights U = G g G^T in fragment order
                                    // (see conv_wino.hip); when the shape qualifies the F(2x2,3x3) kernel runs
     const float *w_wino4 = nullptr;// optional, 3x3 s1 only: F(4x4,3x3) Winograd-domain weights (conv_wino4.hip); preferred over w_wino
-    const void *w_split = nullptr; // optional, 1x1 only: the weights as three bf16 planes in stage-tile order (conv_split.hip)
+    const void *w_split = nullptr; // optional: the weights as three bf16 planes in stage-tile order (conv_split.hip); a 3x3 launch
+                                   // that carries it is a stride-2 downsampling convolution, or a test forcing the path
     const float *w_small = nullptr;// optional, 3x3 with Cout <= 4 (the head): [tap][Cin][4] for k_conv3x3_head
     const float *bias = nullptr;   // [Cout] or null
     const float *coefA = nullptr, *coefB = nullptr;  // [B, Cin] fused GroupNorm affine, or null
@@ -34,7 +35,7 @@ struct ConvLaunch {
     // weigh grid occupancy for a caller-declared batch (a property of the configuration, the same on every rank / chunk).
     int gen = 0;
     int64_t dispatch_B = 0;
-    int gemm = 0;                   // DLPM_GEMM_AUTO / _F32 / _BF16X3: which matrix pipe the 1x1 convolutions take (conv_split.hip)
+    int gemm = 0;                   // DLPM_GEMM_AUTO / _F32 / _BF16X3: which matrix pipe the 1x1 and downsampling convolutions take (conv_split.hip)
     // Optional fused GroupNorm statistics of the OUTPUT: per (image, pixel tile, channel) the
     // pair (mean, centred sum of squares) over the tile's pixels, written by the MFMA kernels'
     // epilogue when the tile lies inside one image.  [B][HW/tile][Cout] float2 with tile =
@@ -67,11 +68,12 @@ bool wino4_preferred(const ConvLaunch &c, int *bh, int *bw, int *nimg);   // geo
 int launch_conv_wino4(const ConvLaunch &c, hipStream_t st);
 int64_t wino4_weight_floats(int Cout, int Cin);
 int relayout_weight_wino4(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st);
-// 1x1 convolutions as an fp32 GEMM on the bf16 matrix pipe, operands split exactly into three bf16 planes (conv_split.hip)
-bool gemm_split_ok(const ConvLaunch &c);
-int launch_conv1x1_split(const ConvLaunch &c, hipStream_t st);
-int64_t split_weight_floats(int Cout, int Cin);
-int relayout_weight_split(const float *oihw_dev, void *dst_dev, int Cout, int Cin, hipStream_t st);
+// 1x1 convolutions, and 3x3 ones as an implicit GEMM, on the bf16 matrix pipe with fp32 operands split exactly into three
+// bf16 planes (conv_split.hip); taps = 1 or 9
+bool conv_split_ok(const ConvLaunch &c);
+int launch_conv_split(const ConvLaunch &c, hipStream_t st);
+int64_t split_weight_floats(int Cout, int Cin, int taps);
+int relayout_weight_split(const float *oihw_dev, void *dst_dev, int Cout, int Cin, int taps, hipStream_t st);
 // pixels behind one stats_out partial for this launch (0: the launch cannot emit statistics)
 int conv_stats_pixels(const ConvLaunch &c);
 // non-MFMA shapes: the stem kernel when it applies, the generic direct kernel otherwise

@@ -1064,6 +1064,22 @@ int launch_conv_igemm(const ConvLaunch &c, hipStream_t st) {
                  c.stride, c.ups, c.coefA ? 1 : 0);
     else
         snprintf(pname, sizeof(pname), "%s", c.ks == 3 ? (halo_ok(c, &th, &nimg) ? "conv3x3_halo" : "conv3x3_igemm") : "conv1x1_igemm");
+    if (conv_split_ok(c)) {
+        if (prof_enabled() && prof_detail())
+            snprintf(pname, sizeof(pname), "conv%dx%d_bf16x3:H%d:Cin%d+%d:Cout%d:s%d:coef%d", c.ks, c.ks, c.Hout, c.C0, c.C1, c.Cout, c.stride,
+                     c.coefA ? 1 : 0);
+        else
+            snprintf(pname, sizeof(pname), c.ks == 1 ? "conv1x1_bf16x3" : "conv3x3_bf16x3");
+        // bytes as the kernel moves them: the weights are 6 B per element here
+        ProfScope pss(pname, 2.0 * M * c.Cout * K, bytes + 2.0 * K * c.Cout, st);
+#ifdef DLPM_PHASE_TIMING
+        const_cast<ConvLaunch &>(c).phase = phase_buffer();
+#endif
+#ifdef DLPM_IGEMM_ABLATIONS
+        { const char *e = getenv("DLPM_ABL"); if (e) const_cast<ConvLaunch &>(c).abl = atoi(e); }
+#endif
+        return launch_conv_split(c, st);
+    }
     {
         int wb, ww, wi;
         if (wino4_preferred(c, &wb, &ww, &wi)) {
@@ -1082,21 +1098,6 @@ int launch_conv_igemm(const ConvLaunch &c, hipStream_t st) {
             ProfScope psw(pname, 2.0 * M * c.Cout * K, bytes, st);   // ALGORITHMIC flops (direct-conv count)
             return launch_conv_wino(c, st);
         }
-    }
-    if (gemm_split_ok(c)) {
-        if (prof_enabled() && prof_detail())
-            snprintf(pname, sizeof(pname), "conv1x1_bf16x3:H%d:Cin%d+%d:Cout%d:coef%d", c.Hout, c.C0, c.C1, c.Cout, c.coefA ? 1 : 0);
-        else
-            snprintf(pname, sizeof(pname), "conv1x1_bf16x3");
-        // bytes as the kernel moves them: the weights are 6 B per element here
-        ProfScope pss(pname, 2.0 * M * c.Cout * K, bytes + 2.0 * K * c.Cout, st);
-#ifdef DLPM_PHASE_TIMING
-        const_cast<ConvLaunch &>(c).phase = phase_buffer();
-#endif
-#ifdef DLPM_IGEMM_ABLATIONS
-        { const char *e = getenv("DLPM_ABL"); if (e) const_cast<ConvLaunch &>(c).abl = atoi(e); }
-#endif
-        return launch_conv1x1_split(c, st);
     }
     ProfScope ps(pname, 2.0 * M * c.Cout * K, bytes, st);
 #ifdef DLPM_IGEMM_ABLATIONS   // developer builds only (DLPM_BUILD_DEFS): timing ablations, results are WRONG when set

@@ -58,18 +58,20 @@ __device__ __forceinline__ void split2(float lo, float hi, uint32_t &p0, uint32_
     p2 = __builtin_amdgcn_perm(__float_as_uint(sh), __float_as_uint(sl), 0x07060302u);
 }
 
-// OIHW (1x1: [Cout][Cin]) -> [Cout/128][Cin/32][plane 3][k-step 2][k-half 2][row 128][8 bf16]
-__global__ void k_relayout_weight_split(const float *w, uint4 *dst, int Cout, int Cin) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (n, group of 8 k)
+// OIHW ([Cout][Cin][taps]) -> [tap][Cout/128][Cin/32][plane 3][k-step 2][k-half 2][row 128][8 bf16]
+__global__ void k_relayout_weight_split(const float *w, uint4 *dst, int Cout, int Cin, int taps) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (tap, n, group of 8 k)
     const int kg = Cin / 8;
-    if (i >= (int64_t)Cout * kg) return;
-    const int n = (int)(i / kg), g = (int)(i - (int64_t)n * kg);
-    const float *src = w + (int64_t)n * Cin + g * 8;
+    if (i >= (int64_t)taps * Cout * kg) return;
+    const int tap = (int)(i / ((int64_t)Cout * kg));
+    const int64_t j = i - (int64_t)tap * Cout * kg;
+    const int n = (int)(j / kg), g = (int)(j - (int64_t)n * kg);
+    const float *src = w + ((int64_t)n * Cin + g * 8) * taps + tap;
     uint32_t P[3][4];
 #pragma unroll
-    for (int e = 0; e < 4; e++) split2(src[2 * e], src[2 * e + 1], P[0][e], P[1][e], P[2][e]);
+    for (int e = 0; e < 4; e++) split2(src[(2 * e) * taps], src[(2 * e + 1) * taps], P[0][e], P[1][e], P[2][e]);
     const int nt = n >> 7, row = n & 127, kc = g >> 2, q = g & 3;   // q = k-step * 2 + k-half
-    uint4 *tile = dst + ((int64_t)nt * (Cin / SKC) + kc) * SCHUNKS;
+    uint4 *tile = dst + (((int64_t)tap * (Cout >> 7) + nt) * (Cin / SKC) + kc) * SCHUNKS;
 #pragma unroll
     for (int pl = 0; pl < 3; pl++) tile[pl * (SPLANE / 16) + q * 128 + row] = make_uint4(P[pl][0], P[pl][1], P[pl][2], P[pl][3]);
 }
@@ -79,7 +81,7 @@ __global__ void k_relayout_weight_split(const float *w, uint4 *dst, int Cout, in
 // 128-byte lines.  No LDS, no barrier, every wave busy; the residual's loads are issued before the first add.
 // MASKED: the tile's last rows lie beyond M (ragged last tile).
 template <bool MASKED, int RN>
-__device__ __forceinline__ void store_from_registers(const ConvLaunch &p, floatx16 (&acc)[2][RN], int64_t m0, int nw0, int wm,
+__device__ __forceinline__ void split_store_from_registers(const ConvLaunch &p, floatx16 (&acc)[2][RN], int64_t m0, int nw0, int wm,
                                                      int l31, int kh, int mrem) {
     const int R1 = p.Cout - p.R0;
     const int rlim = mrem - 1 - (wm * 64 + 4 * kh);   // last valid row, counted from this lane's first row
@@ -117,9 +119,10 @@ __device__ __forceinline__ void store_from_registers(const ConvLaunch &p, floatx
 
 // NW waves: 4 = 2 x 2 waves of 64 x 64 (2 workgroups per CU); 8 = 2 x 4 waves of 64 x 32 (2 workgroups = 4 waves per SIMD).
 // (Also measured: 8 waves with two register stages -- 138 registers, one workgroup per CU -- 19 % slower.)
-// DIST: stages of operands waiting in registers.
-template <int NW, int DIST>
-__global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv1x1_split(ConvLaunch p, int nsamp, int xcd_map) {
+// DIST: stages of operands waiting in registers.  TAPS: 1 = 1x1 convolution, 9 = 3x3 (padding 1, stride 1 or 2) as an implicit
+// GEMM over K = 9 Cin (channel chunk outer, tap inner: the taps of a chunk re-read the same input lines from L2).
+template <int NW, int DIST, int TAPS>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split(ConvLaunch p, int nsamp, int xcd_map) {
     constexpr int NT = NW * 64, RN = NW == 4 ? 2 : 1, WN = 4 / RN;   // threads, MFMA column tiles per wave, waves across N
     constexpr int RSTEP = NT / 8, NV = 128 / RSTEP, NWV = SCHUNKS / NT;   // staging: rows per pass, passes, weight chunks per thread
     // [A stage 24 KB][B stage 24 KB] (the statistics epilogue's row image afterwards) [GroupNorm coefficients of the tile's samples]
@@ -159,26 +162,53 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv1x1_sp
     // for the rows beyond M and never stores them: the kernel a layer takes must not depend on the batch
     const int64_t M = (int64_t)p.B * HWo;
     const int mrem = (int)min((int64_t)BM, M - m0);
-    const float *a0 = p.src0 + m0 * p.C0 + 4 * q;
-    const float *a1 = p.src1 ? p.src1 + m0 * p.C1 + 4 * q - p.C0 : a0;
-    int rcl[NV];
+    const float *a0 = p.src0 + (TAPS == 1 ? m0 * p.C0 : 0) + 4 * q;
+    const float *a1 = p.src1 ? p.src1 + (TAPS == 1 ? m0 * p.C1 : 0) + 4 * q - p.C0 : a0;
+    int rcl[NV];        // TAPS 1: row of the tile (clamped);  TAPS 9: first input pixel of the sample
+    int iy0[NV], ix0[NV];
 #pragma unroll
-    for (int v = 0; v < NV; v++) rcl[v] = min(rb + RSTEP * v, mrem - 1);
-    const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(p.w_split) + (int64_t)nt * (Cin / SKC) * SCHUNKS + tid;
+    for (int v = 0; v < NV; v++) {
+        rcl[v] = min(rb + RSTEP * v, mrem - 1);
+        if (TAPS > 1) {
+            const int64_t m = m0 + rcl[v];
+            const int b = (int)(m / HWo), rem = (int)(m - (int64_t)b * HWo);
+            const int oy = rem / p.Wout;
+            iy0[v] = oy * p.stride - 1;
+            ix0[v] = (rem - oy * p.Wout) * p.stride - 1;
+            rcl[v] = b * p.Hin * p.Win;
+        }
+    }
+    const int nkc = Cin / SKC;
+    const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(p.w_split) + (int64_t)nt * nkc * SCHUNKS + tid;
     const bool has_coef = p.coefA != nullptr;
 
-    auto load_step = [&](float4 (&xa)[NV], u32x4 (&wb)[NWV], int s) {
-        const int c0 = s * SKC;
+    // stage s = (channel chunk kc, tap); `ok` collects which of this thread's rows read inside the image (zero padding)
+    auto load_step = [&](float4 (&xa)[NV], u32x4 (&wb)[NWV], int &ok, int s) {
+        const int kc = TAPS == 1 ? s : s / TAPS, tap = TAPS == 1 ? 0 : s - kc * TAPS;
+        const int c0 = kc * SKC;
         const bool first = c0 < p.C0;             // uniform: C0 % 32 == 0
         const float *src = first ? a0 + c0 : a1 + c0;
         const int rs = first ? p.C0 : p.C1;
         if (!(SABL(2) && s >= 2)) {
+            if (TAPS == 1) {
 #pragma unroll
-            for (int v = 0; v < NV; v++) xa[v] = *reinterpret_cast<const float4 *>(src + rcl[v] * rs);
+                for (int v = 0; v < NV; v++) xa[v] = *reinterpret_cast<const float4 *>(src + rcl[v] * rs);
+            } else {
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                ok = 0;
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    const int iy = iy0[v] + ky, ix = ix0[v] + kx;
+                    if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) ok |= 1 << v;
+                    const int pix = rcl[v] + min(max(iy, 0), p.Hin - 1) * p.Win + min(max(ix, 0), p.Win - 1);
+                    xa[v] = *reinterpret_cast<const float4 *>(src + (int64_t)pix * rs);   // unconditional: a load in a branch drains the queue
+                }
+            }
         }
         if (!(SABL(4) && s >= 2)) {
+            const u32x4 *ws = wsrc + ((int64_t)tap * ntile_n * nkc + kc) * SCHUNKS;
 #pragma unroll
-            for (int v = 0; v < NWV; v++) wb[v] = wsrc[(int64_t)s * SCHUNKS + v * NT];
+            for (int v = 0; v < NWV; v++) wb[v] = ws[v * NT];
         }
     };
     // LDS chunk (16 B = 8 channels of one row of one plane) of (ksh, row): ksh * 128 + (row ^ 8 ksh) -- the XOR spreads the
@@ -190,14 +220,15 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv1x1_sp
 #pragma unroll
     for (int v = 0; v < NV; v++) cfo[v] = (nsamp > 1 ? (rb + RSTEP * v) / HWo : 0) * Cin + 4 * q;
     const int wofs = (ksh * 128 + (rb ^ (ksh * 8))) * 2 + (q & 1);
-    auto store_step = [&](float4 (&xa)[NV], u32x4 (&wb)[NWV], int s) {
+    auto store_step = [&](float4 (&xa)[NV], u32x4 (&wb)[NWV], int ok, int s) {
+        const int c0 = (TAPS == 1 ? s : s / TAPS) * SKC;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
             if (SABL(16) && s >= 2) break;
             float4 x = xa[v];
             if (has_coef) {
-                const float4 ca = *reinterpret_cast<const float4 *>(cf + cfo[v] + s * SKC);
-                const float4 cb = *reinterpret_cast<const float4 *>(cf + nsamp * Cin + cfo[v] + s * SKC);
+                const float4 ca = *reinterpret_cast<const float4 *>(cf + cfo[v] + c0);
+                const float4 cb = *reinterpret_cast<const float4 *>(cf + nsamp * Cin + cfo[v] + c0);
                 x.x = fmaf(x.x, ca.x, cb.x);
                 x.y = fmaf(x.y, ca.y, cb.y);
                 x.z = fmaf(x.z, ca.z, cb.z);
@@ -209,6 +240,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv1x1_sp
                 x.z = silu_f(x.z);
                 x.w = silu_f(x.w);
             }
+            if (TAPS > 1 && !(ok >> v & 1)) x = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding of the ACTIVATED tensor
             uint32_t P[3][2];
             if (SPLIT_ABL & 2) {
                 for (int pl = 0; pl < 3; pl++) { P[pl][0] = __float_as_uint(x.x + x.y); P[pl][1] = __float_as_uint(x.z + x.w); }
@@ -264,7 +296,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv1x1_sp
         }
     };
 
-    const int nsteps = Cin / SKC;
+    const int nsteps = nkc * TAPS;
+    int ok0 = 0, ok1 = 0;
     float4 xa0[NV], xa1[NV];
     u32x4 wb0[NWV], wb1[NWV];
     // GroupNorm coefficients of the tile's samples -> LDS [A | B][nsamp][Cin] (read by every stage).  Their loads go out
@@ -282,8 +315,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv1x1_sp
             cq[1][r] = reinterpret_cast<const f32x4 *>(p.coefB + pb0 * Cin)[i];
         }
     }
-    load_step(xa0, wb0, 0);
-    if (DIST == 2 && nsteps > 1) load_step(xa1, wb1, 1);
+    load_step(xa0, wb0, ok0, 0);
+    if (DIST == 2 && nsteps > 1) load_step(xa1, wb1, ok1, 1);
     if (has_coef) {
         f32x4 *dst = reinterpret_cast<f32x4 *>(smem + 2 * SOPER);
 #pragma unroll
@@ -302,21 +335,21 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv1x1_sp
     if constexpr (DIST == 2) {
         // two register sets: the loads of stage s + 2 are issued as soon as stage s has left its registers
         for (int s = 0; s < nsteps; s += 2) {
-            store_step(xa0, wb0, s);
+            store_step(xa0, wb0, ok0, s);
             SPLIT_LP(0);   // developer counters 4..7: stage (incl. the wait for its loads) / barrier / MFMAs / barrier
             __syncthreads();
             SPLIT_LP(1);
-            if (s + 2 < nsteps && !(SPLIT_ABL & 1)) load_step(xa0, wb0, s + 2);
+            if (s + 2 < nsteps && !(SPLIT_ABL & 1)) load_step(xa0, wb0, ok0, s + 2);
             mfma_step();
             SPLIT_LP(2);
             __syncthreads();   // the stage is dead: the next store_step may overwrite it
             SPLIT_LP(3);
             if (s + 1 < nsteps) {
-                store_step(xa1, wb1, s + 1);
+                store_step(xa1, wb1, ok1, s + 1);
                 SPLIT_LP(0);
                 __syncthreads();
                 SPLIT_LP(1);
-                if (s + 3 < nsteps && !(SPLIT_ABL & 1)) load_step(xa1, wb1, s + 3);
+                if (s + 3 < nsteps && !(SPLIT_ABL & 1)) load_step(xa1, wb1, ok1, s + 3);
                 mfma_step();
                 SPLIT_LP(2);
                 __syncthreads();
@@ -325,11 +358,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv1x1_sp
         }
     } else {
         for (int s = 0; s < nsteps; s++) {
-            store_step(xa0, wb0, s);
+            store_step(xa0, wb0, ok0, s);
             SPLIT_LP(0);
             __syncthreads();
             SPLIT_LP(1);
-            if (s + 1 < nsteps && !(SPLIT_ABL & 1)) load_step(xa0, wb0, s + 1);   // in flight under the MFMAs below
+            if (s + 1 < nsteps && !(SPLIT_ABL & 1)) load_step(xa0, wb0, ok0, s + 1);   // in flight under the MFMAs below
             mfma_step();
             SPLIT_LP(2);
             __syncthreads();
@@ -343,8 +376,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv1x1_sp
             return;
         }
     }
-    if (mrem == BM) store_from_registers<false, RN>(p, acc, m0, n0 + wn * (RN * 32), wm, l31, kh, BM);
-    else store_from_registers<true, RN>(p, acc, m0, n0 + wn * (RN * 32), wm, l31, kh, mrem);
+    if (mrem == BM) split_store_from_registers<false, RN>(p, acc, m0, n0 + wn * (RN * 32), wm, l31, kh, BM);
+    else split_store_from_registers<true, RN>(p, acc, m0, n0 + wn * (RN * 32), wm, l31, kh, mrem);
     DLPM_PHASE(p, 2);
 #ifdef DLPM_PHASE_TIMING
     if (p.phase && tid == 0) {
@@ -356,28 +389,30 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv1x1_sp
 
 }  // namespace
 
-int64_t split_weight_floats(int Cout, int Cin) { return ((int64_t)Cout * Cin * 6 + 3) / 4; }   // 3 bf16 planes
+int64_t split_weight_floats(int Cout, int Cin, int taps) { return ((int64_t)taps * Cout * Cin * 6 + 3) / 4; }   // 3 bf16 planes
 
-int relayout_weight_split(const float *oihw_dev, void *dst_dev, int Cout, int Cin, hipStream_t st) {
-    if (Cout % 128 != 0 || Cin % SKC != 0) {
-        set_error("relayout_weight_split: Cout %d %% 128 or Cin %d %% 32", Cout, Cin);
+int relayout_weight_split(const float *oihw_dev, void *dst_dev, int Cout, int Cin, int taps, hipStream_t st) {
+    if (Cout % 128 != 0 || Cin % SKC != 0 || (taps != 1 && taps != 9)) {
+        set_error("relayout_weight_split: Cout %d %% 128, Cin %d %% 32 or %d taps", Cout, Cin, taps);
         return DLPM_ERR_UNSUPPORTED;
     }
-    const int64_t n = (int64_t)Cout * (Cin / 8);
-    k_relayout_weight_split<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, reinterpret_cast<uint4 *>(dst_dev), Cout, Cin);
+    const int64_t n = (int64_t)taps * Cout * (Cin / 8);
+    k_relayout_weight_split<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, reinterpret_cast<uint4 *>(dst_dev), Cout, Cin, taps);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }
 
-// The shapes k_conv_igemm's MODE 2 covers, at the 128-channel tile: 1x1 / stride 1 / NHWC, full tiles.
-bool gemm_split_ok(const ConvLaunch &c) {
+// 1x1 / stride 1 and 3x3 / padding 1 / stride 1 or 2 over NHWC, 128-channel tiles.  Nothing here looks at the batch.
+bool conv_split_ok(const ConvLaunch &c) {
     const int HW = c.Hout * c.Wout;
-    return c.w_split && c.gemm != DLPM_GEMM_F32 && c.ks == 1 && c.stride == 1 && !c.ups && !c.in_nchw && !c.out_nchw &&
-           c.Cout % 128 == 0 && c.C0 % SKC == 0 && (c.C0 + c.C1) % SKC == 0 && (c.R0 & 31) == 0 &&
+    if (!c.w_split || c.gemm == DLPM_GEMM_F32 || c.ups || c.in_nchw || c.out_nchw) return false;
+    if (c.ks == 1 ? c.stride != 1 : (c.ks != 3 || (c.stride != 1 && c.stride != 2))) return false;
+    if (c.Hout != (c.Hin - 1) / c.stride + 1 || c.Wout != (c.Win - 1) / c.stride + 1) return false;
+    return c.Cout % 128 == 0 && c.C0 % SKC == 0 && (c.C0 + c.C1) % SKC == 0 && (c.R0 & 31) == 0 &&
            (HW >= BM ? HW % BM == 0 : (BM % HW == 0 && (!c.coefA || (BM / HW) * (c.C0 + c.C1) * 8 <= 32 * 1024)));   // tiles hold whole samples
 }
 
-int launch_conv1x1_split(const ConvLaunch &c, hipStream_t st) {
+int launch_conv_split(const ConvLaunch &c, hipStream_t st) {
     const int64_t M = (int64_t)c.B * c.Hout * c.Wout;
     static_assert(2 * SOPER >= 64 * 132 * 4, "epilogue image must fit the stage buffers");
     const int HW = c.Hout * c.Wout;
@@ -386,17 +421,22 @@ int launch_conv1x1_split(const ConvLaunch &c, hipStream_t st) {
     const int64_t mt = ceil_div(M, BM);
     const unsigned grid = (unsigned)(mt * (c.Cout / 128));
     const int xcd_map = (c.Cout > 128 && mt % 8 == 0) ? 1 : 0;
-#define DLPM_SPLIT_LAUNCH(NW_, DIST_)                                                                              \
-    do {                                                                                                           \
-        const int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_conv1x1_split<NW_, DIST_>), 2 * SOPER + 32 * 1024); \
-        if (r != DLPM_OK) return r;                                                                                \
-        k_conv1x1_split<NW_, DIST_><<<grid, NW_ * 64, lds, st>>>(c, nsamp, xcd_map);                               \
+#define DLPM_SPLIT_LAUNCH(NW_, DIST_, TAPS_)                                                                              \
+    do {                                                                                                                  \
+        const int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_conv_split<NW_, DIST_, TAPS_>), 2 * SOPER + 32 * 1024); \
+        if (r != DLPM_OK) return r;                                                                                       \
+        k_conv_split<NW_, DIST_, TAPS_><<<grid, NW_ * 64, lds, st>>>(c, nsamp, xcd_map);                                  \
     } while (0)
     // 8 waves (four per SIMD with two workgroups on a CU) measured 5 % faster than 4 waves with two register stages
     // (profiles/r02/gemm_1x1_bf16x3_variants.txt); the 4-wave shape carries the row epilogue with the fused statistics.
     // Both accumulate every output in the same order: which one runs does not change a bit of the result.
-    if (c.stats_out) DLPM_SPLIT_LAUNCH(4, 2);
-    else DLPM_SPLIT_LAUNCH(8, 1);
+    if (c.ks == 1) {
+        if (c.stats_out) DLPM_SPLIT_LAUNCH(4, 2, 1);
+        else DLPM_SPLIT_LAUNCH(8, 1, 1);
+    } else {
+        if (c.stats_out) DLPM_SPLIT_LAUNCH(4, 2, 9);
+        else DLPM_SPLIT_LAUNCH(8, 1, 9);
+    }
 #undef DLPM_SPLIT_LAUNCH
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;

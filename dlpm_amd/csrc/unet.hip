@@ -308,7 +308,7 @@ bool ws_gemm_enabled() {   // DLPM_WS1X1=1: route the UNet's 1x1 convolutions th
     return v == 1;
 }
 
-int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 none, 1 NCHW input (stem), 2 NCHW output (head), 3 time MLP
+int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 none, 1 NCHW input (stem), 2 NCHW output (head), 3 time MLP, 4 stride-2 downsampling
     ConvLaunch probe;
     probe.C0 = C0; probe.C1 = c.cin - C0; probe.Cout = c.cout; probe.ks = c.ks;
     probe.in_nchw = boundary == 1; probe.out_nchw = boundary == 2;
@@ -317,8 +317,8 @@ int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 no
     if (c.use_igemm && c.ks == 1) {  // [O][I] row-major is already the igemm layout
         c.w_dev = const_cast<float *>(src);
         if (c.cout % 128 == 0 && c.cin % 32 == 0 && boundary == 0) {
-            DLPM_HIP(hipMalloc(&c.w_split, (size_t)split_weight_floats(c.cout, c.cin) * sizeof(float)));
-            int r = relayout_weight_split(src, c.w_split, c.cout, c.cin, nullptr);
+            DLPM_HIP(hipMalloc(&c.w_split, (size_t)split_weight_floats(c.cout, c.cin, 1) * sizeof(float)));
+            int r = relayout_weight_split(src, c.w_split, c.cout, c.cin, 1, nullptr);
             if (r != DLPM_OK) return r;
         }
         if (ws_gemm_enabled() && c.cin % 32 == 0 && boundary == 0) {   // fragment order for the weight-streaming GEMM (TAPS = 1)
@@ -332,6 +332,11 @@ int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 no
     if (c.ks == 3 && c.cout <= 4 && c.cin % 32 == 0) {
         DLPM_HIP(hipMalloc(&c.w_small, (size_t)9 * c.cin * 4 * sizeof(float)));
         int r = relayout_weight_head(src, c.w_small, c.cout, c.cin, nullptr);
+        if (r != DLPM_OK) return r;
+    }
+    if (c.use_igemm && c.ks == 3 && boundary == 4 && c.cout % 128 == 0 && c.cin % 32 == 0) {   // stride-2 downsampling convolution
+        DLPM_HIP(hipMalloc(&c.w_split, (size_t)split_weight_floats(c.cout, c.cin, 9) * sizeof(float)));
+        int r = relayout_weight_split(src, c.w_split, c.cout, c.cin, 9, nullptr);
         if (r != DLPM_OK) return r;
     }
     if (c.use_igemm && c.ks == 3 && c.cin % 32 == 0) {
@@ -703,7 +708,7 @@ extern "C" int dlpm_unet_finalize(dlpm_unet *u) {
             Layer &L = s[i];
             const bool cat = (i == 0 && L.kind == L_RES && C0_first > 0);
             const int C0 = cat ? C0_first : L.c1.cin;
-            TRY(prep_conv(u, L.c1, L.kind == L_STEM ? L.c1.cin : C0, L.kind == L_STEM ? 1 : 0));
+            TRY(prep_conv(u, L.c1, L.kind == L_STEM ? L.c1.cin : C0, L.kind == L_STEM ? 1 : L.kind == L_DOWN ? 4 : 0));
             if (L.kind == L_RES || L.kind == L_ATTN) TRY(prep_conv(u, L.c2, L.c2.cin, 0));
             if (L.kind == L_RES && L.has_skip) TRY(prep_conv(u, L.skip, cat ? C0_first : L.skip.cin, 0));
         }
@@ -905,14 +910,15 @@ extern "C" int dlpm_conv2d_f32(const dlpm_conv_args *a, float *scratch_dev, dlpm
         L.ws_gemm = 1;
     }
     L.gemm = DLPM_GEMM_F32;
-    if (ig && a->ksize == 1 && (a->force_direct & 16) && a->Cout % 128 == 0 && (a->C0 + a->C1) % 32 == 0 &&
-        a->scratch_floats >= (int64_t)a->Cout * (a->C0 + a->C1) + split_weight_floats(a->Cout, a->C0 + a->C1)) {
-        float *wsp = scratch_dev + (int64_t)a->Cout * (a->C0 + a->C1);
-        TRY(relayout_weight_split(a->weight, wsp, a->Cout, a->C0 + a->C1, st));
+    const int taps = a->ksize * a->ksize;
+    if (ig && (a->force_direct & 16) && a->Cout % 128 == 0 && (a->C0 + a->C1) % 32 == 0 &&
+        a->scratch_floats >= (int64_t)a->Cout * (a->C0 + a->C1) * taps + split_weight_floats(a->Cout, a->C0 + a->C1, taps)) {
+        float *wsp = scratch_dev + (int64_t)a->Cout * (a->C0 + a->C1) * taps;
+        TRY(relayout_weight_split(a->weight, wsp, a->Cout, a->C0 + a->C1, taps, st));
         L.w_split = wsp;
         L.gemm = DLPM_GEMM_BF16X3;
     }
-    if (ig && a->ksize == 3 && (a->C0 + a->C1) % 32 == 0 &&
+    if (ig && a->ksize == 3 && !L.w_split && (a->C0 + a->C1) % 32 == 0 &&   // (the split copy sits where these would go)
         a->scratch_floats >= (int64_t)a->Cout * (a->C0 + a->C1) * 9 + frag_weight_floats(a->Cout, a->C0 + a->C1)) {
         float *wf = scratch_dev + (int64_t)a->Cout * (a->C0 + a->C1) * 9;
         TRY(relayout_weight_frag(a->weight, wf, a->Cout, a->C0 + a->C1, st));

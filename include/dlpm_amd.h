@@ -299,7 +299,7 @@ int64_t dlpm_unet_flops_per_sample(const dlpm_unet *net);   /* 2*MAC, conv/linea
  * May be called any time after dlpm_unet_finalize; samplers re-capture their graph on the next step. */
 enum dlpm_conv_generation { DLPM_CONV_AUTO = 0, DLPM_CONV_F4 = 1, DLPM_CONV_F2 = 2, DLPM_CONV_IGEMM = 3 };
 int dlpm_unet_set_conv_policy(dlpm_unet *net, int32_t generation, int64_t dispatch_batch);
-/* Which matrix pipe the 1x1 convolutions (qkv, proj, skip connections) run on.  DLPM_GEMM_BF16X3: every fp32 operand is
+/* Which matrix pipe the 1x1 convolutions (qkv, proj, skip connections) and the stride-2 downsampling convolutions run on.  DLPM_GEMM_BF16X3: every fp32 operand is
  * cut exactly into three bf16 planes and a product is formed from the six partial products above 2^-16 of it, accumulated
  * in fp32 (v_mfma_f32_32x32x16_bf16) -- fp32-grade results (measured against float64 beside the fp32 MFMA in the tests)
  * at 6/16 of the fp32 pipe's cost.  DLPM_GEMM_F32: v_mfma_f32_32x32x2_f32 everywhere.  DLPM_GEMM_AUTO = BF16X3 where the
@@ -351,7 +351,8 @@ typedef struct dlpm_conv_args {
     int32_t force_direct;       /* bit 0: use the direct (non-MFMA) kernel regardless of shape; bit 1: no Winograd;
                                    bit 2: 1x1 through the weight-streaming kernel; bit 3: 3x3 through the
                                    Winograd F(4x4,3x3) kernel where the shape qualifies (needs scratch for it);
-                                   bit 4: 1x1 through the bf16-split GEMM where the shape qualifies (scratch: + 1.5x weight) */
+                                   bit 4: 1x1, or 3x3 as an implicit GEMM, through the bf16-split kernel where the shape
+                                   qualifies (scratch: + 1.5x weight) */
     int64_t scratch_floats;     /* size of scratch_dev in floats; room for a second, fragment-ordered copy of a
                                    3x3 weight (+1 KB per 32 output channels) enables the weight-streaming kernel */
 } dlpm_conv_args;

@@ -684,3 +684,47 @@ def test_conv1x1_bf16_split_gemm_is_fp32_grade(case):
     assert e16 <= 1.5 * e32 + 1.2e-7 * mag, name
     assert e16 < 3e-7 * math.sqrt(Cin) * mag, name
     assert not torch.equal(got16, got32) or e16 == 0.0   # the split kernel really ran (different rounding order)
+
+
+SPLIT3_CASES = [
+    # name, B, C0, C1, H, Cout, stride, coef+silu, res
+    ('down_16_to_8', 3, 128, 0, 16, 128, 2, False, False),
+    ('down_8_to_4_256', 2, 256, 0, 8, 256, 2, False, False),
+    ('down_32_to_16_stats_tile', 1, 128, 0, 32, 128, 2, False, False),      # 256 output pixels per image: whole 128-pixel tiles
+    ('s1_4x4_gn_silu_res', 5, 128, 0, 4, 128, 1, True, True),               # ragged: 80 output pixels
+    ('s1_8x8_concat', 2, 128, 64, 8, 256, 1, True, False),
+    ('down_odd_input_7_to_4', 2, 64, 0, 7, 128, 2, False, False),
+]
+
+
+@pytest.mark.parametrize('case', SPLIT3_CASES, ids=[c[0] for c in SPLIT3_CASES])
+def test_conv3x3_bf16_split_implicit_gemm(case):
+    """The 3x3 (padding 1, stride 1 / 2) form of conv_split.hip -- what the UNet's stride-2 downsampling convolutions take
+    (unet.py:96, Downsample.op): judged against float64 beside the fp32 implicit-GEMM kernel, like the 1x1 form."""
+    name, B, C0, C1, H, Cout, stride, act, use_res = case
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    Cin = C0 + C1
+    x0 = torch.randn(B, C0, H, H, generator=g)
+    x1 = torch.randn(B, C1, H, H, generator=g) if C1 else None
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    bias = torch.randn(Cout, generator=g)
+    coef = (1 + 0.3 * torch.randn(B, Cin, generator=g), 0.3 * torch.randn(B, Cin, generator=g)) if act else None
+    Ho = (H - 1) // stride + 1
+    res = torch.randn(B, Cout, Ho, Ho, generator=g) if use_res else None
+    want = ref_conv(x0, w, bias, x1, stride, 0, coef, act, res).double()
+    x = x0 if x1 is None else torch.cat([x0, x1], 1)
+    if coef is not None:
+        x = x * coef[0][:, :, None, None] + coef[1][:, :, None, None]
+    if act:
+        x = nets.silu(x)
+    want = F.conv2d(x.double(), w.double(), bias.double(), stride=stride, padding=1)
+    if res is not None:
+        want = want + res.double()
+    mag = F.conv2d(x.double().abs(), w.double().abs(), stride=stride, padding=1).max().item()
+    got32 = run_conv(x0, w, bias, x1, stride, 0, coef, act, res, force_direct=2).double()
+    got16 = run_conv(x0, w, bias, x1, stride, 0, coef, act, res, force_direct=16).double()
+    e32, e16 = (got32 - want).abs().max().item(), (got16 - want).abs().max().item()
+    print('%s: fp32 implicit GEMM err %.2e, bf16x3 err %.2e (sum|a||b| max %.1f)' % (name, e32, e16, mag))
+    assert e16 <= 1.5 * e32 + 1.2e-7 * mag, name
+    assert e16 < conv_tol(w, Cin), name
+    assert not torch.equal(got16, got32)

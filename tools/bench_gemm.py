@@ -17,8 +17,11 @@ from dlpm_amd import _lib
 
 L = _lib.lib()
 DEV = 'cuda'
-# name, launches per step, B, C0, C1, H, Cout, coef (GroupNorm affine, no SiLU: the qkv input), res
+# name, launches per step, B, C0, C1, H (input), Cout, coef (GroupNorm affine, no SiLU: the qkv input), res[, ksize, stride]
 SHAPES = [
+    ('3x3 s2 H32->16 128->128', 1, 1024, 128, 0, 32, 128, False, False, 3, 2),
+    ('3x3 s2 H16->8 256->256', 1, 1024, 256, 0, 16, 256, False, False, 3, 2),
+    ('3x3 s2 H8->4 256->256', 1, 1024, 256, 0, 8, 256, False, False, 3, 2),
     ('H8  256->768 gn (qkv)', 5, 1024, 256, 0, 8, 768, True, False),
     ('H32 128+128->128 skip', 2, 1024, 128, 128, 32, 128, False, False),
     ('H16 256+256->256 skip', 2, 1024, 256, 256, 16, 256, False, False),
@@ -33,19 +36,20 @@ SHAPES = [
 ]
 
 
-def run(name, n, B, C0, C1, H, Cout, coef, res, reps):
+def run(name, n, B, C0, C1, H, Cout, coef, res, ks=1, stride=1, reps=10):
     Cin = C0 + C1
+    Ho = (H - 1) // stride + 1
     g = torch.Generator(device=DEV).manual_seed(1)
     x0 = torch.randn(B, H, H, C0, device=DEV, generator=g)
     x1 = torch.randn(B, H, H, C1, device=DEV, generator=g) if C1 else None
-    w = torch.randn(Cout, Cin, 1, 1, device=DEV, generator=g) / Cin ** 0.5
+    w = torch.randn(Cout, Cin, ks, ks, device=DEV, generator=g) / (Cin * ks * ks) ** 0.5
     bias = torch.randn(Cout, device=DEV, generator=g)
     a = _lib.ConvArgs()
     a.src0, a.C0 = x0.data_ptr(), C0
     if C1:
         a.src1, a.C1 = x1.data_ptr(), C1
-    a.B, a.Hin, a.Win, a.Hout, a.Wout = B, H, H, H, H
-    a.ksize, a.stride, a.upsample = 1, 1, 0
+    a.B, a.Hin, a.Win, a.Hout, a.Wout = B, H, H, Ho, Ho
+    a.ksize, a.stride, a.upsample = ks, stride, 0
     a.weight, a.bias = w.data_ptr(), bias.data_ptr()
     keep = []
     cA = cB = r = None
@@ -54,10 +58,10 @@ def run(name, n, B, C0, C1, H, Cout, coef, res, reps):
         cB = torch.randn(B, Cin, device=DEV, generator=g) * 0.1
         a.coefA, a.coefB = cA.data_ptr(), cB.data_ptr()
     if res:
-        r = torch.randn(B, H, H, Cout, device=DEV, generator=g)
+        r = torch.randn(B, Ho, Ho, Cout, device=DEV, generator=g)
         a.res0, a.R0 = r.data_ptr(), Cout
     a.Cout = Cout
-    scratch = torch.empty(4 * w.numel() + 64 * 1024, device=DEV)
+    scratch = torch.empty(14 * w.numel() + 64 * 1024 * (1 + Cout // 32), device=DEV)
     a.scratch_floats = scratch.numel()
     st = _lib.stream_ptr()
     # float64 reference on the first 4096 rows
@@ -66,12 +70,18 @@ def run(name, n, B, C0, C1, H, Cout, coef, res, reps):
     if coef:   # fmaf(x, A, B) in fp32, as both kernels stage it: the float64 expression rounded once
         bidx = torch.arange(rows, device=DEV) // (H * H)
         xin = (xin.double() * cA[bidx].double() + cB[bidx].double()).float()
-    want = xin.double() @ w.reshape(Cout, Cin).double().t() + bias.double()
-    if res:
-        want = want + r.reshape(-1, Cout)[:rows].double()
+    if ks == 1:
+        want = xin.double() @ w.reshape(Cout, Cin).double().t() + bias.double()
+        if res:
+            want = want + r.reshape(-1, Cout)[:rows].double()
+    else:   # the first samples through float64 conv2d
+        nb = max(1, rows // (Ho * Ho))
+        rows = nb * Ho * Ho
+        want = torch.nn.functional.conv2d(x0[:nb].permute(0, 3, 1, 2).double(), w.double(), bias.double(), stride=stride, padding=1)
+        want = want.permute(0, 2, 3, 1).reshape(rows, Cout)
     out = {}
-    for mode, bit in (('f32', 0), ('bf16x3', 16)):
-        o = torch.empty(B, H, H, Cout, device=DEV)
+    for mode, bit in (('f32', 2 if ks == 3 else 0), ('bf16x3', 16)):
+        o = torch.empty(B, Ho, Ho, Cout, device=DEV)
         a.out = o.data_ptr()
         a.force_direct = bit
         _lib.check(L.dlpm_conv2d_f32(C.byref(a), scratch.data_ptr(), st))
