@@ -47,6 +47,7 @@ METRIC = {
     'celeba64': 'samples/sec at T=1000 (CelebA 64x64, alpha=1.8) [builder-defined net, not the headline]',
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 (the guide's figure; tools/mb/mfma_bf16.hip measures 2.3-2.5 PFLOP/s in a bare loop)
 PEAK_HBM_GBS = 8000.0
 # HBM traffic of the dominant kernel comes from rocprofv3 PMC passes (separate --pmc runs, FETCH_SIZE doubled per the
 # gfx950 guide), which cannot run inside this process.  tools/pmc_summarize.py --json writes profiles/pmc_traffic.json
@@ -147,6 +148,7 @@ class NativeRunner:
         # the per-GPU batch of the BASELINE configuration is a declared property of the workload (the same on every rank and
         # for every chunk), so the dispatch policy may weigh grid occupancy for it (dlpm_unet_set_conv_policy)
         self.net.set_conv_policy(args.conv, args.dispatch_batch if args.dispatch_batch >= 0 else WORKLOADS[args.workload][1])
+        self.net.set_gemm_policy(args.gemm)
         self.shape = [B, p['data']['channels'], p['data']['image_size'], p['data']['image_size']]
         ev = p['eval']['dlpm']
         self.meth = dlpm_amd.GenerativeLevyProcess(alpha, str(dev), T, rescale_timesteps=True, seed=0, sample_offset=rank * B,
@@ -253,6 +255,10 @@ def main():
     ap.add_argument('--no-full-trajectory', action='store_true',
                     help='do not time a whole T-step trajectory; value = init + (T-1) * ms_per_step + gather')
     ap.add_argument('--conv', default='auto', choices=['auto', 'f4', 'f2', 'igemm'], help='convolution generation (A/B runs)')
+    ap.add_argument('--gemm', default='auto', choices=['auto', 'f32', 'bf16x3'],
+                    help='matrix pipe of the 1x1 and stride-2 convolutions (dlpm_unet_set_gemm_policy): bf16x3 = fp32 operands split '
+                         'exactly into three bf16 planes, six partial products, fp32 accumulate (default where the shape admits it); '
+                         'f32 = the fp32 MFMA everywhere (A/B runs)')
     ap.add_argument('--dispatch-batch', type=int, default=-1,
                     help='dlpm_unet_set_conv_policy dispatch batch (default: the per-GPU batch of the workload\'s BASELINE config; 0: geometry only)')
     ap.add_argument('--non-iso', action='store_true',
@@ -362,7 +368,7 @@ def main():
         value, value_source = B * world / total_s, 'extrapolated: init + %d x ms_per_step (%d timed steps)%s' % (
             nsteps, K, ' + all-gather' if world > 1 else '')
 
-    roofline, upd, breakdown, att = None, None, None, None
+    roofline, upd, breakdown, att, split = None, None, None, None, None
     if not args.no_prof and rank == 0 and not dry:
         # instrumented eager pass on the same stream: HIP events around every launch, by kernel class
         nprof = 3
@@ -386,8 +392,27 @@ def main():
                        tflops=round(tf, 2), gbytes_per_s=round(gbs, 1), flop_per_byte=round(at['flops'] / at['bytes'], 2),
                        launches_per_step=at['launches'] // nprof, avg_launch_ms=round(at['ms'] / at['launches'], 5),
                        note='algorithmic bytes = qkv read + out write; 0.2 % of the step FLOPs')
-        u = prof.get('update')
-        if u:
+        sp = [v for k, v in prof.items() if 'bf16x3' in k]
+        if sp:
+            fl, ms_ = sum(v['flops'] for v in sp), sum(v['ms'] for v in sp)
+            eq = fl / (ms_ * 1e-3) / 1e12
+            split = dict(kernel='k_conv_split (1x1 and stride-2 3x3 convolutions as an fp32 GEMM on the bf16 matrix pipe: 3 bf16 planes per '
+                                'operand, 6 of the 9 partial products, v_mfma_f32_32x32x16_bf16, fp32 accumulate)', bound='mfma',
+                         achieved=round(6 * eq, 1), peak=PEAK_BF16_MFMA_TFLOPS, unit='TFLOP/s', frac=round(6 * eq / PEAK_BF16_MFMA_TFLOPS, 4),
+                         fp32_equivalent_tflops=round(eq, 2), launches_per_step=sum(v['launches'] for v in sp) // nprof,
+                         share_of_step_ms=round(ms_ / nprof, 3),
+                         note='achieved = bf16 FLOP/s EXECUTED (6 x the fp32-equivalent rate) over the dense bf16 MFMA peak; the same '
+                              'launches on the fp32 MFMA (--gemm f32) run at 85-115 fp32 TFLOP/s')
+        u, hu = prof.get('update'), prof.get('conv3x3_head+update')
+        if hu:   # the default path: the head convolution applies the update in its epilogue (dlpm_unet_forward_update)
+            gbs = hu['bytes'] / (hu['ms'] * 1e-3) / 1e9
+            upd = dict(kernel='k_conv3x3_head with the x_{t-1} update (Philox noise) fused into its epilogue: eps never reaches HBM, no '
+                              'separate update launch', bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                       frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, bytes_per_launch=hu['bytes'] / hu['launches'],
+                       avg_launch_ms=round(hu['ms'] / hu['launches'], 5),
+                       note='algorithmic bytes = the convolution input once + read x + write x; the launch is VALU-bound (36 FMAs and '
+                            'one SiLU per input element), not bandwidth-bound: see DESIGN.md section 3')
+        elif u:
             gbs = u['bytes'] / (u['ms'] * 1e-3) / 1e9
             upd = dict(kernel='k_update_rows (fused x_{t-1} update, Philox noise)', bound='hbm', achieved=round(gbs, 1),
                        peak=PEAK_HBM_GBS, unit='GB/s', frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None,
@@ -411,7 +436,7 @@ def main():
                        'net': 'reference cifar10.yml UNet (mc=128, 39.6M params), random init + re-drawn zero tensors'
                        if cfg_name == 'cifar10' else cfg_name,
                        'rng': 'philox (device, keyed by global sample index)', 'hip_graph': not args.no_graph,
-                       'conv_generation': args.conv, 'conv_dispatch_batch': args.dispatch_batch if args.dispatch_batch >= 0 else WORKLOADS[args.workload][1],
+                       'conv_generation': args.conv, 'gemm_1x1_and_downsample': args.gemm + (' (= bf16x3: fp32 operands split exactly into 3 bf16 planes, 6 partial products per multiply, fp32 accumulate; fp32-grade error, tests/test_gpu_kernels.py)' if args.gemm == 'auto' else ''), 'conv_dispatch_batch': args.dispatch_batch if args.dispatch_batch >= 0 else WORKLOADS[args.workload][1],
                        'parallelism': ('batch-sharded x%d, one RCCL all-gather at the end' % world) if world > 1 else 'single GPU (no collective)'},
             'value_source': value_source,
             'full_trajectory_s': None if full_s is None else round(full_s, 4),
@@ -420,7 +445,7 @@ def main():
             'whole_step_tflops': round(step_tflops, 3),
             'whole_step_frac_of_fp32_peak': round(step_tflops / (PEAK_FP32_MFMA_TFLOPS * world), 4),
             'samples_finite': finite,
-            'roofline': roofline, 'update_kernel': upd, 'attention_kernel': att, 'ms_per_step_by_kernel_class': breakdown, 'cpu_baseline': cpu,
+            'roofline': roofline, 'split_gemm_kernel': split, 'update_kernel': upd, 'attention_kernel': att, 'ms_per_step_by_kernel_class': breakdown, 'cpu_baseline': cpu,
         }
         if dry:
             out['dry_run'] = 'control-flow test only (DLPM_BENCH_DRY_RUN=1): stub sampler on CPU, NOT a measurement'

@@ -23,6 +23,9 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=o
 # with the product build: they go to _obj_<tag>/ and lib/libdlpm_amd_<tag>.so (load one with DLPM_LIB=<path>).
 DEFS = os.environ.get('DLPM_BUILD_DEFS', '').split()
 FLAGS += ['-D' + d.lstrip('-D') if d.startswith('-D') else '-D' + d for d in DEFS]
+XFLAGS = os.environ.get('DLPM_BUILD_FLAGS', '').split()   # extra compiler flags of an experiment build (e.g. -fno-slp-vectorize)
+FLAGS += XFLAGS
+DEFS = DEFS + XFLAGS
 if DEFS:
     import hashlib
     _tag = hashlib.sha256(' '.join(sorted(DEFS)).encode()).hexdigest()[:8]

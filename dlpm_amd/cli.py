@@ -46,6 +46,10 @@ def main(argv=None):
                     help='3x3 convolution generation of the UNet (UNetModel.set_conv_policy): auto = fastest per layer '
                          '(Winograd F(4x4,3x3) where it applies, 1.6e-5 of the reference per forward), f2 / igemm = 3e-6 / '
                          '4e-6 at 1.33x / 2.2x the time; never a function of the batch, so chunking does not change a pixel')
+    ap.add_argument('--gemm', default='auto', choices=['auto', 'f32', 'bf16x3'],
+                    help='matrix pipe of the 1x1 and stride-2 convolutions (UNetModel.set_gemm_policy): bf16x3 = fp32 operands split '
+                         'exactly into three bf16 planes, fp32 accumulate (fp32-grade results, the default where the shape admits it); '
+                         'f32 = the fp32 MFMA everywhere')
     ap.add_argument('--out', default=None, help='.npy file for the generated samples')
     ap.add_argument('--gen_data_path', default=None,
                     help='directory for <i>.png files (EvaluationManager image dump); images only')
@@ -97,6 +101,10 @@ def main(argv=None):
         if not hasattr(model, 'set_conv_policy'):
             raise SystemExit('--conv applies to the UNet score networks')
         model.set_conv_policy(a.conv)
+    if a.gemm != 'auto':
+        if not hasattr(model, 'set_gemm_policy'):
+            raise SystemExit('--gemm applies to the UNet score networks')
+        model.set_gemm_policy(a.gemm)
     method = dlpm_amd.init_method_by_parameter(p, rng=a.rng, seed=seed or 0)
     is_image = dlpm_amd.is_image_dataset(p['data']['dataset'])
     gm = dlpm_amd.GenerationManager(method, dlpm_amd.ShapeProbe(sample_shape(p)), is_image, **p['eval'][m])

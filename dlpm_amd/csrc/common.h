@@ -40,6 +40,9 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // (a process may drive several GPUs, and two host threads may launch a kernel for the first time together).
 int ensure_dynamic_lds(const void *kernel, int bytes);
 
+// t <- t - 1 on the device step counter (noise.hip): what DLPM_UPD_ADVANCE does after an update
+int launch_step_advance(int32_t *t_dev, hipStream_t st);
+
 // Optional per-launch timing (dlpm_prof_enable): brackets one launch with HIP events on its stream.
 bool prof_enabled();
 bool prof_detail();   // DLPM_PROF_DETAIL=1: one class per distinct launch shape

@@ -51,9 +51,23 @@ bool igemm_supported(const ConvLaunch &c);
 int launch_conv_igemm(const ConvLaunch &c, hipStream_t st);
 int launch_conv_direct(const ConvLaunch &c, hipStream_t st);
 int launch_conv_stem(const ConvLaunch &c, hipStream_t st);
-// head convolution (Cout <= 4) as a VALU kernel (conv_direct.hip)
+// head convolution (Cout <= 4) as a VALU kernel (conv_direct.hip), optionally with the sampler's reverse update fused into
+// its epilogue: x <- (x - c_eps[t,b] eps) / g[t] + c_noise[t,b] z on the NCHW state the eps would have been subtracted from
+struct HeadUpdate {
+    float *x = nullptr;                 // [B, Cout*H*W] state, updated in place (null: plain convolution, eps -> ConvLaunch::out)
+    const float *z = nullptr;           // injected normals, or null = in-kernel Philox (same counters as k_update_rows)
+    const int32_t *t = nullptr;         // device step counter
+    const float *g = nullptr, *c_eps = nullptr, *c_noise = nullptr;   // [T], [T,B], [T,B]
+    const uint64_t *key = nullptr;      // optional device {seed, sample_offset}
+    uint64_t seed = 0;
+    int64_t sample_offset = 0;
+    float *const *hist_pp = nullptr;    // optional history cell (dlpm_update_args::hist_pp)
+    float *eps_out = nullptr;           // optional: also keep eps
+    int32_t T = 0;
+    int64_t B = 0;
+};
 bool head_conv_ok(const ConvLaunch &c);
-int launch_conv_head(const ConvLaunch &c, hipStream_t st);
+int launch_conv_head(const ConvLaunch &c, const HeadUpdate *hu, hipStream_t st);
 int relayout_weight_head(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st);
 // Winograd F(2x2,3x3) path (conv_wino.hip)
 bool wino_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg);

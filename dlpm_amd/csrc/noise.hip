@@ -16,7 +16,6 @@ namespace {
 constexpr int kPurposeA = 1;       // rows of A[T,B]
 constexpr int kPurposeInitA = 2;   // the unclamped a of gen_sas
 constexpr int kPurposeInitZ = 3;   // x_T normals
-constexpr int kPurposeStepZ = 4;   // per-step normals
 constexpr int kPurposeAElem = 5;     // non-isotropic: A[T,B,D], counter = (sample, element, purpose | t << 8)
 constexpr int kPurposeInitAElem = 6; // non-isotropic: the unclamped per-element a of gen_sas
 
@@ -348,10 +347,6 @@ __global__ void __launch_bounds__(256) k_update_elem(dlpm_update_args p) {
 // (sample, quad), and there is no per-element index division.  Three quads per thread are loaded
 // before any arithmetic.  The division by gamma_t is a reciprocal multiply plus one Newton residual
 // step (correctly rounded except for ties; the reference divides).
-__device__ __forceinline__ float div_by(float a, float g, float rg) {
-    const float q = a * rg;
-    return fmaf(fmaf(-q, g, a), rg, q);
-}
 
 __global__ void __launch_bounds__(256) k_update_rows(dlpm_update_args p) {
     const int t = *p.t_dev;
@@ -603,6 +598,14 @@ extern "C" int dlpm_update_f32(const dlpm_update_args *a, dlpm_stream_t stream) 
     }
     return DLPM_OK;
 }
+
+namespace dlpm {
+int launch_step_advance(int32_t *t_dev, hipStream_t st) {
+    k_advance<<<1, 64, 0, st>>>(t_dev);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+}  // namespace dlpm
 
 extern "C" int dlpm_lim_update_f32(const dlpm_lim_update_args *a, dlpm_stream_t stream) {
     DLPM_CHECK_ARG(a && a->x_dev && a->eps_dev && a->t_dev && a->tmp_dev && a->cx_dev && a->cs_dev && a->cn_dev,

@@ -36,4 +36,14 @@ __device__ __forceinline__ float4 philox_normal4(uint64_t seed, uint64_t gidx, u
                        r1 * __builtin_amdgcn_sinf(u3));
 }
 
+// Philox 'purpose' of the per-step normals of the reverse update (the other purposes live in noise.hip)
+constexpr int kPurposeStepZ = 4;
+
+// a / g as the correctly rounded quotient refined from the reciprocal (one Newton step on the residual): the division of
+// the reverse update (x - c_eps eps) / gamma_t, shared by the update kernels and the head convolution's fused epilogue
+__device__ __forceinline__ float div_by(float a, float g, float rg) {
+    const float q = a * rg;
+    return fmaf(fmaf(-q, g, a), rg, q);
+}
+
 }  // namespace dlpm

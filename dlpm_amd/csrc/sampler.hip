@@ -112,7 +112,6 @@ int one_step(dlpm_sampler *s, const float *z, bool advance, hipStream_t st) {
         return dlpm_lim_update_f32(&a, st);
     }
     TRY(dlpm_fill_scaled_t_f32(s->tvec, s->t_dev, s->cfg.T, s->cfg.B, st));
-    TRY(model_forward(s, st));
     dlpm_update_args a{};
     a.x_dev = s->x; a.eps_dev = s->eps; a.z_dev = z; a.t_dev = s->t_dev;
     a.g_dev = s->g; a.bg_dev = s->bg; a.bs_dev = s->bs;
@@ -123,6 +122,15 @@ int one_step(dlpm_sampler *s, const float *z, bool advance, hipStream_t st) {
     a.hist_pp = s->hist_cell;
     a.dlim_eta = s->cfg.dlim_eta; a.alpha = (float)s->cfg.alpha;
     a.seed = s->cfg.seed; a.sample_offset = s->cfg.sample_offset; a.key_dev = s->key_dev;
+    if (s->cfg.unet) {   // the UNet's head convolution applies the update itself where the variant allows (eps stays on chip)
+        const float *xin = s->x;
+        if (s->in_scale) {
+            TRY(dlpm_scale_by_table_f32(s->x, s->xin, s->cfg.B * s->D, s->t_dev, s->in_scale, st));
+            xin = s->xin;
+        }
+        return dlpm_unet_forward_update(s->cfg.unet, xin, s->tvec, &a, s->eps, s->cfg.B, s->ws, s->ws_bytes, st);
+    }
+    TRY(model_forward(s, st));
     return dlpm_update_f32(&a, st);
 }
 

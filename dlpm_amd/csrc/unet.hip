@@ -357,7 +357,7 @@ int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 no
     return relayout_weight(src, c.w_dev, c.cout, c.cin, c.ks, c.use_igemm, nullptr);
 }
 
-int run_conv(const dlpm_unet *u, const ConvW &c, ConvLaunch L, hipStream_t st) {
+int run_conv(const dlpm_unet *u, const ConvW &c, ConvLaunch L, hipStream_t st, const HeadUpdate *hu = nullptr) {
     policy_of(u, L);
     L.w = c.w_dev;
     L.w_frag = c.w_frag;
@@ -368,7 +368,8 @@ int run_conv(const dlpm_unet *u, const ConvW &c, ConvLaunch L, hipStream_t st) {
     L.ws_gemm = (c.ks == 1 && c.w_frag) ? 1 : 0;
     L.ks = c.ks;
     L.Cout = c.cout;
-    if (head_conv_ok(L)) return launch_conv_head(L, st);
+    if (head_conv_ok(L)) return launch_conv_head(L, hu, st);
+    if (hu) { set_error("unet: the head convolution of this net cannot carry the fused update"); return DLPM_ERR_UNSUPPORTED; }
     return c.use_igemm ? launch_conv_igemm(L, st) : launch_conv_fallback(L, st);
 }
 
@@ -385,6 +386,7 @@ struct Ctx {
     hipStream_t st;
     float *embout = nullptr;
     bool uniform_t = false;      // every sample has the same timestep: the time MLP and the emb linears run on ONE row
+    const HeadUpdate *hu = nullptr;   // the sampler's reverse update, fused into the head convolution (dlpm_unet_forward_update)
     bool dry() const { return ws.dry; }
 };
 
@@ -581,7 +583,7 @@ int walk(dlpm_unet *u, Ctx &cx, const float *x, const float *t, float *eps) {
         ConvLaunch a;
         a.src0 = h.p; a.C0 = h.C; a.B = B; a.Hin = a.Hout = h.H; a.Win = a.Wout = h.W;
         a.bias = u->params[u->head.p_b].dev; a.coefA = cA; a.coefB = cB; a.act_silu = 1; a.out = eps; a.out_nchw = 1;
-        TRY(run_conv(u, u->head, a, cx.st));
+        TRY(run_conv(u, u->head, a, cx.st, cx.hu));
     }
     if (!cx.ws.reuse) return DLPM_OK;
     for (auto &f : u->feats) f.p = nullptr;     // the arena has recycled them: dlpm_unet_get_feature needs dlpm_unet_keep_features
@@ -803,7 +805,7 @@ extern "C" int64_t dlpm_unet_workspace_bytes(const dlpm_unet *net, int64_t B) {
 }
 
 static int unet_forward(dlpm_unet *net, const float *x_dev, const float *t_dev, float *eps_dev, int64_t B, void *workspace_dev,
-                        int64_t workspace_bytes, dlpm_stream_t stream, bool uniform_t);
+                        int64_t workspace_bytes, dlpm_stream_t stream, bool uniform_t, const HeadUpdate *hu = nullptr);
 
 extern "C" int dlpm_unet_forward(dlpm_unet *net, const float *x_dev, const float *t_dev, float *eps_dev, int64_t B,
                                  void *workspace_dev, int64_t workspace_bytes, dlpm_stream_t stream) {
@@ -815,8 +817,48 @@ extern "C" int dlpm_unet_forward_uniform_t(dlpm_unet *net, const float *x_dev, c
     return unet_forward(net, x_dev, t_dev, eps_dev, B, workspace_dev, workspace_bytes, stream, true);
 }
 
+// Whether this net's head convolution runs on the kernel that can carry the update (a property of the architecture).
+static bool head_fusable(const dlpm_unet *u) {
+    ConvLaunch L;
+    const int H = u->cfg.image_size;
+    L.C0 = u->head.cin; L.Hin = L.Hout = H; L.Win = L.Wout = H; L.ks = 3; L.Cout = u->head.cout; L.out_nchw = 1;
+    L.w_small = u->head.w_small;
+    return head_conv_ok(L);
+}
+
+extern "C" int dlpm_unet_forward_update(dlpm_unet *net, const float *x_in_dev, const float *t_dev, const dlpm_update_args *upd,
+                                        float *eps_scratch_dev, int64_t B, void *workspace_dev, int64_t workspace_bytes,
+                                        dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(net && x_in_dev && t_dev && upd && upd->x_dev && upd->t_dev && upd->g_dev && upd->c_eps_dev && upd->c_noise_dev,
+                   "dlpm_unet_forward_update: null argument");
+    DLPM_CHECK_ARG(upd->B == B, "dlpm_unet_forward_update: update batch %lld != %lld", (long long)upd->B, (long long)B);
+    const int64_t D = (int64_t)net->cfg.out_channels * net->cfg.image_size * net->cfg.image_size;
+    DLPM_CHECK_ARG(upd->D == D, "dlpm_unet_forward_update: state of %lld elements per sample, the net emits %lld", (long long)upd->D,
+                   (long long)D);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(upd->x_dev) | reinterpret_cast<uintptr_t>(upd->z_dev)) % 16) == 0;
+    const bool fuse = net->finalized && head_fusable(net) && aligned &&
+                      !(upd->flags & (DLPM_UPD_DLIM | DLPM_UPD_CLIP | DLPM_UPD_ELEMENTWISE));
+    if (!fuse) {   // the variants the head's epilogue does not carry: eps through HBM, then the update kernels
+        DLPM_CHECK_ARG(eps_scratch_dev, "dlpm_unet_forward_update: this update variant needs the eps scratch buffer");
+        int r = unet_forward(net, x_in_dev, t_dev, eps_scratch_dev, B, workspace_dev, workspace_bytes, stream, true);
+        if (r != DLPM_OK) return r;
+        dlpm_update_args a = *upd;
+        a.eps_dev = eps_scratch_dev;
+        return dlpm_update_f32(&a, stream);
+    }
+    HeadUpdate hu;
+    hu.x = upd->x_dev; hu.z = upd->z_dev; hu.t = upd->t_dev; hu.g = upd->g_dev; hu.c_eps = upd->c_eps_dev; hu.c_noise = upd->c_noise_dev;
+    hu.key = upd->key_dev; hu.seed = upd->seed; hu.sample_offset = upd->sample_offset; hu.hist_pp = upd->hist_pp;
+    hu.T = upd->T; hu.B = B;
+    float dummy;   // walk() wants a non-null eps pointer; the fused head never writes it
+    int r = unet_forward(net, x_in_dev, t_dev, eps_scratch_dev ? eps_scratch_dev : &dummy, B, workspace_dev, workspace_bytes, stream, true, &hu);
+    if (r != DLPM_OK) return r;
+    if (upd->flags & DLPM_UPD_ADVANCE) return launch_step_advance(const_cast<int32_t *>(upd->t_dev), as_stream(stream));
+    return DLPM_OK;
+}
+
 static int unet_forward(dlpm_unet *net, const float *x_dev, const float *t_dev, float *eps_dev, int64_t B, void *workspace_dev,
-                        int64_t workspace_bytes, dlpm_stream_t stream, bool uniform_t) {
+                        int64_t workspace_bytes, dlpm_stream_t stream, bool uniform_t, const HeadUpdate *hu) {
     DLPM_CHECK_ARG(net && x_dev && t_dev && eps_dev && workspace_dev, "dlpm_unet_forward: null argument");
     DLPM_CHECK_ARG(B > 0 && B < (1 << 24), "dlpm_unet_forward: bad batch %lld", (long long)B);
     if (!net->finalized) {
@@ -837,6 +879,7 @@ static int unet_forward(dlpm_unet *net, const float *x_dev, const float *t_dev, 
     cx.ws.reuse = !net->keep_feats;
     cx.st = as_stream(stream);
     cx.uniform_t = uniform_t;
+    cx.hu = hu;
     return walk(net, cx, x_dev, t_dev, eps_dev);
 }
 
@@ -948,7 +991,7 @@ extern "C" int dlpm_conv2d_f32(const dlpm_conv_args *a, float *scratch_dev, dlpm
             float *ws = scratch_dev + (a->scratch_floats - wsz);
             TRY(relayout_weight_head(a->weight, ws, a->Cout, a->C0, st));
             L.w_small = ws;
-            if (head_conv_ok(L)) return launch_conv_head(L, st);
+            if (head_conv_ok(L)) return launch_conv_head(L, nullptr, st);
         }
     }
     if (ig) return launch_conv_igemm(L, st);

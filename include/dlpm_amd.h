@@ -278,6 +278,16 @@ int dlpm_unet_forward(dlpm_unet *net, const float *x_dev, const float *t_dev, fl
  * (unet.py:147-150, 336-338) are evaluated for one row instead of B identical ones.  Same bits as dlpm_unet_forward. */
 int dlpm_unet_forward_uniform_t(dlpm_unet *net, const float *x_dev, const float *t_dev, float *eps_dev, int64_t B,
                                 void *workspace_dev, int64_t workspace_bytes, dlpm_stream_t stream);
+/* One network evaluation AND the reverse update of the sampler in one call: x_in_dev is what the net reads (the state, or its
+ * input-scaled copy), upd describes the update of upd->x_dev exactly as for dlpm_update_f32 except that upd->eps_dev is ignored --
+ * eps is what this forward computes.  For the stochastic DLPM step without clipping / DLIM / element-wise tables, on nets whose
+ * head convolution runs on the VALU head kernel (Cout <= 4, 16 | model_channels, 8 <= W <= 64), the update is applied in that
+ * kernel's epilogue and eps never reaches HBM; bit-identical to dlpm_unet_forward_uniform_t + dlpm_update_f32.  Every other
+ * variant runs exactly that pair, through eps_scratch_dev ([B, D]; may be NULL when the fused form applies).  t_dev: B floats,
+ * all equal (as for dlpm_unet_forward_uniform_t).  Replaces p_mean_variance + p_sample, GenerativeLevyProcess.py:170-239. */
+int dlpm_unet_forward_update(dlpm_unet *net, const float *x_in_dev, const float *t_dev, const dlpm_update_args *upd,
+                             float *eps_scratch_dev, int64_t B, void *workspace_dev, int64_t workspace_bytes,
+                             dlpm_stream_t stream);
 /* After a forward: copy block output `index` (0..n_in-1 down, then middle, then up blocks) to a
  * device buffer as NCHW for bisecting against UNetModel.get_feature_vectors (unet.py:494-524). */
 /* Block outputs are only kept when asked for: by default the activation arena recycles each buffer after its last

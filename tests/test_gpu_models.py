@@ -187,3 +187,85 @@ def test_celeba64_unet_at_its_own_width_against_oracle():
     err = (got - want).abs().max().item()
     print('celeba64 net (mc=128, 64x64): max |hip - oracle| = %.3g (|y| max %.3g)' % (err, want.abs().max().item()))
     assert err < 1e-4
+
+
+@pytest.mark.parametrize('name', ['tiny2', 'cifar'])
+@pytest.mark.parametrize('variant', ['philox', 'injected_z', 'history', 'dlim_unfused'])
+def test_unet_forward_with_fused_update_is_bit_identical_to_the_pair(name, variant):
+    """dlpm_unet_forward_update (the head convolution applies x <- (x - c_eps eps)/g + c_noise z in its epilogue,
+    GenerativeLevyProcess.py:225-239) against dlpm_unet_forward_uniform_t followed by dlpm_update_f32: same bits, with
+    in-kernel Philox noise, with injected normals, with a history row, and for a variant that takes the unfused pair."""
+    import ctypes as C
+    from dlpm_amd import _lib
+    f = golden('f6_unet_' + name)
+    net, _ = build_unet(name)
+    x0 = torch.from_numpy(f['x']).to(DEV)
+    x0 = torch.cat([x0, x0.flip(0) * 0.5, x0 * 0.25])[:3].contiguous()
+    B, D, T, t = 3, x0[0].numel(), 7, 4
+    g = torch.Generator(device='cpu').manual_seed(11)
+    gam = (0.5 + torch.rand(T, generator=g)).to(DEV)
+    c_eps, c_noise = torch.rand(T, B, generator=g).to(DEV), torch.rand(T, B, generator=g).to(DEV)
+    c_noise[t, 1] = 0.0                                    # a sample whose noise coefficient is exactly zero
+    bg, bs = torch.rand(T, generator=g).to(DEV) + 0.5, torch.rand(T, generator=g).to(DEV) + 0.1
+    A = torch.rand(T, B, generator=g).to(DEV) + 0.5
+    z = torch.randn(B, D, generator=g).to(DEV) if variant == 'injected_z' else None
+    tvec = torch.full((B,), t / T, device=DEV)
+    L, h = _lib.lib(), net.native_handle(x0.shape[2])
+    ws = net.workspace(B, x0.device)
+    st = _lib.stream_ptr()
+
+    def args(x, t_dev, eps, hist_cell):
+        a = _lib.UpdateArgs()
+        a.x_dev, a.eps_dev, a.t_dev = x.data_ptr(), eps.data_ptr() if eps is not None else None, t_dev.data_ptr()
+        a.z_dev = z.data_ptr() if z is not None else None
+        a.g_dev, a.bg_dev, a.bs_dev = gam.data_ptr(), bg.data_ptr(), bs.data_ptr()
+        a.c_eps_dev, a.c_noise_dev, a.A_dev = c_eps.data_ptr(), c_noise.data_ptr(), A.data_ptr()
+        a.B, a.D, a.T = B, D, T
+        a.flags = _lib.UPD_ADVANCE | (_lib.UPD_DLIM if variant == 'dlim_unfused' else 0)
+        a.alpha, a.seed, a.sample_offset = 1.7, 1234, 40
+        a.hist_pp = hist_cell.data_ptr() if hist_cell is not None else None
+        return a
+
+    outs = []
+    for fused in (False, True):
+        x = x0.clone()
+        t_dev = torch.tensor([t], dtype=torch.int32, device=DEV)
+        eps = torch.empty_like(x0)
+        hist = torch.zeros(T, B, D, device=DEV) if variant == 'history' else None
+        cell = torch.tensor([hist.data_ptr()], dtype=torch.int64, device=DEV) if hist is not None else None
+        a = args(x, t_dev, eps, cell)
+        if fused:
+            _lib.check(L.dlpm_unet_forward_update(h, x.data_ptr(), tvec.data_ptr(), C.byref(a), eps.data_ptr(), B, ws.data_ptr(),
+                                                  ws.numel(), st))
+        else:
+            _lib.check(L.dlpm_unet_forward_uniform_t(h, x.data_ptr(), tvec.data_ptr(), eps.data_ptr(), B, ws.data_ptr(), ws.numel(), st))
+            _lib.check(L.dlpm_update_f32(C.byref(a), st))
+        torch.cuda.synchronize()
+        assert int(t_dev.item()) == t - 1                  # DLPM_UPD_ADVANCE on both paths
+        outs.append((x.cpu(), None if hist is None else hist.cpu()))
+    assert torch.isfinite(outs[0][0]).all() and not torch.equal(outs[0][0], x0.cpu())
+    assert torch.equal(outs[0][0], outs[1][0])
+    if variant == 'history':
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.count_nonzero(outs[1][1][T - t]).item() > 0
+
+
+@pytest.mark.parametrize('name', ['cifar', 'wide'])
+def test_unet_gemm_policy_both_pipes_against_reference(name):
+    """UNetModel.set_gemm_policy: the 1x1 and stride-2 convolutions on the bf16 pipe with split operands (the default) and
+    on the fp32 MFMA, each against the reference's own output of the same net (unet.py:463-492).  The two are different
+    kernels (the outputs differ in the last bits) of the same accuracy: the conv-generation tests hold the other
+    convolutions fixed at F(2x2) here so that only the GEMM pipe moves."""
+    f = golden('f6_unet_' + name)
+    net, _ = build_unet(name)
+    net.set_conv_policy('f2')
+    x, t = torch.from_numpy(f['x']).to(DEV), torch.from_numpy(f['t']).to(DEV)
+    err, outs = {}, {}
+    for mode in ('f32', 'bf16x3', 'auto'):
+        net.set_gemm_policy(mode)
+        outs[mode] = net(x, t).cpu()
+        err[mode] = np.abs(outs[mode].numpy() - f['y']).max()
+    print('%s: |hip - reference| max  fp32 MFMA %.2e   bf16x3 %.2e' % (name, err['f32'], err['bf16x3']))
+    assert torch.equal(outs['auto'], outs['bf16x3'])
+    assert not torch.equal(outs['f32'], outs['bf16x3'])
+    assert err['f32'] < 1e-5 and err['bf16x3'] < 1e-5
+    assert err['bf16x3'] < 2 * err['f32'] + 1e-6
