@@ -26,7 +26,7 @@
 #endif
 
 #ifdef DLPM_IGEMM_ABLATIONS   // developer builds only: DLPM_ABL bits at run time (results are wrong when set): 1 no output stores,
-#define SABL(b) (p.abl & (b))  // 2 no activation re-loads, 4 no weight re-loads, 8 no MFMAs, 16 no activation staging, 32 no weight staging
+#define SABL(b) (p.abl & (b))  // 2 no activation re-loads, 4 no weight re-loads, 8 no MFMAs, 16 no activation staging, 32 no weight staging, 64 no B fragment reads
 #else
 #define SABL(b) 0
 #endif
@@ -121,8 +121,17 @@ __device__ __forceinline__ void split_store_from_registers(const ConvLaunch &p, 
 // (Also measured: 8 waves with two register stages -- 138 registers, one workgroup per CU -- 19 % slower.)
 // DIST: stages of operands waiting in registers.  TAPS: 1 = 1x1 convolution, 9 = 3x3 (padding 1, stride 1 or 2) as an implicit
 // GEMM over K = 9 Cin (channel chunk outer, tap inner: the taps of a chunk re-read the same input lines from L2).
+#ifndef SPLIT_WGS8
+#define SPLIT_WGS8 1
+#endif
+#ifndef SPLIT_DIST8
+#define SPLIT_DIST8 1
+#endif
+// (Measured and dropped, profiles/r02/gemm_bf16x3_pingpong_groups.txt: two 8-wave groups in one workgroup running the same
+// barriers one phase apart -- one group's MFMAs over the other's staging by construction -- 9 % SLOWER.  The launch time is
+// MFMA time + everything else, profiles/r02/gemm_1x1_bf16x3_ablations.txt, and that is not a phase-alignment effect.)
 template <int NW, int DIST, int TAPS>
-__global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split(ConvLaunch p, int nsamp, int xcd_map) {
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : SPLIT_WGS8) k_conv_split(ConvLaunch p, int nsamp, int xcd_map) {
     constexpr int NT = NW * 64, RN = NW == 4 ? 2 : 1, WN = 4 / RN;   // threads, MFMA column tiles per wave, waves across N
     constexpr int RSTEP = NT / 8, NV = 128 / RSTEP, NWV = SCHUNKS / NT;   // staging: rows per pass, passes, weight chunks per thread
     // [A stage 24 KB][B stage 24 KB] (the statistics epilogue's row image afterwards) [GroupNorm coefficients of the tile's samples]
@@ -270,6 +279,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split
     const int ax0 = l31 ^ (kh * 8), ax1 = l31 ^ ((2 + kh) * 8);   // swizzled row of this lane for k-step 0 / 1
     auto mfma_step = [&]() {
         if (SABL(8)) return;
+        __builtin_amdgcn_s_setprio(1);   // MFMA-issuing waves first: +4-8 % on the long launches (profiles/r02/gemm_bf16x3_priority.txt)
 #pragma unroll
         for (int ks = 0; ks < ((SPLIT_ABL & 4) ? 0 : 2); ks++) {
             bf16x8 A[2][3], B[RN][3];
@@ -279,7 +289,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split
 #pragma unroll
                 for (int i = 0; i < 2; i++) A[i][pl] = af[pl * (SPLANE / 16) + ks * 256 + i * 32 + ax];
 #pragma unroll
-                for (int j = 0; j < RN; j++) B[j][pl] = bf[pl * (SPLANE / 16) + ks * 256 + j * 32];
+                for (int j = 0; j < RN; j++) B[j][pl] = SABL(64) ? A[j][pl] : bf[pl * (SPLANE / 16) + ks * 256 + j * 32];
             }
             // smallest terms first within a (tile, k-step)
 #pragma unroll
@@ -294,6 +304,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][0], acc[i][j], 0, 0, 0);
                 }
         }
+        __builtin_amdgcn_s_setprio(0);
     };
 
     const int nsteps = nkc * TAPS;
@@ -432,10 +443,10 @@ int launch_conv_split(const ConvLaunch &c, hipStream_t st) {
     // Both accumulate every output in the same order: which one runs does not change a bit of the result.
     if (c.ks == 1) {
         if (c.stats_out) DLPM_SPLIT_LAUNCH(4, 2, 1);
-        else DLPM_SPLIT_LAUNCH(8, 1, 1);
+        else DLPM_SPLIT_LAUNCH(8, SPLIT_DIST8, 1);
     } else {
         if (c.stats_out) DLPM_SPLIT_LAUNCH(4, 2, 9);
-        else DLPM_SPLIT_LAUNCH(8, 1, 9);
+        else DLPM_SPLIT_LAUNCH(8, SPLIT_DIST8, 9);
     }
 #undef DLPM_SPLIT_LAUNCH
     DLPM_LAUNCH_CHECK();
