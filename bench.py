@@ -429,7 +429,9 @@ def main():
         out = {
             'metric': METRIC[cfg_name], 'value': round(value, 4),
             'unit': 'samples/s', 'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(ms_per_step, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.gemm == 'f32' or cfg_name == 'mnist' else 'f32 (1x1 / stride-2 convolutions: fp32 operands split exactly into 3 bf16 planes, bf16 MFMA products, fp32 accumulate)',
+            'data': 'synthetic',
             'config': {'workload': args.workload + ('+non_iso' if args.non_iso else '') + ('+lim_sde' if args.lim else ''), 'state_shape_per_gpu': shape, 'global_batch': B * world,
                        'reverse_steps': T, 'alpha': alpha, 'timed_steps': K, 'trajectory_steps': nsteps,
                        'init_ms': round(init_s * 1e3, 3), 'allgather_ms': None if gather_s is None else round(gather_s * 1e3, 3),
