@@ -443,10 +443,18 @@ int launch_conv_split(const ConvLaunch &c, hipStream_t st) {
     // Both accumulate every output in the same order: which one runs does not change a bit of the result.
     if (c.ks == 1) {
         if (c.stats_out) DLPM_SPLIT_LAUNCH(4, 2, 1);
+#ifdef SPLIT_V4
+        else DLPM_SPLIT_LAUNCH(4, 1, 1);
+#else
         else DLPM_SPLIT_LAUNCH(8, SPLIT_DIST8, 1);
+#endif
     } else {
         if (c.stats_out) DLPM_SPLIT_LAUNCH(4, 2, 9);
+#ifdef SPLIT_V4
+        else DLPM_SPLIT_LAUNCH(4, 1, 9);
+#else
         else DLPM_SPLIT_LAUNCH(8, SPLIT_DIST8, 9);
+#endif
     }
 #undef DLPM_SPLIT_LAUNCH
     DLPM_LAUNCH_CHECK();
