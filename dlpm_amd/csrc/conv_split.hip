@@ -121,17 +121,14 @@ __device__ __forceinline__ void split_store_from_registers(const ConvLaunch &p, 
 // (Also measured: 8 waves with two register stages -- 138 registers, one workgroup per CU -- 19 % slower.)
 // DIST: stages of operands waiting in registers.  TAPS: 1 = 1x1 convolution, 9 = 3x3 (padding 1, stride 1 or 2) as an implicit
 // GEMM over K = 9 Cin (channel chunk outer, tap inner: the taps of a chunk re-read the same input lines from L2).
-#ifndef SPLIT_WGS8
-#define SPLIT_WGS8 1
-#endif
-#ifndef SPLIT_DIST8
-#define SPLIT_DIST8 1
-#endif
-// (Measured and dropped, profiles/r02/gemm_bf16x3_pingpong_groups.txt: two 8-wave groups in one workgroup running the same
-// barriers one phase apart -- one group's MFMAs over the other's staging by construction -- 9 % SLOWER.  The launch time is
-// MFMA time + everything else, profiles/r02/gemm_1x1_bf16x3_ablations.txt, and that is not a phase-alignment effect.)
+// What bounds this kernel is the chip's power budget, not its structure: on all-zero operands the same launches run 27-31 %
+// faster (profiles/r02/gemm_bf16x3_zero_operands_dvfs.txt: the bare MFMA + fragment-read + barrier loop then reaches 2.0
+// PFLOP/s, 80 % of the bf16 pipe; on random data 1.45) -- the bf16 MFMAs at this rate with toggling operands pull the clock
+// down.  Which is why every structural variant measured here landed within +-5 % of this one (all under profiles/r02/gemm_*):
+// two 8-wave groups in one workgroup one barrier phase apart (ping-pong), 256-pixel tiles with two LDS stages and one
+// barrier per stage, 4 waves at three workgroups per CU, two register stages at 128 VGPRs.
 template <int NW, int DIST, int TAPS>
-__global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : SPLIT_WGS8) k_conv_split(ConvLaunch p, int nsamp, int xcd_map) {
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split(ConvLaunch p, int nsamp, int xcd_map) {
     constexpr int NT = NW * 64, RN = NW == 4 ? 2 : 1, WN = 4 / RN;   // threads, MFMA column tiles per wave, waves across N
     constexpr int RSTEP = NT / 8, NV = 128 / RSTEP, NWV = SCHUNKS / NT;   // staging: rows per pass, passes, weight chunks per thread
     // [A stage 24 KB][B stage 24 KB] (the statistics epilogue's row image afterwards) [GroupNorm coefficients of the tile's samples]
@@ -279,7 +276,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : SPLIT_WGS8) k_c
     const int ax0 = l31 ^ (kh * 8), ax1 = l31 ^ ((2 + kh) * 8);   // swizzled row of this lane for k-step 0 / 1
     auto mfma_step = [&]() {
         if (SABL(8)) return;
-        __builtin_amdgcn_s_setprio(1);   // MFMA-issuing waves first: +4-8 % on the long launches (profiles/r02/gemm_bf16x3_priority.txt)
+        if (!(SPLIT_ABL & 16)) __builtin_amdgcn_s_setprio(1);   // MFMA-issuing waves first: +4-8 % on the long launches (profiles/r02/gemm_bf16x3_priority.txt)
 #pragma unroll
         for (int ks = 0; ks < ((SPLIT_ABL & 4) ? 0 : 2); ks++) {
             bf16x8 A[2][3], B[RN][3];
@@ -369,7 +366,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : SPLIT_WGS8) k_c
         }
     } else {
         for (int s = 0; s < nsteps; s++) {
-            store_step(xa0, wb0, ok0, s);
+            if (!(SPLIT_ABL & 8) || s == 0) store_step(xa0, wb0, ok0, s);   // SPLIT_ABL 8: stage 0 only
             SPLIT_LP(0);
             __syncthreads();
             SPLIT_LP(1);
@@ -443,18 +440,10 @@ int launch_conv_split(const ConvLaunch &c, hipStream_t st) {
     // Both accumulate every output in the same order: which one runs does not change a bit of the result.
     if (c.ks == 1) {
         if (c.stats_out) DLPM_SPLIT_LAUNCH(4, 2, 1);
-#ifdef SPLIT_V4
-        else DLPM_SPLIT_LAUNCH(4, 1, 1);
-#else
-        else DLPM_SPLIT_LAUNCH(8, SPLIT_DIST8, 1);
-#endif
+        else DLPM_SPLIT_LAUNCH(8, 1, 1);
     } else {
         if (c.stats_out) DLPM_SPLIT_LAUNCH(4, 2, 9);
-#ifdef SPLIT_V4
-        else DLPM_SPLIT_LAUNCH(4, 1, 9);
-#else
-        else DLPM_SPLIT_LAUNCH(8, SPLIT_DIST8, 9);
-#endif
+        else DLPM_SPLIT_LAUNCH(8, 1, 9);
     }
 #undef DLPM_SPLIT_LAUNCH
     DLPM_LAUNCH_CHECK();

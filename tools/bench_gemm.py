@@ -44,6 +44,10 @@ def run(name, n, B, C0, C1, H, Cout, coef, res, ks=1, stride=1, reps=10):
     x1 = torch.randn(B, H, H, C1, device=DEV, generator=g) if C1 else None
     w = torch.randn(Cout, Cin, ks, ks, device=DEV, generator=g) / (Cin * ks * ks) ** 0.5
     bias = torch.randn(Cout, device=DEV, generator=g)
+    if os.environ.get('BENCH_ZEROS') == '1':   # the same instruction stream without data toggling (DVFS check)
+        x0.zero_(); w.zero_()
+        if x1 is not None:
+            x1.zero_()
     a = _lib.ConvArgs()
     a.src0, a.C0 = x0.data_ptr(), C0
     if C1:

@@ -147,6 +147,82 @@ void run_lds(const char *name) {
     hipFree(out); hipFree(clk);
 }
 
+
+// The stage loop of conv_split.hip without its global loads: per stage a wave (64 x 32 output tile, six-product split) reads
+// 18 fragments (2 k-steps x (2 x 3 A planes + 3 B planes)) and issues 24 MFMAs; NBAR barriers per stage (0, 1 or 2), WR LDS
+// write instructions per stage (ds_write_b128 of a register), NW waves per workgroup.  What does the barrier-phased structure
+// cost by itself?
+template <int NW, int NBAR, int WR, int WPE = 1>
+__global__ void __launch_bounds__(NW * 64, WPE) k_stage(float *out, int iters, float seed, unsigned long long *clk) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bf16x8 *lds = reinterpret_cast<bf16x8 *>(smem);
+    for (int i = tid; i < 3072; i += NW * 64) {
+        bf16x8 t;
+        for (int e = 0; e < 8; e++) t[e] = (__bf16)(seed + (i & 7) + e);
+        lds[i] = t;
+    }
+    __syncthreads();
+    floatx16 acc[2];
+    for (int q = 0; q < 2; q++) for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
+    const bf16x8 *a = lds + (wave & 1) * 64 + (lane & 31) + (lane >> 5) * 128;
+    const bf16x8 *b = lds + 1536 + (wave >> 1) % 4 * 32 + (lane & 31) + (lane >> 5) * 128;
+    bf16x8 wv;
+    for (int e = 0; e < 8; e++) wv[e] = (__bf16)(seed + e);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 A[2][3], B[3];
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                A[0][p] = a[p * 512 + ks * 256];
+                A[1][p] = a[p * 512 + ks * 256 + 32];
+                B[p] = b[p * 512 + ks * 256];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][2], B[0], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], B[1], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[2], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], B[0], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[1], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[0], acc[i], 0, 0, 0);
+            }
+        }
+        if (NBAR >= 1) __syncthreads();
+#pragma unroll
+        for (int w = 0; w < WR; w++) lds[3072 + (w * NW * 64 + tid) % 3072] = wv;   // a second 48-KB region: no hazard with the reads
+        if (NBAR >= 2) __syncthreads();
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && tid == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+    float s = 0.f;
+    for (int q = 0; q < 2; q++) for (int r = 0; r < 16; r++) s += acc[q][r];
+    out[(size_t)blockIdx.x * NW * 64 + tid] = s;
+}
+
+template <int NW, int NBAR, int WR, int WPE = 1>
+void run_stage(const char *name, int lds_bytes) {
+    float *out;
+    unsigned long long *clk;
+    const int grid = 256 * 6, iters = 600;
+    hipMalloc(&out, (size_t)grid * NW * 64 * 4);
+    hipMalloc(&clk, 16);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stage<NW, NBAR, WR, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    k_stage<NW, NBAR, WR, WPE><<<grid, NW * 64, lds_bytes>>>(out, 10, 0.3f, clk);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    k_stage<NW, NBAR, WR, WPE><<<grid, NW * 64, lds_bytes>>>(out, iters, 0.3f, clk);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    report(name, ms, 2.0 * 32 * 32 * 16 * 24.0 * iters * NW * grid, clk);
+    hipFree(out); hipFree(clk);
+}
+
 int main() {
     run<0, 0, 4>("fp32 32x32x2, 1 wave/SIMD");
     run<0, 0, 8>("fp32 32x32x2, 2 waves/SIMD");
@@ -163,5 +239,16 @@ int main() {
     run<0, 4, 8>("fp32 32x32x2 + 4 fma per MFMA, 2 waves/SIMD");
     run_lds<1>("bf16 32x32x16, 64x64 per wave, operands from LDS");
     run_lds<3>("six-product split, 64x64 per wave, 3+3 planes from LDS");
+    // LDS per workgroup chosen so that 2 workgroups of 8 waves (or 1 of 16) share a CU, as in conv_split.hip
+    run_stage<8, 0, 0>("stage loop, 8 waves x 2 WGs/CU, no barrier, no writes", 76 * 1024);
+    run_stage<8, 1, 0>("stage loop, 8 waves x 2 WGs/CU, 1 barrier per stage", 76 * 1024);
+    run_stage<8, 2, 0>("stage loop, 8 waves x 2 WGs/CU, 2 barriers per stage", 76 * 1024);
+    run_stage<8, 2, 9>("stage loop, 8 waves x 2 WGs/CU, 2 barriers + 9 LDS writes", 76 * 1024);
+    run_stage<8, 0, 9>("stage loop, 8 waves x 2 WGs/CU, no barrier, 9 LDS writes", 76 * 1024);
+    run_stage<16, 1, 0>("stage loop, 16 waves x 1 WG/CU, 1 barrier per stage", 150 * 1024);
+    run_stage<16, 1, 5>("stage loop, 16 waves x 1 WG/CU, 1 barrier + 5 LDS writes", 150 * 1024);
+    run_stage<4, 2, 0>("stage loop, 4 waves x 3 WGs/CU, 2 barriers per stage", 50 * 1024);
+    run_stage<8, 2, 9, 4>("stage loop, 8 waves x 2 WGs/CU, 2 barriers + 9 writes, <= 128 VGPRs", 76 * 1024);
+    run_stage<8, 2, 0, 4>("stage loop, 8 waves x 2 WGs/CU, 2 barriers, <= 128 VGPRs", 76 * 1024);
     return 0;
 }
