@@ -12,8 +12,10 @@ LIB_PATH = os.environ.get('DLPM_LIB') or os.path.join(_HERE, 'lib', 'libdlpm_amd
 
 vp, i32, i64, u32, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
 
-ABI_VERSION = 4   # must equal dlpm_abi_version(): struct layouts below mirror include/dlpm_amd.h at this version
+ABI_VERSION = 5   # must equal dlpm_abi_version(): struct layouts below mirror include/dlpm_amd.h at this version
 UPD_DLIM, UPD_CLIP, UPD_ADVANCE, SMP_NO_FUSED_MLP, UPD_ELEMENTWISE, SMP_LIM = 1, 2, 4, 8, 16, 32
+MEAN_TYPES = {'EPSILON': 0, 'START_X': 1, 'Z': 2, 'PREVIOUS_X': 3}   # dlpm_mean_type
+PRED_TO_XSTART, PRED_CLIP, PRED_TO_EPS, PRED_ELEMENTWISE = 1, 2, 4, 16
 CONV_AUTO, CONV_F4, CONV_F2, CONV_IGEMM = 0, 1, 2, 3
 GEMM_AUTO, GEMM_F32, GEMM_BF16X3 = 0, 1, 2
 
@@ -27,6 +29,11 @@ class UpdateArgs(C.Structure):
                 ('bs_dev', vp), ('c_eps_dev', vp), ('c_noise_dev', vp), ('A_dev', vp), ('B', i64), ('D', i64),
                 ('T', i32), ('flags', i32), ('dlim_eta', f32), ('alpha', f32), ('seed', u64), ('sample_offset', i64), ('key_dev', vp),
                 ('hist_pp', vp)]
+
+
+class PredictArgs(C.Structure):
+    _fields_ = [('x_dev', vp), ('in_dev', vp), ('out_dev', vp), ('t_dev', vp), ('g_dev', vp), ('bg_dev', vp), ('bs_dev', vp),
+                ('c_eps_dev', vp), ('A_dev', vp), ('B', i64), ('D', i64), ('T', i32), ('mean_type', i32), ('flags', i32)]
 
 
 class LimUpdateArgs(C.Structure):
@@ -52,7 +59,8 @@ class SamplerConfig(C.Structure):
     _fields_ = [('unet', vp), ('mlp', vp), ('B', i64), ('C', i32), ('H', i32), ('W', i32), ('T', i32), ('alpha', f64),
                 ('clamp_a', f64), ('clamp_eps', f64), ('flags', i32), ('dlim_eta', f32), ('seed', u64),
                 ('sample_offset', i64), ('use_graph', i32), ('g', vp), ('bg', vp), ('s', vp), ('bs', vp),
-                ('lim_ts', vp), ('lim_tmp', vp), ('lim_cx', vp), ('lim_cs', vp), ('lim_cn', vp), ('in_scale', vp)]
+                ('lim_ts', vp), ('lim_tmp', vp), ('lim_cx', vp), ('lim_cs', vp), ('lim_cn', vp), ('in_scale', vp),
+                ('mean_type', i32)]
 
 
 # name -> (restype, argtypes); one entry per function declared in include/dlpm_amd.h
@@ -72,6 +80,7 @@ SIGNATURES = {
     'dlpm_init_state_philox_f32': (C.c_int, [vp, i64, i64, f64, f64, f32, u64, i64, vp]),
     'dlpm_coeff_tables_f32': (C.c_int, [vp, vp, vp, vp, C.c_int, i64, vp, vp, vp, vp]),
     'dlpm_update_f32': (C.c_int, [C.POINTER(UpdateArgs), vp]),
+    'dlpm_predict_f32': (C.c_int, [C.POINTER(PredictArgs), vp]),
     'dlpm_fill_scaled_t_f32': (C.c_int, [vp, vp, i32, i64, vp]),
     'dlpm_postprocess_f32': (C.c_int, [vp, vp, i64, f32, C.c_int, vp]),
     'dlpm_scale_by_table_f32': (C.c_int, [vp, vp, i64, vp, vp, vp]),

@@ -22,7 +22,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=o
 # Instrumented / ablation builds (DLPM_BUILD_DEFS="DLPM_PHASE_TIMING F4_X=11 ...") never share objects or the library name
 # with the product build: they go to _obj_<tag>/ and lib/libdlpm_amd_<tag>.so (load one with DLPM_LIB=<path>).
 DEFS = os.environ.get('DLPM_BUILD_DEFS', '').split()
-FLAGS += ['-D' + d.lstrip('-D') if d.startswith('-D') else '-D' + d for d in DEFS]
+FLAGS += ['-D' + (d[2:] if d.startswith('-D') else d) for d in DEFS]
 XFLAGS = os.environ.get('DLPM_BUILD_FLAGS', '').split()   # extra compiler flags of an experiment build (e.g. -fno-slp-vectorize)
 FLAGS += XFLAGS
 DEFS = DEFS + XFLAGS

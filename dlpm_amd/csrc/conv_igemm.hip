@@ -1045,6 +1045,8 @@ int launch_conv_stem(const ConvLaunch &c, hipStream_t st) {
 int conv_stats_pixels(const ConvLaunch &c) {
     int a, b, n;
     if (c.in_nchw) return stem_stats_ok(c) ? 1024 : 0;
+    // same order as launch_conv_igemm's dispatch: a launch that carries split weights runs k_conv_split whatever else it carries
+    if (conv_split_ok(c)) return ((int64_t)c.Hout * c.Wout) % BM == 0 && (c.R0 & 3) == 0 ? BM : 0;
     if (wino4_preferred(c, &a, &b, &n)) return n == 1 ? 256 : 0;
     if (wino_geometry(c, &a, &b, &n)) return n == 1 ? 4 * wino_tiles(c) : 0;
     if (c.out_nchw || (c.Cout & 3) || (c.R0 & 3)) return 0;

@@ -84,8 +84,11 @@ template <bool MASKED, int RN>
 __device__ __forceinline__ void split_store_from_registers(const ConvLaunch &p, floatx16 (&acc)[2][RN], int64_t m0, int nw0, int wm,
                                                      int l31, int kh, int mrem) {
     const int R1 = p.Cout - p.R0;
-    const int rlim = mrem - 1 - (wm * 64 + 4 * kh);   // last valid row, counted from this lane's first row
+    const int rlim = mrem - 1 - (wm * 64 + 4 * kh);   // last valid row, counted from this lane's first row (negative: the lane has none)
     const int64_t row0 = m0 + wm * 64 + 4 * kh;
+    // residual rows of a ragged tile are clamped to the tile's last valid row IN ABSOLUTE terms: a lane whose first row already
+    // lies beyond M (rlim < 0) reads row mrem - 1 of the tile, never memory behind the tensor
+    const int rres0 = MASKED ? min(wm * 64 + 4 * kh, mrem - 1) : 0;   // this lane's first residual row, counted from m0
 #pragma unroll
     for (int j = 0; j < RN; j++) {
         const int n = nw0 + j * 32 + l31;
@@ -94,7 +97,8 @@ __device__ __forceinline__ void split_store_from_registers(const ConvLaunch &p, 
         float q[2][16];
         if (p.res0) {
             const bool r0 = n < p.R0;                    // uniform per (wave, j): R0 % 32 == 0 (gemm_split_ok)
-            const float *rp = r0 ? p.res0 + row0 * p.R0 + n : p.res1 + row0 * R1 + (n - p.R0);
+            const int64_t rrow0 = MASKED ? m0 + rres0 : row0;
+            const float *rp = r0 ? p.res0 + rrow0 * p.R0 + n : p.res1 + rrow0 * R1 + (n - p.R0);
             const int rs = r0 ? p.R0 : R1;
 #pragma unroll
             for (int i = 0; i < 2; i++)
@@ -224,7 +228,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split
     const float *cf = reinterpret_cast<const float *>(smem + 2 * SOPER);
     int cfo[NV];                                  // this thread's rows' coefficient rows in the LDS table
 #pragma unroll
-    for (int v = 0; v < NV; v++) cfo[v] = (nsamp > 1 ? (rb + RSTEP * v) / HWo : 0) * Cin + 4 * q;
+    for (int v = 0; v < NV; v++) cfo[v] = (nsamp > 1 ? min(rb + RSTEP * v, mrem - 1) / HWo : 0) * Cin + 4 * q;   // rows beyond M: the last valid sample's (written) coefficients
     const int wofs = (ksh * 128 + (rb ^ (ksh * 8))) * 2 + (q & 1);
     auto store_step = [&](float4 (&xa)[NV], u32x4 (&wb)[NWV], int ok, int s) {
         const int c0 = (TAPS == 1 ? s : s / TAPS) * SKC;
@@ -429,6 +433,10 @@ int launch_conv_split(const ConvLaunch &c, hipStream_t st) {
     const int64_t mt = ceil_div(M, BM);
     const unsigned grid = (unsigned)(mt * (c.Cout / 128));
     const int xcd_map = (c.Cout > 128 && mt % 8 == 0) ? 1 : 0;
+    if (c.stats_out && (HW % BM != 0 || M % BM != 0)) {   // the statistics epilogue has no bounds tests and one partial per in-image tile
+        set_error("launch_conv_split: fused statistics need whole 128-pixel tiles inside one image (HW %d)", HW);
+        return DLPM_ERR_UNSUPPORTED;
+    }
 #define DLPM_SPLIT_LAUNCH(NW_, DIST_, TAPS_)                                                                              \
     do {                                                                                                                  \
         const int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_conv_split<NW_, DIST_, TAPS_>), 2 * SOPER + 32 * 1024); \

@@ -391,6 +391,33 @@ __global__ void __launch_bounds__(256) k_update_rows(dlpm_update_args p) {
     }
 }
 
+// p_mean_variance for the model mean types other than "EPSILON without clipping" (GenerativeLevyProcess.py:182-207):
+// the model output becomes x_0 (per mean type), optionally clamped, and is turned back into the eps the step formulas
+// take (predict_eps, dlpm.py:198-202).  Element-wise, the reference's rounding order; ELEMENTWISE: [T,B,D] tables.
+__global__ void __launch_bounds__(256) k_predict(dlpm_predict_args p) {
+    const int t = *p.t_dev;
+    const float g = p.g_dev[t], bg = p.bg_dev[t], bs = p.bs_dev[t];
+    const bool elem = p.flags & DLPM_PRED_ELEMENTWISE;
+    const int64_t n = p.B * p.D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t col = elem ? i : i / p.D;
+        const int64_t ti = (int64_t)t * (elem ? n : p.B) + col;
+        const float x = p.x_dev[i];
+        float v = p.in_dev[i];
+        if (p.flags & DLPM_PRED_TO_XSTART) {
+            if (p.mean_type != DLPM_MEAN_START_X) {
+                float e = v;
+                if (p.mean_type == DLPM_MEAN_Z) e = __fmul_rn(__fsqrt_rn(p.A_dev[ti]), v);                       // eps = sqrt(A[t]) * out (:193)
+                else if (p.mean_type == DLPM_MEAN_PREVIOUS_X) e = __fdiv_rn(x - __fmul_rn(v, g), p.c_eps_dev[ti]);   // dlpm.py:204-209
+                v = __fdiv_rn(x - __fmul_rn(e, bs), bg);                                                        // predict_xstart, dlpm.py:191-196
+            }
+        }
+        if (p.flags & DLPM_PRED_CLIP) v = fminf(fmaxf(v, -1.0f), 1.0f);
+        if (p.flags & DLPM_PRED_TO_EPS) v = __fdiv_rn(x - __fmul_rn(v, bg), bs);                                  // predict_eps
+        p.out_dev[i] = v;
+    }
+}
+
 // LIM update (sde_score_update / ode_score_update, dlpm/methods/LIM/functions/sampler.py:85-152): per step the
 // coefficients are four scalars; the SDE noise is gen_sas's clamp(sqrt(a_b) z) with a fresh per-sample a.
 // One workgroup per sample (wave-uniform coefficients, Philox counter = (sample, quad)); VEC needs D % 4 == 0.
@@ -596,6 +623,21 @@ extern "C" int dlpm_update_f32(const dlpm_update_args *a, dlpm_stream_t stream) 
         k_advance<<<1, 64, 0, as_stream(stream)>>>(const_cast<int32_t *>(a->t_dev));
         DLPM_LAUNCH_CHECK();
     }
+    return DLPM_OK;
+}
+
+extern "C" int dlpm_predict_f32(const dlpm_predict_args *a, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(a && a->x_dev && a->in_dev && a->out_dev && a->t_dev && a->g_dev && a->bg_dev && a->bs_dev, "dlpm_predict_f32: null pointer");
+    DLPM_CHECK_ARG(a->B > 0 && a->D > 0 && a->T >= 2, "dlpm_predict_f32: bad shape");
+    DLPM_CHECK_ARG(a->mean_type >= DLPM_MEAN_EPSILON && a->mean_type <= DLPM_MEAN_PREVIOUS_X, "dlpm_predict_f32: unknown mean type %d", a->mean_type);
+    if (a->flags & DLPM_PRED_TO_XSTART) {
+        DLPM_CHECK_ARG(a->mean_type != DLPM_MEAN_Z || a->A_dev, "dlpm_predict_f32: mean type Z needs A");
+        DLPM_CHECK_ARG(a->mean_type != DLPM_MEAN_PREVIOUS_X || a->c_eps_dev, "dlpm_predict_f32: mean type PREVIOUS_X needs c_eps");
+    }
+    const int64_t n = a->B * a->D;
+    ProfScope ps("predict", 0.0, 12.0 * (double)n, as_stream(stream));
+    k_predict<<<(unsigned)std::min<int64_t>(ceil_div(n, 256), 256 * 16), 256, 0, as_stream(stream)>>>(*a);
+    DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }
 

@@ -122,6 +122,20 @@ int one_step(dlpm_sampler *s, const float *z, bool advance, hipStream_t st) {
     a.hist_pp = s->hist_cell;
     a.dlim_eta = s->cfg.dlim_eta; a.alpha = (float)s->cfg.alpha;
     a.seed = s->cfg.seed; a.sample_offset = s->cfg.sample_offset; a.key_dev = s->key_dev;
+    if (s->cfg.mean_type != DLPM_MEAN_EPSILON) {
+        // the net predicts x_0 / z_t / the anterior mean: model output -> x_0 -> (clamp) -> eps in one pass over the eps buffer
+        // (p_mean_variance's else-branch, GenerativeLevyProcess.py:185-207), then the plain step
+        TRY(model_forward(s, st));
+        dlpm_predict_args q{};
+        q.x_dev = s->x; q.in_dev = s->eps; q.out_dev = s->eps; q.t_dev = s->t_dev;
+        q.g_dev = s->g; q.bg_dev = s->bg; q.bs_dev = s->bs; q.c_eps_dev = s->c_eps; q.A_dev = s->A;
+        q.B = s->cfg.B; q.D = s->D; q.T = s->cfg.T; q.mean_type = s->cfg.mean_type;
+        q.flags = DLPM_PRED_TO_XSTART | DLPM_PRED_TO_EPS | ((s->cfg.flags & DLPM_UPD_CLIP) ? DLPM_PRED_CLIP : 0) |
+                  (s->elem ? DLPM_PRED_ELEMENTWISE : 0);
+        TRY(dlpm_predict_f32(&q, st));
+        a.flags &= ~DLPM_UPD_CLIP;
+        return dlpm_update_f32(&a, st);
+    }
     if (s->cfg.unet) {   // the UNet's head convolution applies the update itself where the variant allows (eps stays on chip)
         const float *xin = s->x;
         if (s->in_scale) {
@@ -169,6 +183,8 @@ extern "C" int dlpm_sampler_create(const dlpm_sampler_config *cfg, dlpm_sampler 
     const bool have_lim = cfg->lim_ts && cfg->lim_tmp && cfg->lim_cx && cfg->lim_cs && cfg->lim_cn;
     DLPM_CHECK_ARG(!is_lim || have_lim || (!cfg->lim_ts && !cfg->lim_tmp && !cfg->lim_cx && !cfg->lim_cs && !cfg->lim_cn),
                    "dlpm_sampler_create: give all five LIM tables or none");
+    DLPM_CHECK_ARG(cfg->mean_type >= DLPM_MEAN_EPSILON && cfg->mean_type <= DLPM_MEAN_PREVIOUS_X, "dlpm_sampler_create: unknown mean type %d", cfg->mean_type);
+    DLPM_CHECK_ARG(!is_lim || cfg->mean_type == DLPM_MEAN_EPSILON, "LIM only supports epsilon prediction, fixed variance and rescaled timesteps");
     DLPM_CHECK_ARG(!is_lim || !(cfg->flags & (DLPM_UPD_CLIP | DLPM_UPD_ELEMENTWISE)),
                    "dlpm_sampler_create: the LIM sampler has no clip_denoised / non-isotropic variant (the reference's are commented out)");
     dlpm_sampler *s = new dlpm_sampler();
@@ -236,7 +252,7 @@ extern "C" int dlpm_sampler_create(const dlpm_sampler_config *cfg, dlpm_sampler 
     if ((e = hipMalloc(&s->A, tb)) != hipSuccess) return fail(e);
     // Non-isotropic tables are T*B*D floats each (12.6 GB for [1024,3,32,32], T = 1000): A is only read again by
     // DLIM with eta > 0, otherwise c_eps is computed in place over it.
-    const bool keepA = !s->elem || ((cfg->flags & DLPM_UPD_DLIM) && cfg->dlim_eta != 0.0f);
+    const bool keepA = !s->elem || ((cfg->flags & DLPM_UPD_DLIM) && cfg->dlim_eta != 0.0f) || cfg->mean_type == DLPM_MEAN_Z;
     if (is_lim) {
         s->c_eps = s->A;     // LIM has no coefficient tables: A[i,b] is read directly by the update
         s->c_noise = nullptr;
@@ -276,8 +292,9 @@ extern "C" int dlpm_sampler_reseed(dlpm_sampler *s, uint64_t seed, int64_t sampl
     s->cfg.seed = seed;
     s->cfg.sample_offset = sample_offset;
     // The key is read from device memory by the captured update node: no recapture needed.  It is written by a
-    // one-thread kernel on the stream of the next begin*() -- stream order puts it behind every replay of the previous
-    // trajectory (dlpm_sampler_steps fences its private stream back into the caller's), so nothing synchronises here.
+    // one-thread kernel on the stream of the next begin*() / set_state / steps / step_injected, whichever comes first --
+    // stream order puts it behind every replay of the previous trajectory (dlpm_sampler_steps fences its private stream
+    // back into the caller's), so nothing synchronises here.
     s->key_dirty = true;
     return DLPM_OK;
 }
@@ -314,6 +331,7 @@ extern "C" int dlpm_sampler_set_state(dlpm_sampler *s, const float *x_dev, int32
     DLPM_CHECK_ARG(s, "dlpm_sampler_set_state: null handle");
     DLPM_CHECK_ARG(t >= 1 && t <= s->cfg.T - 1, "dlpm_sampler_set_state: t = %d outside 1..%d", t, s->cfg.T - 1);
     hipStream_t st = as_stream(stream);
+    TRY(flush_key(s, st));   // reseed -> set_state -> steps (resuming a trajectory under a new key) must not draw with the old one
     if (x_dev)
         DLPM_HIP(hipMemcpyAsync(s->x, x_dev, (size_t)s->cfg.B * s->D * sizeof(float), hipMemcpyDeviceToDevice, st));
     k_set_t<<<1, 64, 0, st>>>(s->t_dev, t);
@@ -326,6 +344,7 @@ extern "C" int dlpm_sampler_step_injected(dlpm_sampler *s, const float *z_dev, d
     DLPM_CHECK_ARG(s, "dlpm_sampler_step_injected: null handle");
     if (s->t_host < 1) return DLPM_OK;
     TRY(sync_plan(s));
+    TRY(flush_key(s, as_stream(stream)));
     TRY(one_step(s, z_dev, true, as_stream(stream)));
     s->t_host -= 1;
     return DLPM_OK;
@@ -376,10 +395,11 @@ extern "C" int dlpm_sampler_steps(dlpm_sampler *s, int32_t nsteps, dlpm_stream_t
     if (nsteps > s->t_host) nsteps = s->t_host;
     if (nsteps == 0) return DLPM_OK;
     TRY(sync_plan(s));
+    TRY(flush_key(s, st));   // one thread, stream-ordered before the (replayed) steps; free when the key is clean
     // toy net, plain stochastic DLPM steps: the whole run of steps is one launch (state in registers)
     // (one wave per sample: best while the batch is latency-bound; beyond ~16k samples the 4-samples-per-wave
     //  forward kernel + update kernel reuse the weights better)
-    if (s->cfg.mlp && !(s->cfg.flags & (DLPM_UPD_DLIM | DLPM_UPD_CLIP | DLPM_SMP_NO_FUSED_MLP | DLPM_SMP_LIM)) && s->D <= 4 &&
+    if (s->cfg.mlp && !(s->cfg.flags & (DLPM_UPD_DLIM | DLPM_UPD_CLIP | DLPM_SMP_NO_FUSED_MLP | DLPM_SMP_LIM)) && s->D <= 4 && s->cfg.mean_type == DLPM_MEAN_EPSILON &&
         s->cfg.B <= 16384 && !s->hist && !s->in_scale && !prof_enabled()) {
         TRY(dlpm_mlp_sample_steps_f32(s->cfg.mlp, s->x, s->c_eps, s->c_noise, s->g, s->cfg.T, s->cfg.B, s->t_host, nsteps,
                                       s->cfg.seed, s->cfg.sample_offset, s->key_dev, st));

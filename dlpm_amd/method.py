@@ -28,7 +28,11 @@ from .process import DLPM
 
 
 class ModelMeanType:
-    EPSILON = 'EPSILON'
+    """What the net predicts (dlpm/methods/dlpm.py:10-18)."""
+    PREVIOUS_X = 'PREVIOUS_X'   # the anterior mean m_tilde_{t-1}
+    START_X = 'START_X'         # x_0
+    EPSILON = 'EPSILON'         # eps (every shipped config)
+    Z = 'Z'                     # z_t
 
 
 class ModelVarType:
@@ -79,10 +83,14 @@ class GenerativeLevyProcess:
                  model_var_type=ModelVarType.FIXED, time_spacing='linear', rescale_timesteps=False, isotropic=True,
                  LIM=False, scale='scale_preserving', input_scaling=False,
                  rng='philox', seed=0, sample_offset=0, use_graph=True, reference_streams=None, fused_mlp=True):
-        assert (model_mean_type == ModelMeanType.EPSILON) and (model_var_type == ModelVarType.FIXED), \
-            'Only epsilon prediction and fixed variance are supported for the moment'
+        # The reference constructor asserts EPSILON here (GenerativeLevyProcess.py:74-77) although p_mean_variance carries
+        # the START_X / Z / PREVIOUS_X branches (:186-207), reachable there only by setting `model_mean_type` afterwards.
+        # This build runs them (dlpm_predict_f32); the variance stays FIXED as in the reference.
+        assert model_mean_type in _lib.MEAN_TYPES, 'unknown model_mean_type {}'.format(model_mean_type)
+        assert model_var_type == ModelVarType.FIXED, 'Only fixed variance is supported for the moment'
         if LIM:
-            assert rescale_timesteps, 'LIM only supports epsilon prediction, fixed variance and rescaled timesteps'
+            assert (model_mean_type == ModelMeanType.EPSILON) and rescale_timesteps, \
+                'LIM only supports epsilon prediction, fixed variance and rescaled timesteps'
             if not isotropic:
                 raise NotImplementedError('the LIM sampler is isotropic only (its non-isotropic branch is commented '
                                           'out in the reference, LIM/functions/sampler.py:144-148)')
@@ -162,7 +170,7 @@ class GenerativeLevyProcess:
         # old one's address back from the allocator, and a cached sampler's hipGraph still points at the freed weights
         key = (id(model), model.handle_generation, tuple(shape),
                self.reverse_steps, self.alpha, flags, eta, clamp_a, clamp_eps, self.use_graph, self.fused_mlp,
-               self.dlpm.host_schedule[3].data_ptr(), self._input_scale() is not None)
+               self.dlpm.host_schedule[3].data_ptr(), self._input_scale() is not None, self.model_mean_type)
         ent = self._samplers.get(key)
         if ent is not None:
             _lib.check(_lib.lib().dlpm_sampler_reseed(ent['h'], seed, offset))
@@ -178,6 +186,7 @@ class GenerativeLevyProcess:
         cfg.clamp_eps = -1.0 if clamp_eps is None else float(clamp_eps)
         cfg.flags = flags | (0 if self.fused_mlp else _lib.SMP_NO_FUSED_MLP)
         cfg.dlim_eta, cfg.seed = float(eta), seed
+        cfg.mean_type = _lib.MEAN_TYPES[self.model_mean_type]
         gs = 0
         if self.use_graph and self.rng == 'philox':
             # steps per captured graph: 1 for the UNets (~150 launches, ms-long steps), 33 for the
@@ -303,8 +312,11 @@ class GenerativeLevyProcess:
             _lib.check(L.dlpm_sampler_set_history(h, None, st))
         return (x, hist) if history else x
 
-    def _run_callable(self, model, shape, flags, eta, clamp_a, clamp_eps, noise, history, progress):
-        """Generic `model(x, t)` (any torch callable on the GPU): same kernels, Python between them."""
+    def _run_callable(self, model, shape, flags, eta, clamp_a, clamp_eps, noise, history, progress,
+                      denoised_fn=None, model_kwargs=None):
+        """Generic `model(x, t, **model_kwargs)` (any torch callable on the GPU): same kernels, Python between them.
+        Also the loop for a `denoised_fn` (a Python function applied to the x_0 prediction, p_mean_variance :162-167)."""
+        model_kwargs = model_kwargs or {}
         L, st = _lib.lib(), _lib.stream_ptr()
         T, B = self.reverse_steps, shape[0]
         D = int(np.prod(shape[1:]))
@@ -340,6 +352,21 @@ class GenerativeLevyProcess:
         isc = None if isc is None else isc.to(dev)
         hist = [x.clone()] if history else []
         need_z = not (flags & _lib.UPD_DLIM) or eta != 0.0
+        # p_mean_variance (:182-207): EPSILON without clipping bypasses everything (a denoised_fn is then never called, as in
+        # the reference); EPSILON + clip without a denoised_fn is a flag of the update kernel; every other case goes
+        # model output -> x_0 -> [denoised_fn] -> [clamp] -> eps through dlpm_predict_f32
+        clip = bool(flags & _lib.UPD_CLIP)
+        mean_type = _lib.MEAN_TYPES[self.model_mean_type]
+        predict = (mean_type != 0) or (clip and denoised_fn is not None)
+        pa = None
+        if predict:
+            flags &= ~_lib.UPD_CLIP
+            pa = _lib.PredictArgs()
+            pa.t_dev, pa.g_dev, pa.bg_dev, pa.bs_dev = t_dev.data_ptr(), g.data_ptr(), bg.data_ptr(), bs.data_ptr()
+            pa.c_eps_dev, pa.A_dev = c_eps.data_ptr(), A.data_ptr()
+            pa.B, pa.D, pa.T, pa.mean_type = B, D, T, mean_type
+            el = _lib.PRED_ELEMENTWISE if not self.isotropic else 0
+            tail = (_lib.PRED_CLIP if clip else 0) | _lib.PRED_TO_EPS | el
         args = _lib.UpdateArgs()
         args.t_dev, args.g_dev, args.bg_dev, args.bs_dev = t_dev.data_ptr(), g.data_ptr(), bg.data_ptr(), bs.data_ptr()
         args.c_eps_dev, args.c_noise_dev, args.A_dev = c_eps.data_ptr(), c_noise.data_ptr(), A.data_ptr()
@@ -353,8 +380,19 @@ class GenerativeLevyProcess:
             t_dev.fill_(i)
             _lib.check(L.dlpm_fill_scaled_t_f32(tvec.data_ptr(), t_dev.data_ptr(), T, B, st))
             xin = x if isc is None else x * isc[i]
-            eps = model(xin, tvec if self.rescale_timesteps else torch.full((B,), i, device=dev))
+            eps = model(xin, tvec if self.rescale_timesteps else torch.full((B,), i, device=dev), **model_kwargs)
             eps = eps.contiguous().float()
+            if predict:
+                pa.x_dev, pa.in_dev, pa.out_dev = x.data_ptr(), eps.data_ptr(), eps.data_ptr()
+                if denoised_fn is None:
+                    pa.flags = _lib.PRED_TO_XSTART | tail
+                    _lib.check(L.dlpm_predict_f32(C.byref(pa), st))
+                else:
+                    pa.flags = _lib.PRED_TO_XSTART | el
+                    _lib.check(L.dlpm_predict_f32(C.byref(pa), st))
+                    eps = denoised_fn(eps.view(shape)).contiguous().float()
+                    pa.in_dev, pa.out_dev, pa.flags = eps.data_ptr(), eps.data_ptr(), tail
+                    _lib.check(L.dlpm_predict_f32(C.byref(pa), st))
             z = None
             if host and need_z:
                 z = (self._streams().randn(shape) if self.rng == 'reference' else torch.randn(shape)).to(dev)
@@ -419,6 +457,40 @@ class GenerativeLevyProcess:
         if pbar:
             pbar.close()
         return (x, torch.stack(hist)) if history else x
+
+    def _loop(self, model, shape, flags, eta, noise, denoised_fn, model_kwargs, history, progress):
+        from .unet import UNetModel
+        from .mlp import MLPModel
+        if hasattr(model, 'eval'):
+            model.eval()
+        clamp_a = self.dlpm.gen_a.kwargs.get('clamp_a')
+        clamp_eps = self.dlpm.gen_eps.kwargs.get('clamp_eps')
+        native = isinstance(model, (UNetModel, MLPModel)) and self.rescale_timesteps and denoised_fn is None and not model_kwargs
+        with torch.inference_mode():
+            if native:
+                out = self._run_native(model, list(shape), flags, eta, clamp_a, clamp_eps, noise, history, progress)
+            else:
+                out = self._run_callable(model, list(shape), flags, eta, clamp_a, clamp_eps, noise, history, progress,
+                                         denoised_fn=denoised_fn, model_kwargs=model_kwargs)
+        self.calls += 1
+        return out
+
+    def p_sample_loop(self, model, shape, noise=None, clip_denoised=False, denoised_fn=None, model_kwargs=None, progress=False,
+                      get_sample_history=False):
+        """GenerativeLevyProcess.p_sample_loop (:241-289): the stochastic loop with the arguments `sample()` does not pass on --
+        `noise` (x_T), `denoised_fn`, `model_kwargs`.  Clamps are the generators' current ones (set by the last sample())."""
+        assert self.device is not None
+        assert isinstance(shape, (tuple, list))
+        return self._loop(model, shape, _lib.UPD_CLIP if clip_denoised else 0, 0.0, noise, denoised_fn, model_kwargs,
+                          get_sample_history, progress)
+
+    def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=False, denoised_fn=None, model_kwargs=None, progress=False,
+                         eta=0.0, get_sample_history=False):
+        """GenerativeLevyProcess.ddim_sample_loop (:364-403): the DLIM loop."""
+        assert self.device is not None
+        assert isinstance(shape, (tuple, list))
+        return self._loop(model, shape, _lib.UPD_DLIM | (_lib.UPD_CLIP if clip_denoised else 0), eta, noise, denoised_fn,
+                          model_kwargs, get_sample_history, progress)
 
     # -------------------------------------------------------------------------------- BEM: SAMPLING
     def sample(self, models, shape, reverse_steps, time_spacing=None, initial_data=None, clip_denoised=False,

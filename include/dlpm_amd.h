@@ -170,6 +170,41 @@ typedef struct dlpm_update_args {
  * tables, +4 B/element when a history row is written. */
 int dlpm_update_f32(const dlpm_update_args *args, dlpm_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Model mean types (what the net predicts) -- p_mean_variance, GenerativeLevyProcess.py:182-207, ModelMeanType dlpm.py:10-18
+ * ------------------------------------------------------------------------------------------ */
+enum dlpm_mean_type {
+    DLPM_MEAN_EPSILON = 0,    /* the net predicts eps (every shipped config)                                        */
+    DLPM_MEAN_START_X = 1,    /* the net predicts x_0                                                               */
+    DLPM_MEAN_Z = 2,          /* the net predicts z_t: eps = sqrt(A[t,b]) out  (:192-196)                           */
+    DLPM_MEAN_PREVIOUS_X = 3  /* the net predicts the anterior mean: eps = (x - out g_t) / (bs_t Gamma_t)  (dlpm.py:204-209) */
+};
+enum dlpm_predict_flags {
+    DLPM_PRED_TO_XSTART = 1,  /* model output -> x_0 per mean type (EPSILON: predict_xstart, dlpm.py:191-196)       */
+    DLPM_PRED_CLIP = 2,       /* clamp to [-1, 1] (clip_denoised, process_xstart :162-167)                          */
+    DLPM_PRED_TO_EPS = 4,     /* x_0 -> eps = (x - x_0 bg_t) / bs_t  (predict_eps, dlpm.py:198-202)                 */
+    DLPM_PRED_ELEMENTWISE = 16/* non-isotropic: c_eps / A are [T,B,D] (same bit as DLPM_UPD_ELEMENTWISE)            */
+};
+typedef struct dlpm_predict_args {
+    const float *x_dev;       /* [B,D] state x_t                                                                    */
+    const float *in_dev;      /* [B,D] model output, or an x_0 (flags without DLPM_PRED_TO_XSTART)                  */
+    float *out_dev;           /* [B,D] result; may alias in_dev                                                     */
+    const int32_t *t_dev;     /* device scalar: step index t                                                        */
+    const float *g_dev, *bg_dev, *bs_dev;   /* schedule, [T]                                                        */
+    const float *c_eps_dev;   /* [T,B] bs_t Gamma_t from dlpm_coeff_tables_f32 (PREVIOUS_X only)                    */
+    const float *A_dev;       /* [T,B] (Z only)                                                                     */
+    int64_t B, D;
+    int32_t T;
+    int32_t mean_type;        /* dlpm_mean_type                                                                     */
+    int32_t flags;            /* dlpm_predict_flags                                                                 */
+} dlpm_predict_args;
+/* The part of p_mean_variance between the model call and anterior_mean_variance_*: out = stages(in) in the order
+ * TO_XSTART -> CLIP -> TO_EPS.  A caller with a `denoised_fn` runs TO_XSTART, applies its function, then CLIP | TO_EPS;
+ * without one all three stages are one launch.  The reference indexes A[t] / Sigmas[t] with the [B] tensor t in the Z and
+ * PREVIOUS_X branches, which only has the intended per-sample meaning for B = 1 (it raises for B > 1); here row t,
+ * column b is used, i.e. the B = 1 result for every sample.  HBM-bound: 12 B/element. */
+int dlpm_predict_f32(const dlpm_predict_args *args, dlpm_stream_t stream);
+
 /* tvec_dev[b] = float(*t_dev) * (1/T): the `t/T` the reference feeds the net
  * (GenerativeLevyProcess._scale_timesteps, :92-96). */
 int dlpm_fill_scaled_t_f32(float *tvec_dev, const int32_t *t_dev, int32_t T, int64_t B, dlpm_stream_t stream);
@@ -418,6 +453,8 @@ typedef struct dlpm_sampler_config {
      * (ts[T], the others [T-1]), or all NULL = computed by it */
     const float *lim_ts, *lim_tmp, *lim_cx, *lim_cs, *lim_cn;
     const float *in_scale;      /* optional host table [T]: the net sees x * in_scale[t] (input_scaling), NULL = x */
+    int32_t mean_type;          /* dlpm_mean_type: what the net predicts (0 = eps); other types run dlpm_predict_f32 between
+                                   the net and the update inside the captured step                                  */
 } dlpm_sampler_config;
 
 typedef struct dlpm_sampler dlpm_sampler;

@@ -85,6 +85,35 @@ def clipped_eps(x, eps, t, bg, bs):
     return (x - xs * bg[t]) / bs[t]
 
 
+def model_eps(x, out, t, mean_type, clip, denoised_fn, g, bg, bs, Sig=None, A=None):
+    """p_mean_variance between the model call and anterior_mean_variance_* (GenerativeLevyProcess.py:182-207):
+    EPSILON without clipping bypasses everything (a denoised_fn is then never called); otherwise the output becomes x_0
+    per mean type, goes through process_xstart (denoised_fn, then clamp) and back to eps (predict_eps, dlpm.py:198-202).
+    Z / PREVIOUS_X index A[t] / Sigmas[t] with the [B] tensor t in the reference, which raises for every B (shape
+    [B,B,...] against [B,...]); the per-sample reading -- the same helpers called with an integer t
+    (predict_eps_from_m_tilde, dlpm.py:204-209) -- is restated here and pinned by tests/golden/f12_mean_types.npz."""
+    if mean_type == 'EPSILON' and not clip:
+        return out
+    if mean_type == 'START_X':
+        xs = out
+    else:
+        if mean_type == 'EPSILON':
+            e = out
+        elif mean_type == 'Z':
+            e = torch.sqrt(_b(A[t], x)) * out
+        elif mean_type == 'PREVIOUS_X':
+            Gam, _ = gamma_var(t, Sig, g)
+            e = (x - out * g[t]) / (bs[t] * _b(Gam, x))
+        else:
+            raise NotImplementedError(mean_type)
+        xs = (x - e * bs[t]) / bg[t]
+    if denoised_fn is not None:
+        xs = denoised_fn(xs)
+    if clip:
+        xs = xs.clamp(-1, 1)
+    return (x - xs * bg[t]) / bs[t]
+
+
 def generation_postprocess(x, is_image):
     """bem/GenerationManager.py:50-63 + bem/datasets/__init__.py:108-109."""
     c = 1.0 if is_image else 6.0

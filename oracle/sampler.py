@@ -41,8 +41,9 @@ class Streams:
 
 def sample(model, shape, T, alpha, streams, deterministic=False, dlim_eta=0.0, clip_denoised=False,
            clamp_a=None, clamp_eps=None, get_sample_history=False, trace=None, isotropic=True,
-           scale='scale_preserving', input_scaling=False):
+           scale='scale_preserving', input_scaling=False, mean_type='EPSILON', denoised_fn=None, model_kwargs=None, noise=None):
     B = shape[0]
+    model_kwargs = model_kwargs or {}
     n = B if isotropic else int(np.prod(shape))
     g, bg, s, bs = P.schedule(T, alpha, scale)
     A = torch.stack([streams.skewed_levy(alpha, n, clamp_a) for _ in range(T)])    # dlpm.py:226-227
@@ -50,21 +51,23 @@ def sample(model, shape, T, alpha, streams, deterministic=False, dlim_eta=0.0, c
         A = A.reshape([T] + list(shape))
     Sig = P.sigma_table(A, g, s)                                                    # dlpm.py:230-239
     # x_T: GenerativeLevyProcess.py:313 -> gen_sas (own unclamped a, then randn, then clamp_eps)
-    a0 = streams.skewed_levy(alpha, n, None)
-    a0 = P._b(a0, torch.empty(shape)) if isotropic else a0.reshape(shape)
-    e = torch.sqrt(a0) * streams.randn(shape)
-    if clamp_eps is not None:
-        e = torch.clamp(e, -clamp_eps, clamp_eps)
-    x = bs[-1] * e
+    if noise is not None:                                                           # :311-312: a given x_T draws nothing
+        x = noise
+    else:
+        a0 = streams.skewed_levy(alpha, n, None)
+        a0 = P._b(a0, torch.empty(shape)) if isotropic else a0.reshape(shape)
+        e = torch.sqrt(a0) * streams.randn(shape)
+        if clamp_eps is not None:
+            e = torch.clamp(e, -clamp_eps, clamp_eps)
+        x = bs[-1] * e
     hist = [x]
     if trace is not None:
         trace.update(A=A, Sigmas=Sig, xT=x, z=[])
     for i in range(T - 1, 0, -1):
         t = torch.full((B,), i, dtype=torch.int64)
         xin = x * (1 / (1 + bs[i])) if input_scaling else x                         # :176-179 (scale_exploding only)
-        eps = model(xin, t.float() * (1.0 / T))                                     # :92-96,180
-        if clip_denoised:
-            eps = P.clipped_eps(x, eps, i, bg, bs)
+        eps = model(xin, t.float() * (1.0 / T), **model_kwargs)                     # :92-96,180
+        eps = P.model_eps(x, eps, i, mean_type, clip_denoised, denoised_fn, g, bg, bs, Sig=Sig, A=A)   # :182-207
         if deterministic:
             z = streams.randn(shape) if dlim_eta != 0.0 else None
             x = P.dlim_step(x, eps, i, g, bs, eta=dlim_eta, alpha=alpha, A=A, z=z)

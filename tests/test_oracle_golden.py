@@ -119,6 +119,54 @@ def test_single_step_formulas():
         assert np.array_equal(P.clipped_eps(x, eps, t, bg, bs).numpy(), f['eps_from_clipped_xstart_t%d' % t])
 
 
+# ---------------------------------------------------------------- F12: p_mean_variance beyond eps-prediction
+def f12_dfn(v):
+    return 0.875 * v + 0.03125
+
+
+class StartXKw:
+    def __call__(self, x, t, shift=0.0):
+        return 0.25 * x + shift * (1.0 - t.view(-1, *([1] * (x.dim() - 1))))
+
+
+class SynthKw:
+    def __call__(self, x, t, shift=0.0):
+        return 0.5 * x + t.view(-1, *([1] * (x.dim() - 1))) + shift
+
+
+def test_mean_type_single_steps():
+    """GenerativeLevyProcess.py:182-207 for every mean type x clip x denoised_fn: eps bit-exact, then the step."""
+    f = golden('f12_mean_types')
+    A, g, bg, s, bs = (T_(f[k]) for k in ['A', 'g', 'bg', 's', 'bs'])
+    x, out = T_(f['x']), T_(f['out']) + float(f['shift'])
+    Sig = P.sigma_table(A, g, s)
+    for mt in ('EPSILON', 'START_X', 'Z', 'PREVIOUS_X'):
+        for t in (1, 2, 17, 49):
+            for clip in (0, 1):
+                for fn in (0, 1):
+                    key = '%s_t%d_clip%d_fn%d' % (mt, t, clip, fn)
+                    eps = P.model_eps(x, out, t, mt, bool(clip), f12_dfn if fn else None, g, bg, bs, Sig=Sig, A=A)
+                    assert np.array_equal(eps.numpy(), f['eps_' + key]), key
+                    _, mean, var = P.dlpm_step(x, eps, t, Sig, g, bs, torch.zeros_like(x))
+                    assert np.array_equal(mean.numpy(), f['mean_' + key]), key
+                    assert np.array_equal(var.numpy(), f['var_' + key]), key
+
+
+@pytest.mark.parametrize('name', ['f12_traj_startx', 'f12_traj_startx_dlim_noise', 'f12_traj_eps_fn'])
+def test_mean_type_loops_same_seeds(name):
+    """p_sample_loop / ddim_sample_loop with noise, denoised_fn and model_kwargs (:241-330, 364-452) on identical seeds."""
+    f = golden(name)
+    T, alpha, ddim, clip, fn, noise = f['meta']
+    shape = [int(v) for v in f['shape']]
+    model = SynthKw() if 'eps' in name else StartXKw()
+    x, hist = sampler.sample(model, shape, int(T), float(alpha), sampler.Streams(0, 0), deterministic=bool(ddim), dlim_eta=0.0,
+                             clip_denoised=bool(clip), get_sample_history=True, mean_type='EPSILON' if 'eps' in name else 'START_X',
+                             denoised_fn=f12_dfn if fn else None, model_kwargs=dict(shift=0.5), noise=T_(f['xT']) if noise else None)
+    want = f['history']
+    scale = np.abs(want).max(axis=tuple(range(1, want.ndim)), keepdims=True) + 1e-6
+    assert np.max(np.abs(hist.numpy() - want) / scale) < 2e-5
+
+
 # ---------------------------------------------------------------- F5
 class Synth:
     def __call__(self, x, t):

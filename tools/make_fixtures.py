@@ -18,6 +18,7 @@ Fixture families:
   F7 layers              GroupNorm32, QKVAttention, embedding...  dlpm/models/unet.py, nn.py
   F8 generation manager  clamp + inverse affine                   bem/GenerationManager.py:29-63
   F10 LIM sampler        VPSDE, LIM_sampler sde/ode updates        dlpm/methods/LIM/functions/{sde,sampler}.py
+  F12 mean types         p_mean_variance: START_X / Z / PREVIOUS_X, denoised_fn, model_kwargs   GenerativeLevyProcess.py:154-219
   F11 image quantisation PIL's float -> 8-bit path (torchvision absent)  bem/evaluate/EvaluationManager.py:188-190
   F9 checkpoints         TrainingManager.save/load, EMAHelper,    bem/TrainingManager.py:240-285, bem/utils_ema.py,
                          FileHandler path hashing                 bem/utils_exp.py:52-151, dlpm/dlpm_experiment.py:11-19
@@ -212,6 +213,104 @@ def f4_single_step():
         arrs['xstart_t%d' % t] = xs
         arrs['eps_from_clipped_xstart_t%d' % t] = d.predict_eps(x, torch.full((4,), t), xs.clamp(-1, 1))
     save('f4_single_step', **arrs)
+
+
+def f12_dfn(v):
+    # the denoised_fn of the F12 fixtures: one exactly-rounded multiply and add (identical on CPU and GPU)
+    return 0.875 * v + 0.03125
+
+
+class StartXModel(torch.nn.Module):
+    # x_0 prediction with a conditioning keyword: exercises `model_kwargs` (GenerativeLevyProcess.py:180)
+    def forward(self, x, t, shift=0.0):
+        return 0.25 * x + shift * (1.0 - t.view(-1, *([1] * (x.dim() - 1))))
+
+
+def f12_mean_types():
+    """p_mean_variance beyond eps-prediction (GenerativeLevyProcess.py:154-219): START_X, Z, PREVIOUS_X, denoised_fn,
+    model_kwargs.  The constructor asserts EPSILON (:74-77), so `model_mean_type` is assigned afterwards.  START_X (and
+    EPSILON with a denoised_fn) run through the reference's own p_mean_variance / p_sample_loop.  Z and PREVIOUS_X raise an
+    AssertionError there for EVERY batch size (A[t] / Sigmas[t] indexed with the [B] tensor t give [B,B,...] against
+    [B,...], predict_xstart's shape assert, dlpm.py:192): their single steps are composed from the reference's own helpers
+    with an integer t -- sqrt(A[t]) * out, compute_Gamma_t + the formula line of predict_eps_from_m_tilde, predict_xstart,
+    predict_eps, anterior_mean_variance_dlpm -- which is the per-sample reading of those branches."""
+    T, shape, alpha = 50, [4, 3, 4, 4], 1.7
+    np.random.seed(5)
+    torch.manual_seed(5)
+    meth = GenerativeLevyProcess(alpha=alpha, device='cpu', reverse_steps=T, rescale_timesteps=True)
+    d = meth.dlpm
+    d.sample_A(shape, T)
+    d.compute_Sigmas()
+    x = torch.randn(shape) * 3
+    out = torch.randn(shape)
+    arrs = dict(A=d.A[:, :, 0, 0, 0], g=d.gammas, bg=d.bargammas, s=d.sigmas, bs=d.barsigmas, x=x, out=out,
+                shift=np.float32(0.25))
+
+    def model(xx, tt, shift=0.0):
+        return out + shift
+
+    for mt in ['EPSILON', 'START_X', 'Z', 'PREVIOUS_X']:
+        meth.model_mean_type = mt
+        for t in [1, 2, 17, 49]:
+            for clip in (0, 1):
+                for use_fn in (0, 1):
+                    fn = f12_dfn if use_fn else None
+                    key = '%s_t%d_clip%d_fn%d' % (mt, t, clip, use_fn)
+                    if mt in ('EPSILON', 'START_X'):
+                        r = meth.p_mean_variance(model, x, torch.full((shape[0],), t), clip_denoised=bool(clip), denoised_fn=fn,
+                                                 model_kwargs=dict(shift=0.25))
+                        eps, mean, var = r['eps'], r['mean'], r['variance']
+                    else:
+                        o = model(x, None, shift=0.25)
+                        if mt == 'Z':
+                            e0 = torch.sqrt(d.A[t]) * o                                      # GenerativeLevyProcess.py:193
+                        else:
+                            # predict_eps_from_m_tilde (dlpm.py:204-209) turns even an integer t into a [B] tensor before
+                            # indexing Sigmas, so its one formula line (:208) is evaluated here on the reference's own
+                            # tensors, Gamma_t from compute_Gamma_t exactly as anterior_mean_variance_dlpm obtains it (:274)
+                            gg, _, _, bbs = d.update_constants(o.shape)
+                            Gam = d.compute_Gamma_t(t, d.Sigmas[t - 1], d.Sigmas[t])
+                            e0 = (x - o * gg[t]) / (bbs[t] * Gam)
+                        xs = d.predict_xstart(x, t, e0)
+                        if fn is not None:
+                            xs = fn(xs)
+                        if clip:
+                            xs = xs.clamp(-1, 1)
+                        eps = d.predict_eps(x, t, xs)
+                        mean, var = d.anterior_mean_variance_dlpm(x, torch.tensor(t), eps)
+                    arrs['eps_' + key], arrs['mean_' + key], arrs['var_' + key] = eps, mean, var[:, 0, 0, 0]
+    save('f12_mean_types', **arrs)
+
+    # whole loops through the reference's p_sample_loop / ddim_sample_loop with the arguments sample() does not pass on
+    net = StartXModel()
+    for name, ddim, clip, fn, noise in [('f12_traj_startx', False, True, f12_dfn, False),
+                                        ('f12_traj_startx_dlim_noise', True, False, None, True),
+                                        ('f12_traj_eps_fn', False, True, f12_dfn, False)]:
+        np.random.seed(0)
+        torch.manual_seed(0)
+        T2, shp = 30, [4, 3, 4, 4]
+        m2 = GenerativeLevyProcess(alpha=1.7, device='cpu', reverse_steps=T2, rescale_timesteps=True)
+        m2.model_mean_type = 'EPSILON' if 'eps' in name else 'START_X'
+        x_T = torch.randn(shp) * 2 if noise else None
+        mod = SynthKw() if 'eps' in name else net
+        with _Recorder() as rec:
+            if ddim:
+                xf, hist = m2.ddim_sample_loop(mod, shp, noise=x_T, clip_denoised=clip, denoised_fn=fn, model_kwargs=dict(shift=0.5),
+                                               eta=0.0, get_sample_history=True)
+            else:
+                xf, hist = m2.p_sample_loop(mod, shp, noise=x_T, clip_denoised=clip, denoised_fn=fn, model_kwargs=dict(shift=0.5),
+                                            get_sample_history=True)
+        arrs = dict(final=xf, history=hist, A=m2.dlpm.A[:, :, 0, 0, 0], xT=hist[0], shape=np.array(shp),
+                    meta=np.array([T2, 1.7, float(ddim), float(clip), float(fn is not None), float(noise)]))
+        if rec.z:
+            arrs['z'] = torch.stack(rec.z)
+        save(name, **arrs)
+
+
+class SynthKw(torch.nn.Module):
+    # eps prediction with a conditioning keyword
+    def forward(self, x, t, shift=0.0):
+        return 0.5 * x + t.view(-1, *([1] * (x.dim() - 1))) + shift
 
 
 class _Recorder:
@@ -730,8 +829,8 @@ def f10_lim():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f11', 'f1', 'f2', 'f3', 'f4', 'f5', 'f5u', 'f5w', 'f5k', 'f5c', 'f6', 'f7', 'f8', 'f9', 'f10']
-    table = dict(f11=f11_image_quantise, f10=f10_lim, f1=f1_schedule, f2=f2_noise, f3=f3_tables, f4=f4_single_step, f5=f5_trajectories, f5u=f5_unet_trajectory, f5w=f5_wide_unet_trajectory, f5k=f5_unet_trajectories_T1000, f5c=f5_cifar_teacher_forced,
+    which = sys.argv[1:] or ['f11', 'f1', 'f2', 'f3', 'f4', 'f5', 'f5u', 'f5w', 'f5k', 'f5c', 'f6', 'f7', 'f8', 'f9', 'f10', 'f12']
+    table = dict(f12=f12_mean_types, f11=f11_image_quantise, f10=f10_lim, f1=f1_schedule, f2=f2_noise, f3=f3_tables, f4=f4_single_step, f5=f5_trajectories, f5u=f5_unet_trajectory, f5w=f5_wide_unet_trajectory, f5k=f5_unet_trajectories_T1000, f5c=f5_cifar_teacher_forced,
                  f6=f6_models, f7=f7_layers, f8=f8_generation_manager, f9=f9_checkpoints)
     with torch.no_grad():
         for w in which:
