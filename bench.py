@@ -89,41 +89,97 @@ def parse_prof(txt):
     return out
 
 
-def cpu_baseline(cfg_name, T, alpha, budget_s=20.0):
-    """The oracle (a torch-CPU port of the reference loop) on this box's host cores, bounded sample."""
-    from oracle import nets, sampler as osampler
+def cpu_baseline(cfg_name, T, alpha, B=32, steps=21, warm=2):
+    """The oracle (a torch-CPU port of the reference loop) on this box's host cores -- SURVEY.md 8d / BASELINE.md 4:
+    B = 32, the real T-step schedule and tables, `warm` untimed reverse steps, then `steps` >= 20 reverse steps timed ONE BY ONE;
+    the figure is built from the MEDIAN step (and the three 7-step thirds are printed, to show the spread).  Both data
+    layouts are timed on the same steps: "reference-faithful" (full-size [T,B,C,H,W] A / Sigma tensors, the schedule
+    re-broadcast by `repeat` twice per step: what the reference executes, and the reported `value`) and "scalar-table"
+    ([T,B] tables); the network forward is common to both.  The table set-up (A expansion + Sigma recursion) is timed
+    once per layout and enters the trajectory figure.  Plus the C++ host library's noise streams (1 core)."""
+    import numpy as np
+    from oracle import nets, sampler as osampler, process as P
     import dlpm_amd
+    from dlpm_amd import _lib
     p = dlpm_amd.load_config(cfg_name)
     torch.manual_seed(1234)
     net = dlpm_amd.rerandomize_(dlpm_amd.init_model_by_parameter(p), 4321)
     sd = {k: v.detach() for k, v in net.state_dict().items()}
     heads = p['model']['num_heads']
-    B, steps = 8, 4
     shape = [B, p['data']['channels'], p['data']['image_size'], p['data']['image_size']]
-    g = torch.Generator().manual_seed(0)
     model = lambda x, t: nets.unet_forward(sd, x, t, heads)
     cores = torch.get_num_threads()
+    ev = p['eval']['dlpm']
     with torch.inference_mode():
-        x = torch.randn(shape, generator=g)
-        t0 = time.time()
-        model(x, torch.full((B,), 0.5))           # warm-up + cost probe
-        probe = time.time() - t0
-        steps = max(2, min(64, int(budget_s / max(probe, 1e-3))))
-        Tshort = steps + 1
-        A = torch.rand(Tshort, B, generator=g) + 0.5
-        zs = [torch.randn(shape, generator=g) for _ in range(steps)]
-        t0 = time.time()
-        osampler.sample_with_tables(model, shape, Tshort, alpha, A, x, zs)
-        dt = time.time() - t0
-    per_step = dt / steps
-    return dict(value=B / (per_step * (T - 1)), unit='samples/s at T=1000', cores=cores, kind='port',
-                sample='oracle (torch-CPU port of the reference loop), same UNet, B=%d, %d reverse steps timed '
-                       '(%.1f s), extrapolated linearly to 999 steps' % (B, steps, dt))
+        streams = osampler.Streams(0, 0)
+        g, bg, s_, bs = P.schedule(T, alpha)
+        t0 = time.perf_counter()
+        A = torch.stack([streams.skewed_levy(alpha, B, ev['clamp_a']) for _ in range(T)])
+        draw_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        Sig = P.sigma_table(A, g, s_)
+        init_scalar = draw_s + time.perf_counter() - t0
+        t0 = time.perf_counter()
+        Af, Sigf = osampler.full_size_tables(A, shape, g, s_)
+        init_full = draw_s + time.perf_counter() - t0
+        del Af
+        x = bs[-1] * torch.clamp(torch.sqrt(streams.skewed_levy(alpha, B, None)).view(-1, 1, 1, 1) * streams.randn(shape),
+                                 -ev['clamp_eps'], ev['clamp_eps'])
+        net_t, full_t, scal_t = [], [], []
+        i = T - 1
+        for k in range(warm + steps):
+            t0 = time.perf_counter()
+            eps = model(x, torch.full((B,), i, dtype=torch.int64).float() * (1.0 / T))
+            z = streams.randn(shape)                          # th.randn_like in p_sample: part of the reference's step
+            t1 = time.perf_counter()
+            xf = osampler.full_size_step(x, eps, i, Sigf, g, bs, z)
+            t2 = time.perf_counter()
+            xs, _, _ = P.dlpm_step(x, eps, i, Sig, g, bs, z)
+            t3 = time.perf_counter()
+            assert torch.equal(xf, xs)
+            x, i = xf, i - 1
+            if k >= warm:
+                net_t.append(t1 - t0); full_t.append(t2 - t1); scal_t.append(t3 - t2)
+        net_t, full_t, scal_t = np.array(net_t), np.array(full_t), np.array(scal_t)
+        # the C++ host library (libdlpm_amd's parity streams, one core): seconds of noise per B=32 trajectory
+        L = _lib.lib()
+        mt = _lib.MT19937()
+        _lib.check(L.dlpm_mt19937_seed(C.byref(mt), 0))
+        nz, na = 1 << 21, 1 << 17
+        buf = np.empty(nz, np.float32)
+        t0 = time.perf_counter()
+        _lib.check(L.dlpm_randn_host_f32(C.byref(mt), nz, buf.ctypes.data))
+        randn_rate = nz / (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        _lib.check(L.dlpm_skewed_levy_host_f32(C.byref(mt), float(alpha), na, -1.0, buf.ctypes.data))
+        levy_rate = na / (time.perf_counter() - t0)
+    D = shape[1] * shape[2] * shape[3]
+    med_full, med_scal = float(np.median(net_t + full_t)), float(np.median(net_t + scal_t))
+    thirds = [round(float(np.median((net_t + full_t)[j::3])), 4) for j in range(3)]
+    traj_full, traj_scal = init_full + (T - 1) * med_full, init_scalar + (T - 1) * med_scal
+    return dict(value=round(B / traj_full, 6), unit='samples/s at T=1000', cores=cores, kind='port',
+                sample='oracle (torch-CPU port of the reference loop), same UNet and schedule, B=%d, %d untimed + %d timed reverse '
+                       'steps (t = %d..%d) on %d torch threads; value = B / (table set-up + 999 x MEDIAN step) in the reference\'s '
+                       'full-size [T,B,C,H,W] layout' % (B, warm, steps, T - 1 - warm, T - warm - steps, cores),
+                median_step_s=round(med_full, 4), median_step_s_interleaved_thirds=thirds,
+                step_s_min_max=[round(float((net_t + full_t).min()), 4), round(float((net_t + full_t).max()), 4)],
+                network_share_of_step=round(float(np.median(net_t)) / med_full, 4),
+                table_setup_s=round(init_full, 3), timed_cpu_seconds=round(float((net_t + full_t + scal_t).sum()), 1),
+                scalar_table_variant=dict(value=round(B / traj_scal, 6), median_step_s=round(med_scal, 4), table_setup_s=round(init_scalar, 3),
+                                          note='[T,B] tables instead of [T,B,C,H,W]: same arithmetic per element, same bits'),
+                host_library=dict(randn_per_s=round(randn_rate), skewed_levy_per_s=round(levy_rate), cores=1,
+                                  noise_seconds_per_trajectory=round(T * B * D / randn_rate + (T + 1) * B / levy_rate, 2),
+                                  note='libdlpm_amd C++ parity streams (MT19937 -> torch-compatible randn, scipy-compatible CMS): the '
+                                       'noise of one B=%d, T=%d trajectory' % (B, T)))
 
 
-def spawn_ranks(n, argv):
-    """`bench.py --gpus N` started plainly: launch the N ranks as children.  This process has not initialised the GPU
-    (importing torch does not), and it never execs: it waits and hands the children's exit code on."""
+def spawn_ranks(n, argv, timeout_s=None):
+    """`bench.py --gpus N` started plainly: launch the N ranks as FRESH children.  This process has not initialised the GPU
+    (importing torch does not), and it never execs: it waits and hands the children's exit code on.  A rank that dies
+    mid-trajectory leaves its peers in a barrier: torch.distributed.run notices the dead worker, terminates the others
+    and exits non-zero; should that ever not happen, the deadline (--rank-timeout, default 2 h) ends the children's own
+    process group -- never a pattern kill -- and the parent exits 124."""
+    import signal
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
@@ -132,7 +188,25 @@ def spawn_ranks(n, argv):
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', '8')
-    return subprocess.run(cmd, env=env).returncode
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)      # its own process group: the only thing ever signalled
+    try:
+        return child.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write('bench.py: ranks still running after %.0f s -- terminating process group %d\n' % (timeout_s, child.pid))
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(child.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=20)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return 124
+    except KeyboardInterrupt:
+        os.killpg(child.pid, signal.SIGTERM)
+        raise
 
 
 class NativeRunner:
@@ -192,6 +266,12 @@ class DryRunner:
         self.t = 0
 
     def steps(self, n):
+        # test hooks: a rank that dies / hangs in the middle of the trajectory
+        die = os.environ.get('DLPM_BENCH_DIE_RANK')
+        if die is not None and int(die) == self.rank and self.t + n > int(os.environ.get('DLPM_BENCH_DIE_AT', '0')):
+            if os.environ.get('DLPM_BENCH_DIE_MODE') == 'hang':
+                time.sleep(3600)
+            os._exit(17)
         self.t += n
         time.sleep(1e-4 * n)
 
@@ -263,13 +343,15 @@ def main():
                     help='dlpm_unet_set_conv_policy dispatch batch (default: the per-GPU batch of the workload\'s BASELINE config; 0: geometry only)')
     ap.add_argument('--non-iso', action='store_true',
                     help='non-isotropic noise variant (--non_iso of the reference): [T,B,D] tables; not the headline config')
+    ap.add_argument('--rank-timeout', type=float, default=7200.0,
+                    help='N > 1 started plainly: seconds after which the parent ends its ranks (their own process group) and exits 124')
     ap.add_argument('--lim', action='store_true',
                     help='LIM sampler variant (--method lim of the reference, SDE updates): T network evaluations; '
                          'not the headline config')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], args.rank_timeout))
 
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))

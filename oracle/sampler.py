@@ -97,3 +97,43 @@ def sample_with_tables(model, shape, T, alpha, A, xT, zs, clip_denoised=False):
         x, _, _ = P.dlpm_step(x, eps, i, Sig, g, bs, zs[k])
         k += 1
     return x
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The reference's own data layout, for the CPU baseline of bench.py (SURVEY.md 8d "reference-faithful" variant): A and
+# Sigma as full-size [T,B,C,H,W] tensors, the schedule re-broadcast to [T,C,H,W] by `repeat` TWICE per step (the
+# update_constants cache compares a tuple of tensors' shape with a torch.Size and misses every time it is asked for a
+# different shape: compute_Gamma_t asks with Sigma's shape, anterior_mean_variance_dlpm with x's -- dlpm.py:171-174,
+# 250-254, 272-278), full-size element-wise arithmetic.  Bit-identical to the scalar-table functions above.
+# ------------------------------------------------------------------------------------------------------------------
+def match_last_dims(data, size):
+    """dlpm.py:47-51."""
+    for _ in range(len(size) - 1):
+        data = data.unsqueeze(-1)
+    return data.repeat(1, *(size[1:]))
+
+
+def full_size_tables(A_tb, shape, g, s):
+    """sample_A's expand (Distributions.py:45-46: one draw per sample, expanded and copied to the state's shape) and
+    compute_Sigmas (dlpm.py:230-239) over the full-size tensors: T sequential passes over [B,C,H,W]."""
+    T = A_tb.shape[0]
+    A = torch.stack([A_tb[k].view(-1, *([1] * (len(shape) - 1))).expand(shape).clone() for k in range(T)])
+    G = match_last_dims(g, shape)
+    S = match_last_dims(s, shape)
+    Sig = [S[0] ** 2 * A[0]]
+    for t in range(1, T):
+        Sig.append(S[t] ** 2 * A[t] + G[t] ** 2 * Sig[-1])
+    return A, torch.stack(Sig)
+
+
+def full_size_step(x, eps, i, Sig, g, bs, z):
+    """p_mean_variance's tail + p_sample with the reference's tensors (GenerativeLevyProcess.py:208-239, dlpm.py:250-278)."""
+    shape = list(x.shape)
+    G1 = match_last_dims(g, shape)                                   # compute_Gamma_t -> update_constants (miss)
+    Gam = 1 - (G1[i] ** 2 * Sig[i - 1]) / Sig[i]
+    G2, BS = match_last_dims(g, shape), match_last_dims(bs, shape)   # anterior_mean_variance_dlpm -> update_constants (miss)
+    t = torch.full((shape[0],), i, dtype=torch.int64)
+    mean = (x - BS[t] * Gam * eps) / G2[t]
+    var = Gam * Sig[i - 1]
+    mask = (t != 1).float().view(-1, *([1] * (len(shape) - 1)))
+    return mean + mask * torch.sqrt(var) * z

@@ -92,3 +92,35 @@ def test_bench_spawns_its_own_ranks_and_propagates_failure():
     # a rank that dies (more steps than exist -> assertion in every rank) must surface as a non-zero exit code
     r, out = _run_bench({'DLPM_BENCH_DRY_RUN': '1'}, '--gpus', '2', '--steps', '5000', '--warmup', '0')
     assert r.returncode != 0 and not out
+
+
+@pytest.mark.parametrize('workload,per_gpu', [('cifar10_unet_b1024_T1000', 1024), ('celeba64_unet_b256_T1000', 256)])
+def test_bench_eight_rank_control_flow_of_the_driver_commands(workload, per_gpu):
+    """BASELINE configs 4 and 5 as the driver would launch them (`bench.py --gpus 8 [--workload ...]`), unattended: eight
+    spawned ranks, gloo, stub sampler (DLPM_BENCH_DRY_RUN) -- rendezvous, barriers, max-over-ranks, ONE all-gather of the
+    per-GPU shards, one JSON line whose batch is 8 x the per-GPU batch of the workload."""
+    r, out = _run_bench({'DLPM_BENCH_DRY_RUN': '1', 'OMP_NUM_THREADS': '1'}, '--gpus', '8', '--steps', '4', '--warmup', '1',
+                        '--workload', workload, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(out) == 1, r.stdout
+    j = out[0]
+    assert j['n_gpus'] == 8 and j['scaling'] == 'weak' and j['config']['global_batch'] == 8 * per_gpu
+    assert j['config']['workload'] == workload and j['config']['allgather_ms'] is not None and j['samples_finite']
+    assert j['full_trajectory_s'] is not None
+
+
+def test_bench_rank_dying_mid_trajectory_fails_the_parent_within_the_deadline():
+    """A rank that exits in the middle of the trajectory (its peers are left in a barrier) makes the parent exit non-zero
+    -- promptly, through torch.distributed.run -- and a rank that HANGS is ended by the parent's deadline (exit 124);
+    only the children's own process group is ever signalled."""
+    import time
+    env = {'DLPM_BENCH_DRY_RUN': '1', 'DLPM_BENCH_DIE_RANK': '1', 'DLPM_BENCH_DIE_AT': '40', 'OMP_NUM_THREADS': '1'}
+    t0 = time.time()
+    r, out = _run_bench(env, '--gpus', '2', '--steps', '5', '--warmup', '2', '--batch', '4', '--rank-timeout', '200', timeout=400)
+    assert r.returncode not in (0, 124) and not out, (r.returncode, r.stdout)
+    assert time.time() - t0 < 150
+    env['DLPM_BENCH_DIE_MODE'] = 'hang'
+    t0 = time.time()
+    r, out = _run_bench(env, '--gpus', '2', '--steps', '5', '--warmup', '2', '--batch', '4', '--rank-timeout', '25', timeout=400)
+    assert r.returncode == 124 and not out, (r.returncode, r.stdout)
+    assert time.time() - t0 < 120
