@@ -19,6 +19,7 @@ struct ConvLaunch {
     const void *w_split = nullptr; // optional: the weights as three bf16 planes in stage-tile order (conv_split.hip); a 3x3 launch
                                    // that carries it is a stride-2 downsampling convolution, or a test forcing the path
     const float *w_small = nullptr;// optional, 3x3 with Cout <= 4 (the head): [tap][Cin][4] for k_conv3x3_head
+    const float *w_taps = nullptr; // optional, 3x3 with Cout <= 3 (the head): [9 Cout -> 32][Cin], the head as a 1x1 GEMM + gather (launch_conv_head_gemm)
     const float *bias = nullptr;   // [Cout] or null
     const float *coefA = nullptr, *coefB = nullptr;  // [B, Cin] fused GroupNorm affine, or null
     int act_silu = 0;
@@ -69,6 +70,13 @@ struct HeadUpdate {
 bool head_conv_ok(const ConvLaunch &c);
 int launch_conv_head(const ConvLaunch &c, const HeadUpdate *hu, hipStream_t st);
 int relayout_weight_head(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st);
+// the head as a 1x1 GEMM onto 9 Cout (padded to 32) tap channels + a 9-point gather that also carries the update (conv_direct.hip);
+// P = scratch of head_gemm_scratch_floats(c) floats
+bool head_gemm_ok(const ConvLaunch &c);
+int head_taps_rows(int Cout);
+int64_t head_gemm_scratch_floats(const ConvLaunch &c);
+int launch_conv_head_gemm(const ConvLaunch &c, const HeadUpdate *hu, float *P, hipStream_t st);
+int relayout_weight_head_taps(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st);
 // Winograd F(2x2,3x3) path (conv_wino.hip)
 bool wino_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg);
 int wino_tiles(const ConvLaunch &c);   // 2x2 output tiles per workgroup (64 or 32)

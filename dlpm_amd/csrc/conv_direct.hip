@@ -210,6 +210,101 @@ __global__ void __launch_bounds__(128) k_conv3x3_head(ConvLaunch p, HeadUpdate u
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Head convolution as a GEMM plus a gather (round 3; k_conv3x3_head above stays as the fallback for shapes this does not take).
+//
+// y[p, co] = b[co] + sum_tap sum_ci act(x)[p + off(tap), ci] w[co, ci, tap]  =  b[co] + sum_tap P[p + off(tap), tap * Cout + co]
+// with P = act(x) W',  W'[ci][n = tap * Cout + co] = w[co, ci, tap]:  a 1x1 convolution with 9 Cout (27, padded to 32) output
+// channels -- the fp32 MFMA kernel with the fused GroupNorm affine + SiLU, every input line fetched exactly once, 27 of 32 MFMA
+// columns live -- followed by a 9-point gather-add over P.  (k_conv3x3_head stages the 128-channel input in 8-channel chunks:
+// 32 bytes of every 128-byte line per pass, 4x the input in HBM/MALL traffic, 0.42 ms for a 0.09-ms read; as an N = 32 MFMA
+// tile of the 3x3 implicit GEMM 29 of 32 columns were empty.)  Zero padding applies to the ACTIVATED input, i.e. taps whose source
+// pixel lies outside the image are simply absent from the sum.
+//
+// The gather kernel is the sampler's fused update kernel: it reads P (4 * 9 Cout B per pixel) and x, applies
+// x <- (x - c_eps eps) / gamma + c_noise z with the Philox counters of k_update_rows (a thread owns four consecutive pixels of
+// one row = element quads of the NCHW state), and writes x: eps never reaches HBM.  HBM-bound.
+// ---------------------------------------------------------------------------------------------
+constexpr int HG_LD = 33;   // LDS words per halo pixel (odd: the 9 Cout values of neighbouring pixels fall into different banks)
+
+template <int COUT>
+__global__ void __launch_bounds__(256) k_head_gather(const float *__restrict__ P, int Np, const float *__restrict__ bias, float *out,
+                                                     int out_nchw, HeadUpdate u, int B, int H, int W, int TH) {
+    extern __shared__ __attribute__((aligned(16))) float hg[];
+    constexpr int NV = 9 * COUT, NQ4 = (NV + 3) / 4;
+    const int tpi = H / TH, b = blockIdx.x / tpi, y0 = (blockIdx.x % tpi) * TH;
+    const int tid = threadIdx.x, nthr = blockDim.x, W2 = W + 2;
+    // ---- P rows y0 - 1 .. y0 + TH of this image -> LDS [row][x + 1][HG_LD]; outside the image: zeros.  All 256 threads load.
+    const int items = (TH + 2) * W2 * NQ4;
+    const float *Pb = P + (int64_t)b * H * W * Np;
+    for (int it = tid; it < items; it += nthr) {
+        const int k = it % NQ4, pix = it / NQ4;
+        const int hy = pix / W2, hx = pix - hy * W2;
+        const int iy = y0 + hy - 1, ix = hx - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = *reinterpret_cast<const float4 *>(Pb + (int64_t)(iy * W + ix) * Np + 4 * k);
+        float *d = hg + pix * HG_LD + 4 * k;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;   // (HG_LD is odd: no 16-byte stores; slots NV .. 4 NQ4 - 1 are padding)
+    }
+    __syncthreads();
+    // ---- a thread = (output channel, row, quad of four consecutive pixels): one Philox counter of the update each
+    const int nq = W >> 2, per_co = TH * nq;
+    if (tid >= COUT * per_co) return;
+    const int co = tid / per_co, rq = tid - co * per_co, r = rq / nq, q = rq - r * nq;
+    const float bv = bias ? bias[co] : 0.f;
+    float acc[4] = {bv, bv, bv, bv};
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            const float *src = hg + ((r + ky) * W2 + 4 * q + kx) * HG_LD + (ky * 3 + kx) * COUT + co;
+#pragma unroll
+            for (int px = 0; px < 4; px++) acc[px] += src[px * HG_LD];
+        }
+    const int64_t HW = (int64_t)H * W;
+    const int64_t pix = (int64_t)(y0 + r) * W + 4 * q;
+    const int64_t e0 = (int64_t)co * HW + pix;       // element index inside the sample (NCHW); e0 % 4 == 0
+    if (u.x) {
+        // the reverse update on this thread's element quad: same arithmetic, same Philox counters as k_update_rows (noise.hip)
+        const int t = *u.t;
+        const float g = u.g[t], rg = 1.0f / g;
+        const float ce = u.c_eps[(int64_t)t * u.B + b], cn = u.c_noise[(int64_t)t * u.B + b];
+        const uint64_t seed = u.key ? u.key[0] : u.seed;
+        const uint64_t gidx = (uint64_t)((u.key ? (int64_t)u.key[1] : u.sample_offset) + b);
+        float *hr = u.hist_pp ? *u.hist_pp : nullptr;
+        const int64_t D = (int64_t)COUT * HW;
+        if (hr) hr += ((int64_t)(u.T - t) * u.B + b) * D;
+        const float4 x = *reinterpret_cast<const float4 *>(u.x + (int64_t)b * D + e0);
+        float4 z;
+        if (u.z) z = *reinterpret_cast<const float4 *>(u.z + (int64_t)b * D + e0);
+        else z = (cn != 0.0f) ? philox_normal4(seed, gidx, (uint32_t)(e0 >> 2), kPurposeStepZ, (uint32_t)t) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 o;
+        o.x = fmaf(cn, z.x, div_by(x.x - ce * acc[0], g, rg));
+        o.y = fmaf(cn, z.y, div_by(x.y - ce * acc[1], g, rg));
+        o.z = fmaf(cn, z.z, div_by(x.z - ce * acc[2], g, rg));
+        o.w = fmaf(cn, z.w, div_by(x.w - ce * acc[3], g, rg));
+        *reinterpret_cast<float4 *>(u.x + (int64_t)b * D + e0) = o;
+        if (hr) *reinterpret_cast<float4 *>(hr + e0) = o;
+        if (u.eps_out) *reinterpret_cast<float4 *>(u.eps_out + (int64_t)b * D + e0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        return;
+    }
+    if (out_nchw) {
+        *reinterpret_cast<float4 *>(out + (int64_t)b * COUT * HW + e0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+#pragma unroll
+        for (int px = 0; px < 4; px++) out[((int64_t)b * HW + pix + px) * COUT + co] = acc[px];
+    }
+}
+
+// OIHW (3x3) -> W' [Np][Cin] (the 1x1 kernel's [Cout][Cin] layout), row n = tap * Cout + co, rows beyond 9 Cout zero
+__global__ void k_relayout_weight_head_taps(const float *oihw, float *dst, int Cout, int Cin, int Np) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Np * Cin) return;
+    const int n = i / Cin, ci = i - n * Cin;
+    const int tap = n / Cout, co = n - tap * Cout;
+    dst[i] = n < 9 * Cout ? oihw[((int64_t)co * Cin + ci) * 9 + tap] : 0.f;
+}
+
 // OIHW (3x3) -> [tap][cin][4] with the output channel padded to 4
 __global__ void k_relayout_weight_head(const float *oihw, float *dst, int Cout, int Cin) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -262,6 +357,63 @@ int launch_conv_head(const ConvLaunch &c, const HeadUpdate *hu, hipStream_t st) 
     int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_conv3x3_head<HC>), 64 * 1024);
     if (r != DLPM_OK) return r;
     k_conv3x3_head<HC><<<(unsigned)(c.B * (H / TH)), TH * (W / 4), shmem, st>>>(c, hu ? *hu : none, TH, Wp);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+int head_taps_rows(int Cout) { return (9 * Cout + 31) / 32 * 32; }
+
+static int head_gather_rows(const ConvLaunch &c) {   // rows of a gather workgroup's tile: (TH + 2) (W + 2) HG_LD floats of LDS <= 48 KB,
+    int th = c.Hout;                                     // Cout TH W / 4 compute threads <= 256
+    while (th > 1 && ((th + 2) * (c.Wout + 2) * HG_LD * 4 > 48 * 1024 || c.Cout * th * (c.Wout / 4) > 256)) th >>= 1;
+    return th;
+}
+
+bool head_gemm_ok(const ConvLaunch &c) {
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("DLPM_NO_HEAD_GEMM"); off = (e && e[0] == '1') ? 1 : 0; }
+    if (off || !c.w_taps || c.ks != 3 || c.stride != 1 || c.ups || c.in_nchw || c.C1 != 0 || c.res0) return false;
+    if (c.Cout < 1 || c.Cout > 3 || c.C0 % 32 != 0 || c.Hin != c.Hout || c.Win != c.Wout) return false;
+    const int W = c.Wout, H = c.Hout;
+    if (W < 16 || W > 64 || (W & 3) || (H & (H - 1)) || ((int64_t)H * W) % 128 != 0) return false;
+    const int TH = head_gather_rows(c);
+    return H % TH == 0 && (TH + 2) * (W + 2) * HG_LD * 4 <= 48 * 1024 && c.Cout * TH * (W / 4) <= 256;
+}
+
+int64_t head_gemm_scratch_floats(const ConvLaunch &c) { return (int64_t)c.B * c.Hout * c.Wout * head_taps_rows(c.Cout); }
+
+int launch_conv_head_gemm(const ConvLaunch &c, const HeadUpdate *hu, float *P, hipStream_t st) {
+    const int Np = head_taps_rows(c.Cout);
+    ConvLaunch g = c;
+    g.ks = 1; g.w = c.w_taps; g.w_frag = nullptr; g.w_wino = nullptr; g.w_wino4 = nullptr; g.w_small = nullptr; g.w_split = nullptr;
+    g.w_taps = nullptr; g.bias = nullptr; g.out = P; g.out_nchw = 0; g.Cout = Np; g.stats_out = nullptr; g.gemm = DLPM_GEMM_F32;
+    int r = launch_conv_igemm(g, st);
+    if (r != DLPM_OK) return r;
+    const int W = c.Wout, H = c.Hout, TH = head_gather_rows(c);
+    const int64_t M = (int64_t)c.B * H * W;
+    // algorithmic bytes of the gather: the 9 Cout partial products per pixel once + the output -- or the state read and written
+    const double bytes = 4.0 * ((double)M * 9 * c.Cout + (double)M * c.Cout * (hu ? 2 + (hu->z ? 1 : 0) + (hu->eps_out ? 1 : 0) : 1));
+    ProfScope ps(hu ? "head_gather+update" : "head_gather", 2.0 * M * c.Cout * 9.0, bytes, st);
+    HeadUpdate none{};
+    const size_t shmem = (size_t)(TH + 2) * (W + 2) * HG_LD * sizeof(float);
+    const unsigned grid = (unsigned)(c.B * (H / TH)), nthr = 256;
+#define DLPM_HG(CO)                                                                                                          \
+    do {                                                                                                                     \
+        r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_head_gather<CO>), 64 * 1024);                               \
+        if (r != DLPM_OK) return r;                                                                                          \
+        k_head_gather<CO><<<grid, nthr, shmem, st>>>(P, Np, c.bias, c.out, c.out_nchw, hu ? *hu : none, c.B, H, W, TH);      \
+    } while (0)
+    if (c.Cout == 1) DLPM_HG(1);
+    else if (c.Cout == 2) DLPM_HG(2);
+    else DLPM_HG(3);
+#undef DLPM_HG
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+int relayout_weight_head_taps(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st) {
+    const int Np = head_taps_rows(Cout);
+    k_relayout_weight_head_taps<<<(unsigned)ceil_div(Np * Cin, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin, Np);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }

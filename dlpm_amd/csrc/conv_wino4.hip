@@ -59,6 +59,12 @@ constexpr int F4_PAD = 8;         // float4 fragments of zero padding behind the
 #ifndef F4_S0
 #define F4_S0 5    // position pair behind which the staging stores start
 #endif
+#ifndef F4_EPI_T
+#define F4_EPI_T 0  // 1: accumulators transposed (lane = tile, 4 consecutive channels): 16-byte epilogue accesses, 32 instead of 128 memory
+                    // instructions per lane -- bit-identical outputs, measured 0.3-0.7 % SLOWER over the eight layer shapes
+                    // (profiles/r03/conv_layers_transposed_epilogue.txt: the same 512 cache-line accesses per wave either way);
+                    // 0 (the build): lane = channel, 4 tiles
+#endif
 #ifndef F4_X
 #define F4_X 13    // position pair behind which waves 0..2 run the input transform (placement sweep, DLPM_BUILD_DEFS="F4_S0=..
                    // F4_X=..": X = 13 is 3-8 % faster than 3, 9, 11, 12, 14..17 for every S0; S0 = 3, 5, 7 are within 0.5 %)
@@ -315,10 +321,19 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
             // fill the pipe behind it.  Measured 45.6 -> 43.9 ms/step (the opposite assignment: 44.4)
             if (F4_PRIO) __builtin_amdgcn_s_setprio(0);
             if (!(ABL & 32)) {
+#if F4_EPI_T
+            // operands swapped: D rows = the wave's 16 output channels, D columns = the 16 tiles, i.e. a lane (li = tile, lk)
+            // ends up with FOUR CONSECUTIVE CHANNELS (4 lk + r) of one tile -- same products, same order, transposed registers
+            acc[2 * pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, a0.x, acc[2 * pp], 0, 0, 0);
+            acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, a1.x, acc[2 * pp + 1], 0, 0, 0);
+            acc[2 * pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, a0.y, acc[2 * pp], 0, 0, 0);
+            acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.w, a1.y, acc[2 * pp + 1], 0, 0, 0);
+#else
             acc[2 * pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc[2 * pp], 0, 0, 0);
             acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.z, acc[2 * pp + 1], 0, 0, 0);
             acc[2 * pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc[2 * pp], 0, 0, 0);
             acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.w, acc[2 * pp + 1], 0, 0, 0);
+#endif
             } else {
                 acc[2 * pp][0] += a0.x * b.x + a0.y * b.y;   // keep the operands alive
                 acc[2 * pp + 1][0] += a1.x * b.z + a1.y * b.w;
@@ -341,6 +356,105 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
     if (p.phase && lane == 0) atomicAdd(p.phase + 16 + wave, (unsigned long long)_wait);
 #endif
 
+#if F4_EPI_T
+    {
+        // ---- epilogue from registers: no LDS, no barrier.  With the MFMA operands swapped a lane (li = tile, lk) holds
+        // M_pos[tile li][channels 16 wave + 4 lk .. + 3] in acc[pos][0..3]: the output transform runs once per channel, and
+        // bias / residual / stores move FOUR consecutive channels of a pixel per instruction (16 bytes per lane, the four lk
+        // lanes of a tile = one 64-byte segment): 16 loads + 16 stores per lane where the lane = channel layout of round 2
+        // issued 64 + 64 four-byte ones (the epilogue is bound by the number of memory instructions the CU's one
+        // texture-address unit takes from 8 waves, not by bytes).  Fused GroupNorm statistics: per-lane shifted sums over
+        // the tile's 16 pixels, then the 16 tiles merged by four butterfly steps in a fixed order.
+        const int64_t pix0 = ((int64_t)img0 * H + 4 * ty0) * W + 4 * tx0;      // wave-uniform
+        const int ch = n0 + 16 * wave + 4 * lk;
+        float4 bias_v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bias_v = *reinterpret_cast<const float4 *>(p.bias + ch);
+        const bool has_res = p.res0 != nullptr;
+        const bool res_first = __builtin_amdgcn_readfirstlane(n0 + 16 * wave) < p.R0;   // R0 % 16 == 0 (wino4_geometry)
+        const float *res_u = has_res ? (res_first ? p.res0 : p.res1 - p.R0) : nullptr;
+        const int res_ld = res_first ? p.R0 : p.Cout - p.R0;
+        const int lbw = 31 - __builtin_clz(bw), lbhw = 31 - __builtin_clz(bh * bw);      // block shapes are powers of two
+        const int timg = li >> lbhw, ty = (li & (bh * bw - 1)) >> lbw, tx = li & (bw - 1);
+        const int tpix = (timg * H + 4 * ty) * W + 4 * tx;
+        const bool ok = img0 + timg < p.B;
+        float *__restrict__ out_t = p.out + (pix0 + tpix) * p.Cout + ch;
+        const float *__restrict__ res_t = has_res ? res_u + (pix0 + tpix) * res_ld + ch : nullptr;
+        const bool do_stats = p.stats_out != nullptr && nimg == 1;
+        float Y[4][16];   // [channel][pixel 4 i + j]
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float Z[4][6];
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                const float m0 = acc[0 * 6 + b][r], m1 = acc[1 * 6 + b][r], m2 = acc[2 * 6 + b][r];
+                const float m3 = acc[3 * 6 + b][r], m4 = acc[4 * 6 + b][r], m5 = acc[5 * 6 + b][r];
+                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                Z[0][b] = m0 + s12 + s34;
+                Z[1][b] = fmaf(2.f, d34, d12);
+                Z[2][b] = fmaf(4.f, s34, s12);
+                Z[3][b] = fmaf(8.f, d34, d12) + m5;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float s12 = Z[i][1] + Z[i][2], d12 = Z[i][1] - Z[i][2], s34 = Z[i][3] + Z[i][4], d34 = Z[i][3] - Z[i][4];
+                Y[r][i * 4 + 0] = Z[i][0] + s12 + s34;
+                Y[r][i * 4 + 1] = fmaf(2.f, d34, d12);
+                Y[r][i * 4 + 2] = fmaf(4.f, s34, s12);
+                Y[r][i * 4 + 3] = fmaf(8.f, d34, d12) + Z[i][5];
+            }
+        }
+        float4 K = make_float4(0.f, 0.f, 0.f, 0.f), s1 = K, s2 = K;
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float4 rs[4];
+                if (has_res) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) rs[j] = *reinterpret_cast<const float4 *>(res_t + (i * W + j) * res_ld);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float4 v = make_float4(Y[0][i * 4 + j] + bias_v.x, Y[1][i * 4 + j] + bias_v.y, Y[2][i * 4 + j] + bias_v.z,
+                                           Y[3][i * 4 + j] + bias_v.w);
+                    if (has_res) { v.x += rs[j].x; v.y += rs[j].y; v.z += rs[j].z; v.w += rs[j].w; }
+                    if (do_stats) {
+                        if (i == 0 && j == 0) K = v;
+                        float d;
+                        d = v.x - K.x; s1.x += d; s2.x = fmaf(d, d, s2.x);
+                        d = v.y - K.y; s1.y += d; s2.y = fmaf(d, d, s2.y);
+                        d = v.z - K.z; s1.z += d; s2.z = fmaf(d, d, s2.z);
+                        d = v.w - K.w; s1.w += d; s2.w = fmaf(d, d, s2.w);
+                    }
+                    *reinterpret_cast<float4 *>(out_t + (i * W + j) * p.Cout) = v;
+                }
+            }
+        }
+        if (do_stats) {
+            float mean[4] = {K.x + s1.x * (1.f / 16.f), K.y + s1.y * (1.f / 16.f), K.z + s1.z * (1.f / 16.f), K.w + s1.w * (1.f / 16.f)};
+            float M2[4] = {fmaxf(s2.x - s1.x * s1.x * (1.f / 16.f), 0.f), fmaxf(s2.y - s1.y * s1.y * (1.f / 16.f), 0.f),
+                           fmaxf(s2.z - s1.z * s1.z * (1.f / 16.f), 0.f), fmaxf(s2.w - s1.w * s1.w * (1.f / 16.f), 0.f)};
+            float na = 16.f;
+#pragma unroll
+            for (int sft = 1; sft <= 8; sft <<= 1) {      // the 16 tiles (lane bits 0..3), lower lane first
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float om = __shfl_xor(mean[c], sft), oM2 = __shfl_xor(M2[c], sft);
+                    const float lo_m = (lane & sft) ? om : mean[c], hi_m = (lane & sft) ? mean[c] : om;
+                    const float lo_M = (lane & sft) ? oM2 : M2[c], hi_M = (lane & sft) ? M2[c] : oM2;
+                    const float dd = hi_m - lo_m;
+                    mean[c] = lo_m + dd * 0.5f;
+                    M2[c] = lo_M + hi_M + dd * dd * (na * 0.5f);
+                }
+                na *= 2.f;
+            }
+            if (li == 0) {
+                float2 *so = p.stats_out + ((int64_t)img0 * ((H * W) / 256) + blk_in_img) * p.Cout + ch;
+#pragma unroll
+                for (int c = 0; c < 4; c++) so[c] = make_float2(mean[c], M2[c]);
+            }
+        }
+    }
+#else
     {
         // ---- epilogue from registers: no LDS, no barrier.  A lane holds 64 outputs of ONE channel (4 tiles x 16 pixels:
         // M_pos[tile 4 lk + r][channel 16 wave + li] in acc[pos][r]), so the output transform, bias, residual, the fused
@@ -425,6 +539,7 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
             if (lk == 0) p.stats_out[((int64_t)img0 * ((H * W) / 256) + blk_in_img) * p.Cout + ch] = make_float2(mean, M2);
         }
     }
+#endif
     DLPM_PHASE(p, 10);
 #ifdef DLPM_PHASE_TIMING
     if (p.phase && tid == 0) {

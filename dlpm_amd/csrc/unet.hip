@@ -45,6 +45,7 @@ struct ConvW {            // one convolution's weights
     float *w_wino = nullptr; // 3x3 only: Winograd-domain weights in fragment order (conv_wino.hip)
     float *w_wino4 = nullptr;// 3x3 only: F(4x4,3x3) Winograd-domain weights (conv_wino4.hip), when DLPM_WINO_F4 is on
     float *w_small = nullptr;// 3x3 with cout <= 4 (head): [tap][cin][4]
+    float *w_taps = nullptr; // 3x3 with cout <= 3 (head): [9 cout -> 32][cin], the head as a 1x1 GEMM + gather (conv_direct.hip)
     void *w_split = nullptr; // 1x1 with cout % 128 == 0, cin % 32 == 0: three bf16 planes in stage-tile order (conv_split.hip)
     bool owns = false;
 };
@@ -333,6 +334,11 @@ int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 no
         DLPM_HIP(hipMalloc(&c.w_small, (size_t)9 * c.cin * 4 * sizeof(float)));
         int r = relayout_weight_head(src, c.w_small, c.cout, c.cin, nullptr);
         if (r != DLPM_OK) return r;
+        if (c.cout <= 3) {
+            DLPM_HIP(hipMalloc(&c.w_taps, (size_t)head_taps_rows(c.cout) * c.cin * sizeof(float)));
+            r = relayout_weight_head_taps(src, c.w_taps, c.cout, c.cin, nullptr);
+            if (r != DLPM_OK) return r;
+        }
     }
     if (c.use_igemm && c.ks == 3 && boundary == 4 && c.cout % 128 == 0 && c.cin % 32 == 0) {   // stride-2 downsampling convolution
         DLPM_HIP(hipMalloc(&c.w_split, (size_t)split_weight_floats(c.cout, c.cin, 9) * sizeof(float)));
@@ -357,17 +363,19 @@ int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 no
     return relayout_weight(src, c.w_dev, c.cout, c.cin, c.ks, c.use_igemm, nullptr);
 }
 
-int run_conv(const dlpm_unet *u, const ConvW &c, ConvLaunch L, hipStream_t st, const HeadUpdate *hu = nullptr) {
+int run_conv(const dlpm_unet *u, const ConvW &c, ConvLaunch L, hipStream_t st, const HeadUpdate *hu = nullptr, float *head_scratch = nullptr) {
     policy_of(u, L);
     L.w = c.w_dev;
     L.w_frag = c.w_frag;
     L.w_wino = c.w_wino;
     L.w_wino4 = c.w_wino4;
     L.w_small = c.w_small;
+    L.w_taps = c.w_taps;
     L.w_split = c.w_split;
     L.ws_gemm = (c.ks == 1 && c.w_frag) ? 1 : 0;
     L.ks = c.ks;
     L.Cout = c.cout;
+    if (head_scratch && head_gemm_ok(L)) return launch_conv_head_gemm(L, hu, head_scratch, st);
     if (head_conv_ok(L)) return launch_conv_head(L, hu, st);
     if (hu) { set_error("unet: the head convolution of this net cannot carry the fused update"); return DLPM_ERR_UNSUPPORTED; }
     return c.use_igemm ? launch_conv_igemm(L, st) : launch_conv_fallback(L, st);
@@ -577,13 +585,20 @@ int walk(dlpm_unet *u, Ctx &cx, const float *x, const float *t, float *eps) {
         u->feats.push_back(h);
     }
     float *cA = cx.ws.alloc((int64_t)B * h.C), *cB = cx.ws.alloc((int64_t)B * h.C);
+    // the head as a GEMM onto its 9 Cout tap channels + gather: the tap-channel tensor P lives in the arena
+    float *P = nullptr;
+    {
+        ConvLaunch a;
+        a.C0 = h.C; a.B = B; a.Hin = a.Hout = h.H; a.Win = a.Wout = h.W; a.ks = 3; a.Cout = u->head.cout; a.w_taps = u->head.w_taps; a.out_nchw = 1;
+        if (head_gemm_ok(a)) P = cx.ws.alloc(head_gemm_scratch_floats(a));
+    }
     if (!cx.dry()) {
         TRY(gn_any(h, Tensor4(), B, h.C < 32 ? h.C : 32, u->params[u->p_head_gn_w].dev, u->params[u->p_head_gn_b].dev, nullptr,
                    0, 0, cA, cB, cx.st));
         ConvLaunch a;
         a.src0 = h.p; a.C0 = h.C; a.B = B; a.Hin = a.Hout = h.H; a.Win = a.Wout = h.W;
         a.bias = u->params[u->head.p_b].dev; a.coefA = cA; a.coefB = cB; a.act_silu = 1; a.out = eps; a.out_nchw = 1;
-        TRY(run_conv(u, u->head, a, cx.st, cx.hu));
+        TRY(run_conv(u, u->head, a, cx.st, cx.hu, P));
     }
     if (!cx.ws.reuse) return DLPM_OK;
     for (auto &f : u->feats) f.p = nullptr;     // the arena has recycled them: dlpm_unet_get_feature needs dlpm_unet_keep_features
@@ -674,6 +689,8 @@ static void free_conv(ConvW &c) {
     c.w_wino4 = nullptr;
     if (c.w_small) (void)hipFree(c.w_small);
     c.w_small = nullptr;
+    if (c.w_taps) (void)hipFree(c.w_taps);
+    c.w_taps = nullptr;
     if (c.w_split) (void)hipFree(c.w_split);
     c.w_split = nullptr;
     c.w_dev = nullptr;
@@ -823,7 +840,8 @@ static bool head_fusable(const dlpm_unet *u) {
     const int H = u->cfg.image_size;
     L.C0 = u->head.cin; L.Hin = L.Hout = H; L.Win = L.Wout = H; L.ks = 3; L.Cout = u->head.cout; L.out_nchw = 1;
     L.w_small = u->head.w_small;
-    return head_conv_ok(L);
+    L.w_taps = u->head.w_taps;
+    return head_gemm_ok(L) || head_conv_ok(L);
 }
 
 extern "C" int dlpm_unet_forward_update(dlpm_unet *net, const float *x_in_dev, const float *t_dev, const dlpm_update_args *upd,
@@ -982,6 +1000,17 @@ extern "C" int dlpm_conv2d_f32(const dlpm_conv_args *a, float *scratch_dev, dlpm
                 L.w_wino = nullptr;   // no F(2x2) alternative: every qualifying geometry takes the F(4x4) kernel
             }
         }
+    }
+    if ((a->force_direct & 32) && a->ksize == 3 && a->Cout <= 3 && a->C0 % 32 == 0 && a->C1 == 0) {
+        // bit 32: the head as a 1x1 GEMM onto 9 Cout tap channels + gather: W' at the front of the scratch buffer, P behind it
+        const int64_t wsz = (int64_t)head_taps_rows(a->Cout) * a->C0;
+        L.w_taps = scratch_dev;   // (head_gemm_ok only looks at the pointer)
+        if (a->scratch_floats >= wsz + head_gemm_scratch_floats(L) && head_gemm_ok(L)) {
+            TRY(relayout_weight_head_taps(a->weight, scratch_dev, a->Cout, a->C0, st));
+            return launch_conv_head_gemm(L, nullptr, scratch_dev + wsz, st);
+        }
+        set_error("dlpm_conv2d_f32: the GEMM + gather head does not take this shape / scratch size");
+        return DLPM_ERR_UNSUPPORTED;
     }
     if (!(a->force_direct & 7) && a->ksize == 3 && a->Cout <= 4 && a->C0 % 32 == 0 && a->C1 == 0) {
         // [tap][cin][4] copy at the END of the scratch buffer (the front holds the layouts built above)

@@ -34,7 +34,7 @@ def nchw(x):
 
 
 def run_conv(x0, w, bias=None, x1=None, stride=1, ups=0, coef=None, silu=False, res=None, in_nchw=False,
-             out_nchw=False, force_direct=False):
+             out_nchw=False, force_direct=False, scratch_extra=0):
     """x0/x1: NCHW cpu tensors; returns NCHW cpu output of the HIP conv."""
     B, C0, Hin, Win = x0.shape
     Cout, Cin, ks, _ = w.shape
@@ -65,7 +65,7 @@ def run_conv(x0, w, bias=None, x1=None, stride=1, ups=0, coef=None, silu=False, 
     out = torch.empty((B, Cout, Hout, Wout) if out_nchw else (B, Hout, Wout, Cout), device=DEV)
     a.out, a.Cout = out.data_ptr(), Cout
     a.in_nchw, a.out_nchw, a.force_direct = int(in_nchw), int(out_nchw), int(force_direct)
-    scratch = torch.empty(9 * w.numel() + 16 * 1024 * (1 + Cout // 32), device=DEV)
+    scratch = torch.empty(9 * w.numel() + 16 * 1024 * (1 + Cout // 32) + scratch_extra, device=DEV)
     a.scratch_floats = scratch.numel()
     _lib.check(L().dlpm_conv2d_f32(C.byref(a), scratch.data_ptr(), st()))
     torch.cuda.synchronize()
@@ -297,6 +297,18 @@ def test_conv_boundary_layouts():
     assert (got - ref_conv(x, w, b)).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize('B,Cin,H,Cout', [(3, 3, 32, 128), (2, 1, 32, 32), (1, 3, 64, 128), (2, 3, 16, 64)])
+def test_stem_conv_kernels(B, Cin, H, Cout):
+    """The stem (unet.py:347: reads the caller's NCHW state, Cin = image channels): whole rows of one image per block through
+    LDS where the image is a multiple of 1024 pixels (CIFAR / MNIST / CelebA shapes), the register-weight kernel otherwise."""
+    g = torch.Generator().manual_seed(B * 10 + Cin + H)
+    x = torch.randn(B, Cin, H, H, generator=g) * 2
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g)
+    got = run_conv(x, w, b, in_nchw=True)
+    assert (got - ref_conv(x, w, b)).abs().max().item() < 1e-5
+
+
 @pytest.mark.parametrize('B,C,H,Cout,nchw', [(3, 64, 16, 3, True), (2, 32, 32, 3, True), (2, 128, 32, 1, True), (1, 32, 64, 4, False)])
 def test_head_conv_kernel(B, C, H, Cout, nchw):
     """The dedicated head kernel (Cout <= 4, fused GN affine + SiLU, NCHW out) against the fp64 reference and against
@@ -313,6 +325,27 @@ def test_head_conv_kernel(B, C, H, Cout, nchw):
     assert (old - want).abs().max().item() < conv_tol(w, C)
     got2 = run_conv(h, w, b, out_nchw=nchw)                     # no activation
     assert (got2 - ref_conv(h, w, b)).abs().max().item() < conv_tol(w, C)
+
+
+@pytest.mark.parametrize('B,C,H,Cout,nchw', [(3, 64, 16, 3, True), (2, 32, 32, 3, True), (2, 128, 32, 1, True), (1, 32, 64, 2, False),
+                                             (5, 128, 32, 3, True)])
+def test_head_conv_as_gemm_plus_gather(B, C, H, Cout, nchw):
+    """The head (unet.py:435) as a 1x1 GEMM onto its 9 Cout tap channels (fused GN affine + SiLU) + the 9-point gather
+    (force_direct bit 32), against the fp64 reference and next to the dedicated VALU kernel it replaces in the UNet plan."""
+    g = torch.Generator().manual_seed(B * 100 + C + H + 7)
+    h = torch.randn(B, C, H, H, generator=g)
+    w = torch.randn(Cout, C, 3, 3, generator=g) / math.sqrt(9 * C)
+    b = torch.randn(Cout, generator=g)
+    coef = (1 + 0.3 * torch.randn(B, C, generator=g), 0.3 * torch.randn(B, C, generator=g))
+    extra = 32 * C + B * H * H * 32
+    want = ref_conv(h, w, b, coef=coef, silu=True)
+    got = run_conv(h, w, b, coef=coef, silu=True, out_nchw=nchw, force_direct=32, scratch_extra=extra)
+    old = run_conv(h, w, b, coef=coef, silu=True, out_nchw=nchw)
+    e_new, e_old = (got - want).abs().max().item(), (old - want).abs().max().item()
+    print('head %dx%d C%d -> %d: GEMM + gather err %.2e, VALU kernel err %.2e, tol %.2e' % (H, H, C, Cout, e_new, e_old, conv_tol(w, C)))
+    assert e_new < conv_tol(w, C) and e_old < conv_tol(w, C)
+    got2 = run_conv(h, w, None, out_nchw=nchw, force_direct=32, scratch_extra=extra)       # no activation, no bias
+    assert (got2 - ref_conv(h, w, None)).abs().max().item() < conv_tol(w, C)
 
 
 def test_linear_as_conv():
