@@ -485,12 +485,23 @@ def main():
                          share_of_step_ms=round(ms_ / nprof, 3),
                          note='achieved = bf16 FLOP/s EXECUTED (6 x the fp32-equivalent rate) over the dense bf16 MFMA peak; the same '
                               'launches on the fp32 MFMA (--gemm f32) run at 85-115 fp32 TFLOP/s')
-        u, hu = prof.get('update'), prof.get('conv3x3_head+update')
-        if hu:   # the default path: the head convolution applies the update in its epilogue (dlpm_unet_forward_update)
+        u, hu, hg = prof.get('update'), prof.get('conv3x3_head+update'), prof.get('head_gather+update')
+        if hg:   # the default path: head convolution = 1x1 GEMM onto 9 Cout tap channels (its own launch, class conv1x1_igemm) + this kernel
+            gbs = hg['bytes'] / (hg['ms'] * 1e-3) / 1e9
+            traffic, tnote = pmc_traffic('k_head_gather', args.workload if not args.batch else '%s@B%d' % (args.workload, B))
+            upd = dict(kernel='k_head_gather with the x_{t-1} update (Philox noise): reads the 9 Cout partial products per pixel the head GEMM '
+                              'left, sums the nine taps, applies the reverse step to the NCHW state in place -- eps never reaches HBM',
+                       bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(gbs / PEAK_HBM_GBS, 4),
+                       traffic=traffic, traffic_note=tnote, bytes_per_launch=hg['bytes'] / hg['launches'],
+                       avg_launch_ms=round(hg['ms'] / hg['launches'], 5),
+                       note='algorithmic bytes = 4 * 9 Cout per pixel of tap partial products + read x + write x (12 B/element of state); '
+                            'north-star target for this kernel: 0.60 of HBM')
+        elif hu:   # nets whose head the GEMM + gather form does not take: the VALU head kernel applies the update in its epilogue
             gbs = hu['bytes'] / (hu['ms'] * 1e-3) / 1e9
+            traffic, tnote = pmc_traffic('k_conv3x3_head', args.workload if not args.batch else '%s@B%d' % (args.workload, B))
             upd = dict(kernel='k_conv3x3_head with the x_{t-1} update (Philox noise) fused into its epilogue: eps never reaches HBM, no '
                               'separate update launch', bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
-                       frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, bytes_per_launch=hu['bytes'] / hu['launches'],
+                       frac=round(gbs / PEAK_HBM_GBS, 4), traffic=traffic, traffic_note=tnote, bytes_per_launch=hu['bytes'] / hu['launches'],
                        avg_launch_ms=round(hu['ms'] / hu['launches'], 5),
                        note='algorithmic bytes = the convolution input once + read x + write x; the launch is VALU-bound (36 FMAs and '
                             'one SiLU per input element), not bandwidth-bound: see DESIGN.md section 3')

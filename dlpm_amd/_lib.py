@@ -100,6 +100,10 @@ SIGNATURES = {
     'dlpm_unet_forward': (C.c_int, [vp, vp, vp, vp, i64, vp, i64, vp]),
     'dlpm_unet_forward_uniform_t': (C.c_int, [vp, vp, vp, vp, i64, vp, i64, vp]),
     'dlpm_unet_forward_update': (C.c_int, [vp, vp, vp, C.POINTER(UpdateArgs), vp, i64, vp, i64, vp]),
+    'dlpm_unet_time_embedding_width': (i64, [vp]),
+    'dlpm_unet_time_embeddings_scratch_bytes': (i64, [vp, i64]),
+    'dlpm_unet_time_embeddings': (C.c_int, [vp, vp, i64, vp, vp, i64, vp]),
+    'dlpm_unet_bind_time_table': (C.c_int, [vp, vp, vp]),
     'dlpm_unet_keep_features': (C.c_int, [vp, C.c_int]),
     'dlpm_unet_num_features': (C.c_int, [vp]),
     'dlpm_unet_feature_shape': (C.c_int, [vp, C.c_int, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),

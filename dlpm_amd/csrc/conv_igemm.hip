@@ -1153,8 +1153,12 @@ int conv_stats_pixels(const ConvLaunch &c) {
     int a, b, n;
     if (c.in_nchw) return stem_stats_ok(c) ? 1024 : 0;
     // same order as launch_conv_igemm's dispatch: a launch that carries split weights runs k_conv_split whatever else it carries
-    if (conv_split_ok(c)) return ((int64_t)c.Hout * c.Wout) % BM == 0 && (c.R0 & 3) == 0 ? BM : 0;
-    if (wino4_preferred(c, &a, &b, &n)) return n == 1 ? 256 : 0;
+    // (k_conv_split: per 128-pixel tile through the 4-wave row epilogue, or per whole 8x8 image from the registers of the 8 / 16-wave shapes)
+    if (conv_split_ok(c)) {
+        const int64_t hw = (int64_t)c.Hout * c.Wout;
+        return (c.R0 & 3) ? 0 : hw % BM == 0 ? BM : hw == 64 ? 64 : 0;
+    }
+    if (wino4_preferred(c, &a, &b, &n)) return n == 1 ? 256 : (n == 4 && a * b == 4 && wino4_image_stats()) ? 64 : 0;   // (four whole 8x8 images per block: one partial per image)
     if (wino_geometry(c, &a, &b, &n)) return n == 1 ? 4 * wino_tiles(c) : 0;
     if (c.out_nchw || (c.Cout & 3) || (c.R0 & 3)) return 0;
     return ((int64_t)c.Hout * c.Wout) % BM == 0 ? BM : 0;

@@ -80,7 +80,9 @@ __global__ void k_relayout_weight_split(const float *w, uint4 *dst, int Cout, in
 // rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5), so one store instruction writes 32 consecutive channels of 2 pixels = two whole
 // 128-byte lines.  No LDS, no barrier, every wave busy; the residual's loads are issued before the first add.
 // MASKED: the tile's last rows lie beyond M (ragged last tile).
-template <bool MASKED, int RN>
+// STATS (8 x 8 images, HW == 64: the 64 rows of a wave are exactly one image, 32 of them in each k-half lane): the fused GroupNorm
+// statistics of the output, one (mean, M2) per image and channel -- per-lane shifted sums over 32 rows, merged with the partner lane.
+template <bool MASKED, int RN, bool STATS = false>
 __device__ __forceinline__ void split_store_from_registers(const ConvLaunch &p, floatx16 (&acc)[2][RN], int64_t m0, int nw0, int wm,
                                                      int l31, int kh, int mrem) {
     const int R1 = p.Cout - p.R0;
@@ -108,6 +110,7 @@ __device__ __forceinline__ void split_store_from_registers(const ConvLaunch &p, 
                     q[i][r] = rp[(MASKED ? max(min(row, rlim), 0) : row) * rs];
                 }
         }
+        float K = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -115,9 +118,24 @@ __device__ __forceinline__ void split_store_from_registers(const ConvLaunch &p, 
                 const int row = i * 32 + (r & 3) + 8 * (r >> 2);
                 float v = acc[i][j][r] + bias;
                 if (p.res0) v += q[i][r];
+                if (STATS) {
+                    if (i == 0 && r == 0) K = v;
+                    const float dd = v - K;
+                    s1 += dd;
+                    s2 = fmaf(dd, dd, s2);
+                }
                 if (SABL(1) && v == v) continue;
                 if (!MASKED || row <= rlim) op[(int64_t)row * p.Cout] = v;
             }
+        if (STATS) {
+            // this lane: 32 of the image's 64 rows; the k-half partner (lane ^ 32) has the other 32: Chan merge, k-half 0 first
+            const float mean = K + s1 * (1.f / 32.f), M2 = fmaxf(s2 - s1 * s1 * (1.f / 32.f), 0.f);
+            const float om = __shfl_xor(mean, 32), oM2 = __shfl_xor(M2, 32);
+            const float lo_m = kh ? om : mean, hi_m = kh ? mean : om;
+            const float dd = hi_m - lo_m;
+            const int64_t img = (m0 + wm * 64) >> 6;
+            if (kh == 0 && img < p.B) p.stats_out[img * p.Cout + n] = make_float2(lo_m + dd * 0.5f, (kh ? oM2 : M2) + (kh ? M2 : oM2) + dd * dd * 16.f);
+        }
     }
 }
 
@@ -131,10 +149,15 @@ __device__ __forceinline__ void split_store_from_registers(const ConvLaunch &p, 
 // down.  Which is why every structural variant measured here landed within +-5 % of this one (all under profiles/r02/gemm_*):
 // two 8-wave groups in one workgroup one barrier phase apart (ping-pong), 256-pixel tiles with two LDS stages and one
 // barrier per stage, 4 waves at three workgroups per CU, two register stages at 128 VGPRs.
+// NW = 16 (round 3, measured and NOT the default -- launch_conv_split): ONE workgroup of 2 x 8 waves per CU computes 128 pixels x 256
+// channels -- the activation stage (loads, GroupNorm affine, SiLU, the three-plane split, LDS writes) is shared by twice the MFMAs,
+// half as many prologues / epilogues per layer; LDS 24 KB of A + 48 KB of B per stage.  Same per-output accumulation order as the
+// other shapes: same bits.
 template <int NW, int DIST, int TAPS>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split(ConvLaunch p, int nsamp, int xcd_map) {
-    constexpr int NT = NW * 64, RN = NW == 4 ? 2 : 1, WN = 4 / RN;   // threads, MFMA column tiles per wave, waves across N
-    constexpr int RSTEP = NT / 8, NV = 128 / RSTEP, NWV = SCHUNKS / NT;   // staging: rows per pass, passes, weight chunks per thread
+    constexpr int NT = NW * 64, RN = NW == 4 ? 2 : 1, WN = NW == 16 ? 8 : 4 / RN;   // threads, MFMA column tiles per wave, waves across N
+    constexpr int NB = NW == 16 ? 2 : 1, BNW = NB * 128;                              // 128-channel weight tiles per stage, tile width
+    constexpr int RSTEP = NT / 8, NV = 128 / RSTEP, NWV = NB * SCHUNKS / NT;   // staging: rows per pass, passes, weight chunks per thread
     // [A stage 24 KB][B stage 24 KB] (the statistics epilogue's row image afterwards) [GroupNorm coefficients of the tile's samples]
     extern __shared__ __align__(16) unsigned char smem[];
     DLPM_PHASE_DECL;
@@ -148,7 +171,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split
     const int l31 = lane & 31, kh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int Cin = p.C0 + p.C1;
-    const int ntile_n = p.Cout >> 7;
+    const int ntile_n = p.Cout / BNW;
     // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8), each with its own L2.  The ntile_n channel tiles of one
     // pixel tile read the same activations: they go to ONE XCD, back to back (xcd_map: pixel tiles % 8 == 0).
     int mt_i, nt;
@@ -161,7 +184,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split
         nt = blockIdx.x % ntile_n;
     }
     const int64_t m0 = (int64_t)mt_i * BM;
-    const int n0 = nt << 7;
+    const int n0 = nt * BNW;
     const int HWo = p.Hout * p.Wout;
 
     // A staging: 8 consecutive lanes read one pixel's 32 channels (a whole 128-byte line), a wave instruction 8 pixels;
@@ -189,7 +212,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split
         }
     }
     const int nkc = Cin / SKC;
-    const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(p.w_split) + (int64_t)nt * nkc * SCHUNKS + tid;
+    // weight image [tap][Cout / 128][Cin / 32][SCHUNKS]: a 256-wide tile stages two consecutive 128-channel tiles, the second one
+    // nkc * SCHUNKS chunks behind the first (thread -> chunk v * NT + tid of the 2 * SCHUNKS; NT = 1024 < SCHUNKS: a thread's chunks
+    // v = 0, 1 lie in the first tile or straddle, computed per chunk below)
+    const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(p.w_split) + (int64_t)nt * NB * nkc * SCHUNKS + (NB == 1 ? tid : 0);
     const bool has_coef = p.coefA != nullptr;
 
     // stage s = (channel chunk kc, tap); `ok` collects which of this thread's rows read inside the image (zero padding)
@@ -216,16 +242,22 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split
             }
         }
         if (!(SABL(4) && s >= 2)) {
-            const u32x4 *ws = wsrc + ((int64_t)tap * ntile_n * nkc + kc) * SCHUNKS;
+            const u32x4 *ws = wsrc + ((int64_t)tap * (p.Cout >> 7) * nkc + kc) * SCHUNKS;
 #pragma unroll
-            for (int v = 0; v < NWV; v++) wb[v] = ws[v * NT];
+            for (int v = 0; v < NWV; v++) {
+                if (NB == 1) wb[v] = ws[v * NT];
+                else {
+                    const int c = v * NT + tid, half = c >= SCHUNKS ? 1 : 0;     // chunk of the 2 x SCHUNKS stage image
+                    wb[v] = ws[(int64_t)half * nkc * SCHUNKS + (c - half * SCHUNKS)];
+                }
+            }
         }
     };
     // LDS chunk (16 B = 8 channels of one row of one plane) of (ksh, row): ksh * 128 + (row ^ 8 ksh) -- the XOR spreads the
     // 8-byte staging writes of a wave (4 ksh x 8 rows) over the banks and leaves a fragment read (32 consecutive rows) contiguous
     uint2 *As = reinterpret_cast<uint2 *>(smem);
     u32x4 *Bs = reinterpret_cast<u32x4 *>(smem + SOPER);
-    const float *cf = reinterpret_cast<const float *>(smem + 2 * SOPER);
+    const float *cf = reinterpret_cast<const float *>(smem + (1 + NB) * SOPER);
     int cfo[NV];                                  // this thread's rows' coefficient rows in the LDS table
 #pragma unroll
     for (int v = 0; v < NV; v++) cfo[v] = (nsamp > 1 ? min(rb + RSTEP * v, mrem - 1) / HWo : 0) * Cin + 4 * q;   // rows beyond M: the last valid sample's (written) coefficients
@@ -276,7 +308,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
     const bf16x8 *af = reinterpret_cast<const bf16x8 *>(smem) + kh * 128 + wm * 64;
-    const bf16x8 *bf = reinterpret_cast<const bf16x8 *>(smem + SOPER) + kh * 128 + wn * (RN * 32) + l31;
+    const bf16x8 *bf = reinterpret_cast<const bf16x8 *>(smem + SOPER + (NW == 16 ? (wn >> 2) * SOPER : 0)) + kh * 128 +
+                       (NW == 16 ? (wn & 3) * 32 : wn * (RN * 32)) + l31;
     const int ax0 = l31 ^ (kh * 8), ax1 = l31 ^ ((2 + kh) * 8);   // swizzled row of this lane for k-step 0 / 1
     auto mfma_step = [&]() {
         if (SABL(8)) return;
@@ -314,7 +347,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split
     u32x4 wb0[NWV], wb1[NWV];
     // GroupNorm coefficients of the tile's samples -> LDS [A | B][nsamp][Cin] (read by every stage).  Their loads go out
     // FIRST: loads retire in order, so the table's LDS writes wait for nothing but themselves.
-    constexpr int CR = 512 / NT;                  // rounds of NT float4 that ride in registers (the first 512)
+    constexpr int CR = NT >= 512 ? 1 : 512 / NT;  // rounds of NT float4 that ride in registers (the first 512, or the first NT)
     f32x4 cq[2][CR] = {};
     const int n4 = has_coef ? nsamp * Cin / 4 : 0;   // float4 per array (<= 1024, gemm_split_ok)
     const int nv4 = has_coef ? (int)min((int64_t)n4, (p.B - m0 / HWo) * (int64_t)(Cin / 4)) : 0;   // the batch may end inside the tile
@@ -330,14 +363,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split
     load_step(xa0, wb0, ok0, 0);
     if (DIST == 2 && nsteps > 1) load_step(xa1, wb1, ok1, 1);
     if (has_coef) {
-        f32x4 *dst = reinterpret_cast<f32x4 *>(smem + 2 * SOPER);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(smem + (1 + NB) * SOPER);
 #pragma unroll
         for (int r = 0; r < CR; r++) {
             const int i = tid + r * NT;
             if (i < n4) { dst[i] = cq[0][r]; dst[n4 + i] = cq[1][r]; }
         }
         const int64_t pb0 = m0 / HWo;
-        for (int i = tid + 512; i < nv4; i += NT) {   // tables beyond 512 float4 (8 samples x 512 channels): the slow way
+        for (int i = tid + CR * NT; i < nv4; i += NT) {   // tables beyond the register rounds (8 samples x 512 channels): the slow way
             dst[i] = reinterpret_cast<const f32x4 *>(p.coefA + pb0 * Cin)[i];
             dst[n4 + i] = reinterpret_cast<const f32x4 *>(p.coefB + pb0 * Cin)[i];
         }
@@ -388,7 +421,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split
             return;
         }
     }
-    if (mrem == BM) split_store_from_registers<false, RN>(p, acc, m0, n0 + wn * (RN * 32), wm, l31, kh, BM);
+    if (NW != 4 && p.stats_out) {   // 8x8 images (launch_conv_split): per-image statistics from the registers
+        if (mrem == BM) split_store_from_registers<false, RN, true>(p, acc, m0, n0 + wn * (RN * 32), wm, l31, kh, BM);
+        else split_store_from_registers<true, RN, true>(p, acc, m0, n0 + wn * (RN * 32), wm, l31, kh, mrem);
+    } else if (mrem == BM) split_store_from_registers<false, RN>(p, acc, m0, n0 + wn * (RN * 32), wm, l31, kh, BM);
     else split_store_from_registers<true, RN>(p, acc, m0, n0 + wn * (RN * 32), wm, l31, kh, mrem);
     DLPM_PHASE(p, 2);
 #ifdef DLPM_PHASE_TIMING
@@ -429,28 +465,39 @@ int launch_conv_split(const ConvLaunch &c, hipStream_t st) {
     static_assert(2 * SOPER >= 64 * 132 * 4, "epilogue image must fit the stage buffers");
     const int HW = c.Hout * c.Wout;
     const int nsamp = HW >= BM ? 1 : BM / HW;     // samples a 128-pixel tile spans
-    const int lds = 2 * SOPER + (c.coefA ? nsamp * (c.C0 + c.C1) * 8 : 0);
+    // DLPM_SPLIT_NW16=1 (A/B runs; same bits either way): 256-wide channel tiles, 16 waves, ONE workgroup per CU, wherever Cout is a
+    // multiple of 256 -- the activation stage shared by twice the MFMAs.  Measured 8-40 % SLOWER per launch on every shape and +0.5 ms
+    // on the whole step (profiles/r03/gemm_bf16x3_256wide_tiles.txt, bench_cifar_alternating_256wide.txt): what two co-resident
+    // workgroups hide of each other's barriers, prologues and epilogues is worth more than the staging they repeat.  Off by default.
+    static int nw16 = -1;
+    if (nw16 < 0) { const char *e = getenv("DLPM_SPLIT_NW16"); nw16 = e ? atoi(e) : 0; }
+    const bool row_stats = c.stats_out && HW % BM == 0;      // per 128-pixel tile, through the 4-wave shape's row epilogue
+    const bool wide = nw16 && c.Cout % 256 == 0 && !row_stats;
+    const int bnw = wide ? 256 : 128;
+    const int lds = (wide ? 3 : 2) * SOPER + (c.coefA ? nsamp * (c.C0 + c.C1) * 8 : 0);
     const int64_t mt = ceil_div(M, BM);
-    const unsigned grid = (unsigned)(mt * (c.Cout / 128));
-    const int xcd_map = (c.Cout > 128 && mt % 8 == 0) ? 1 : 0;
-    if (c.stats_out && (HW % BM != 0 || M % BM != 0)) {   // the statistics epilogue has no bounds tests and one partial per in-image tile
-        set_error("launch_conv_split: fused statistics need whole 128-pixel tiles inside one image (HW %d)", HW);
+    const unsigned grid = (unsigned)(mt * (c.Cout / bnw));
+    const int xcd_map = (c.Cout > bnw && mt % 8 == 0) ? 1 : 0;
+    if (c.stats_out && !row_stats && HW != 64) {   // one partial per in-image 128-pixel tile, or per whole 8x8 image
+        set_error("launch_conv_split: fused statistics need whole 128-pixel tiles inside one image, or 8x8 images (HW %d)", HW);
         return DLPM_ERR_UNSUPPORTED;
     }
 #define DLPM_SPLIT_LAUNCH(NW_, DIST_, TAPS_)                                                                              \
     do {                                                                                                                  \
-        const int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_conv_split<NW_, DIST_, TAPS_>), 2 * SOPER + 32 * 1024); \
+        const int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_conv_split<NW_, DIST_, TAPS_>), 3 * SOPER + 32 * 1024); \
         if (r != DLPM_OK) return r;                                                                                       \
         k_conv_split<NW_, DIST_, TAPS_><<<grid, NW_ * 64, lds, st>>>(c, nsamp, xcd_map);                                  \
     } while (0)
     // 8 waves (four per SIMD with two workgroups on a CU) measured 5 % faster than 4 waves with two register stages
     // (profiles/r02/gemm_1x1_bf16x3_variants.txt); the 4-wave shape carries the row epilogue with the fused statistics.
-    // Both accumulate every output in the same order: which one runs does not change a bit of the result.
+    // All shapes accumulate every output in the same order: which one runs does not change a bit of the result.
     if (c.ks == 1) {
-        if (c.stats_out) DLPM_SPLIT_LAUNCH(4, 2, 1);
+        if (row_stats) DLPM_SPLIT_LAUNCH(4, 2, 1);
+        else if (wide) DLPM_SPLIT_LAUNCH(16, 1, 1);
         else DLPM_SPLIT_LAUNCH(8, 1, 1);
     } else {
-        if (c.stats_out) DLPM_SPLIT_LAUNCH(4, 2, 9);
+        if (row_stats) DLPM_SPLIT_LAUNCH(4, 2, 9);
+        else if (wide) DLPM_SPLIT_LAUNCH(16, 1, 9);
         else DLPM_SPLIT_LAUNCH(8, 1, 9);
     }
 #undef DLPM_SPLIT_LAUNCH

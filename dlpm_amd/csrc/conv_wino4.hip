@@ -472,7 +472,10 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
         const int lbw = 31 - __builtin_clz(bw), lbhw = 31 - __builtin_clz(bh * bw);      // block shapes are powers of two
         float *__restrict__ out_blk = p.out + pix0 * p.Cout;
         const float *__restrict__ res_blk = has_res ? res_u + pix0 * res_ld : nullptr;
-        const bool do_stats = p.stats_out != nullptr && nimg == 1;
+        // statistics: one partial per 256-pixel block inside an image (nimg == 1), or -- four whole 8x8 images per block, four tiles
+        // each -- one per IMAGE: a lane's 64 outputs (tiles 4 lk .. 4 lk + 3) are then exactly image lk's pixels of its channel
+        const bool img_stats = p.stats_out != nullptr && nimg == 4 && bh * bw == 4;
+        const bool do_stats = (p.stats_out != nullptr && nimg == 1) || img_stats;
         float K = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -524,7 +527,10 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
                 }
             }
         }
-        if (do_stats) {
+        if (img_stats) {
+            if (img0 + lk < p.B)
+                p.stats_out[(int64_t)(img0 + lk) * p.Cout + ch] = make_float2(K + s1 * (1.f / 64.f), fmaxf(s2 - s1 * s1 * (1.f / 64.f), 0.f));
+        } else if (do_stats) {
             float mean = K + s1 * (1.f / 64.f), M2 = fmaxf(s2 - s1 * s1 * (1.f / 64.f), 0.f), na = 64.f;
 #pragma unroll
             for (int sft = 16; sft <= 32; sft <<= 1) {
@@ -590,6 +596,7 @@ int f4_mode() {   // DLPM_WINO_F4=0: keep every 3x3 layer on the F(2x2,3x3) kern
 }  // namespace
 
 bool wino4_enabled() { return f4_mode() != 0; }
+bool wino4_image_stats() { return F4_EPI_T == 0; }
 
 bool wino4_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
     if (!c.w_wino4 || c.ks != 3 || c.stride != 1 || c.in_nchw || c.out_nchw || c.abl) return false;

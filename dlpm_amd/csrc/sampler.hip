@@ -27,6 +27,7 @@ struct dlpm_sampler {
     float **hist_cell = nullptr;   // device cell with the history base (see dlpm_update_args::hist_pp)
     float *hist = nullptr;         // its current value (caller-owned [T,B,D] buffer or null)
     float *x = nullptr, *eps = nullptr, *tvec = nullptr;
+    float *emb_tab = nullptr;      // UNet, DLPM loop: the time path's output for every step, [T][emb width] (dlpm_unet_time_embeddings)
     int32_t *t_dev = nullptr;
     uint64_t *key_dev = nullptr;   // {seed, sample_offset}: read by the update kernel, so reseeding keeps the graph
     int graph_steps = 0;           // steps inside the captured graph
@@ -85,7 +86,22 @@ int sync_plan(dlpm_sampler *s) {
     return DLPM_OK;
 }
 
+// RAII: the net reads its time path from the sampler's table while one of the sampler's forward calls is being enqueued
+struct TimeTableBinding {
+    dlpm_unet *u = nullptr;
+    explicit TimeTableBinding(const dlpm_sampler *s) {
+        if (s->cfg.unet && s->emb_tab) {
+            u = s->cfg.unet;
+            (void)dlpm_unet_bind_time_table(u, s->emb_tab, s->t_dev);
+        }
+    }
+    ~TimeTableBinding() {
+        if (u) (void)dlpm_unet_bind_time_table(u, nullptr, nullptr);
+    }
+};
+
 int model_forward(dlpm_sampler *s, hipStream_t st) {
+    TimeTableBinding bound(s);
     const float *xin = s->x;
     if (s->in_scale) {
         TRY(dlpm_scale_by_table_f32(s->x, s->xin, s->cfg.B * s->D, s->t_dev, s->in_scale, st));
@@ -142,6 +158,7 @@ int one_step(dlpm_sampler *s, const float *z, bool advance, hipStream_t st) {
             TRY(dlpm_scale_by_table_f32(s->x, s->xin, s->cfg.B * s->D, s->t_dev, s->in_scale, st));
             xin = s->xin;
         }
+        TimeTableBinding bound(s);
         return dlpm_unet_forward_update(s->cfg.unet, xin, s->tvec, &a, s->eps, s->cfg.B, s->ws, s->ws_bytes, st);
     }
     TRY(model_forward(s, st));
@@ -281,6 +298,28 @@ extern "C" int dlpm_sampler_create(const dlpm_sampler_config *cfg, dlpm_sampler 
         }
         if ((e = hipMalloc(&s->ws, (size_t)s->ws_bytes)) != hipSuccess) return fail(e);
         s->plan_version = dlpm_unet_plan_version(cfg->unet);
+        // The time path (time embedding -> MLP -> per-ResBlock emb linears) is a function of the step index alone: one row per
+        // step, computed here with the kernels the forward would run (t = float(i) * (1 / T), k_fill_t's arithmetic), replaces
+        // four launches of every step.  DLPM loop only (the LIM loop feeds its own time grid).  DLPM_NO_TIME_TABLE=1: off.
+        const char *nt = getenv("DLPM_NO_TIME_TABLE");
+        const int64_t ew = dlpm_unet_time_embedding_width(cfg->unet);
+        if (!is_lim && !(nt && nt[0] == '1') && ew > 0) {
+            std::vector<float> tv(T);
+            for (int i = 0; i < T; i++) tv[i] = (float)i * (1.0f / (float)T);
+            float *tv_dev = nullptr;
+            void *scr = nullptr;
+            const int64_t scr_bytes = dlpm_unet_time_embeddings_scratch_bytes(cfg->unet, T);
+            if ((e = hipMalloc(&tv_dev, T * sizeof(float))) != hipSuccess) return fail(e);
+            if ((e = hipMemcpy(tv_dev, tv.data(), T * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) { (void)hipFree(tv_dev); return fail(e); }
+            if ((e = hipMalloc(&scr, (size_t)scr_bytes)) != hipSuccess) { (void)hipFree(tv_dev); return fail(e); }
+            if ((e = hipMalloc(&s->emb_tab, (size_t)T * ew * sizeof(float))) != hipSuccess) { (void)hipFree(tv_dev); (void)hipFree(scr); return fail(e); }
+            int r = dlpm_unet_time_embeddings(cfg->unet, tv_dev, T, s->emb_tab, scr, scr_bytes, nullptr);
+            hipError_t es = hipDeviceSynchronize();
+            (void)hipFree(tv_dev);
+            (void)hipFree(scr);
+            if (r != DLPM_OK) { dlpm_sampler_destroy(s); return r; }
+            if (es != hipSuccess) return fail(es);
+        }
     }
     *out = s;
     return DLPM_OK;
@@ -460,7 +499,7 @@ extern "C" void dlpm_sampler_destroy(dlpm_sampler *s) {
     if (s->ev_in) (void)hipEventDestroy(s->ev_in);
     if (s->ev_out) (void)hipEventDestroy(s->ev_out);
     if (s->own) (void)hipStreamDestroy(s->own);
-    void *bufs[] = {s->g, s->bg, s->s, s->bs, s->A, s->c_eps == s->A ? nullptr : s->c_eps, s->c_noise, s->x, s->eps, s->tvec,
+    void *bufs[] = {s->g, s->bg, s->s, s->bs, s->A, s->c_eps == s->A ? nullptr : s->c_eps, s->c_noise, s->x, s->eps, s->tvec, s->emb_tab,
                     s->t_dev, s->key_dev, s->ws, s->hist_cell, s->lim_ts, s->lim_tmp, s->lim_cx, s->lim_cs, s->lim_cn,
                     s->in_scale, s->xin};
     for (void *p : bufs)

@@ -129,7 +129,8 @@ void plan_stats(const dlpm_unet *u, Bump &ws, Tensor4 &t, const ConvW &c, int B,
     t.stats_px = 0;
     if (off || (!c.use_igemm && !stem)) return;
     ConvLaunch L;
-    L.w_wino = c.w_wino; L.w_wino4 = c.w_wino4; L.ks = c.ks; L.stride = stride; L.ups = ups; L.Hout = t.H; L.Wout = t.W; L.Cout = c.cout;
+    L.w_wino = c.w_wino; L.w_wino4 = c.w_wino4; L.w_split = c.w_split; L.ks = c.ks; L.stride = stride; L.ups = ups; L.Hout = t.H; L.Wout = t.W; L.Cout = c.cout;
+    L.Hin = ups ? t.H / 2 : t.H * stride; L.Win = ups ? t.W / 2 : t.W * stride;
     L.C0 = C0; L.C1 = c.cin - C0; L.B = B;
     L.in_nchw = stem ? 1 : 0;
     policy_of(u, L);
@@ -178,6 +179,10 @@ struct dlpm_unet {
     int64_t dispatch_B = 0;
     int gemm = DLPM_GEMM_AUTO;       // dlpm_unet_set_gemm_policy
     int64_t plan_version = 0;
+    // optional [T][emb_total] table of the time path's output (time embedding -> time MLP -> the per-ResBlock emb linears) and the
+    // device step counter that picks its row: bound by the sampler around its forward calls (dlpm_unet_bind_time_table)
+    const float *time_table = nullptr;
+    const int32_t *time_index = nullptr;
 
     int add(const std::string &key, int64_t numel) {
         Param p;
@@ -540,6 +545,25 @@ int run_seq(Ctx &cx, const std::vector<Layer> &seq, Tensor4 x0, Tensor4 x1, cons
     return DLPM_OK;
 }
 
+__global__ void k_table_row(const float *__restrict__ table, const int32_t *__restrict__ row, int n, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = table[(int64_t)(*row) * n + i];
+}
+
+// time embedding -> time MLP -> the row-concatenated per-ResBlock emb linears, for M rows of t (unet.py:147-150, 336-338, 470)
+int time_path(dlpm_unet *u, const float *t, int M, float *e0, float *e1, float *e2, float *out, hipStream_t st) {
+    const int mc = u->cfg.model_channels, ted = u->ted;
+    TRY(launch_timestep_embedding(t, e0, M, mc, st));
+    ConvLaunch g;
+    g.B = M; g.Hin = g.Win = g.Hout = g.Wout = 1;
+    g.src0 = e0; g.C0 = mc; g.bias = u->params[u->te0.p_b].dev; g.out = e1;
+    TRY(run_conv(u, u->te0, g, st));
+    g.src0 = e1; g.C0 = ted; g.bias = u->params[u->te2.p_b].dev; g.out = e2; g.act_silu = 1;
+    TRY(run_conv(u, u->te2, g, st));
+    g.src0 = e2; g.bias = u->embcat_b; g.out = out;
+    return run_conv(u, u->embcat, g, st);
+}
+
 int walk(dlpm_unet *u, Ctx &cx, const float *x, const float *t, float *eps) {
     const int B = cx.B, mc = u->cfg.model_channels, ted = u->ted;
     // time embedding -> time MLP -> the per-ResBlock emb linears (unet.py:147-150, 336-338, 470).  In the sampling loop t is
@@ -549,15 +573,14 @@ int walk(dlpm_unet *u, Ctx &cx, const float *x, const float *t, float *eps) {
     float *e0 = cx.ws.alloc((int64_t)B * mc), *e1 = cx.ws.alloc((int64_t)B * ted), *e2 = cx.ws.alloc((int64_t)B * ted);
     cx.embout = cx.ws.alloc((int64_t)B * u->emb_total);
     if (!cx.dry()) {
-        TRY(launch_timestep_embedding(t, e0, Bt, mc, cx.st));
-        ConvLaunch g;
-        g.B = Bt; g.Hin = g.Win = g.Hout = g.Wout = 1;
-        g.src0 = e0; g.C0 = mc; g.bias = u->params[u->te0.p_b].dev; g.out = e1;
-        TRY(run_conv(u, u->te0, g, cx.st));
-        g.src0 = e1; g.C0 = ted; g.bias = u->params[u->te2.p_b].dev; g.out = e2; g.act_silu = 1;
-        TRY(run_conv(u, u->te2, g, cx.st));
-        g.src0 = e2; g.bias = u->embcat_b; g.out = cx.embout;
-        TRY(run_conv(u, u->embcat, g, cx.st));
+        if (cx.uniform_t && u->time_table) {
+            // the whole time path is a function of the step index alone: its output for every step was computed once
+            // (dlpm_unet_time_embeddings, same kernels, one row per step -- same bits) and the step reads its row
+            k_table_row<<<(unsigned)ceil_div(u->emb_total, 256), 256, 0, cx.st>>>(u->time_table, u->time_index, u->emb_total, cx.embout);
+            DLPM_LAUNCH_CHECK();
+        } else {
+            TRY(time_path(u, t, Bt, e0, e1, e2, cx.embout, cx.st));
+        }
     }
     cx.ws.release(e0);
     cx.ws.release(e1);
@@ -802,6 +825,34 @@ extern "C" int dlpm_unet_set_gemm_policy(dlpm_unet *u, int32_t mode) {
     if (u->gemm == mode) return DLPM_OK;
     u->gemm = mode;
     u->plan_version++;
+    return DLPM_OK;
+}
+
+extern "C" int64_t dlpm_unet_time_embedding_width(const dlpm_unet *u) { return u ? u->emb_total : -1; }
+extern "C" int64_t dlpm_unet_time_embeddings_scratch_bytes(const dlpm_unet *u, int64_t M) {
+    return (u && M > 0) ? M * (u->cfg.model_channels + 2 * (int64_t)u->ted) * (int64_t)sizeof(float) : -1;
+}
+
+extern "C" int dlpm_unet_time_embeddings(dlpm_unet *net, const float *t_dev, int64_t M, float *out_dev, void *scratch_dev, int64_t scratch_bytes,
+                                         dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(net && t_dev && out_dev && scratch_dev && M > 0 && M < (1 << 24), "dlpm_unet_time_embeddings: bad argument");
+    if (!net->finalized) {
+        set_error("dlpm_unet_time_embeddings: call dlpm_unet_finalize first");
+        return DLPM_ERR_STATE;
+    }
+    const int64_t need = dlpm_unet_time_embeddings_scratch_bytes(net, M);
+    if (scratch_bytes < need) {
+        set_error("dlpm_unet_time_embeddings: scratch of %lld bytes, need %lld", (long long)scratch_bytes, (long long)need);
+        return DLPM_ERR_NOMEM;
+    }
+    float *e0 = static_cast<float *>(scratch_dev), *e1 = e0 + M * net->cfg.model_channels, *e2 = e1 + M * net->ted;
+    return time_path(net, t_dev, (int)M, e0, e1, e2, out_dev, as_stream(stream));
+}
+
+extern "C" int dlpm_unet_bind_time_table(dlpm_unet *net, const float *table_dev, const int32_t *row_index_dev) {
+    DLPM_CHECK_ARG(net && ((table_dev == nullptr) == (row_index_dev == nullptr)), "dlpm_unet_bind_time_table: give both pointers or neither");
+    net->time_table = table_dev;
+    net->time_index = row_index_dev;
     return DLPM_OK;
 }
 

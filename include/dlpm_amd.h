@@ -308,6 +308,19 @@ int64_t dlpm_unet_workspace_bytes(const dlpm_unet *net, int64_t B);
  * with t already scaled (i/T floats).  Activations live in workspace_dev (NHWC, fp32). */
 int dlpm_unet_forward(dlpm_unet *net, const float *x_dev, const float *t_dev, float *eps_dev, int64_t B,
                       void *workspace_dev, int64_t workspace_bytes, dlpm_stream_t stream);
+/* The UNet's time path -- timestep_embedding -> time_embed MLP -> the per-ResBlock emb linears, row-concatenated (unet.py:147-150,
+ * 336-338, 470) -- depends on the timestep alone, and in the sampling loop the timestep is the step index (GenerativeLevyProcess.py
+ * :319, _scale_timesteps :92-96): a sampler computes it ONCE for every step,
+ *   dlpm_unet_time_embeddings: out_dev[M][dlpm_unet_time_embedding_width(net)] for t_dev[M], with
+ *   dlpm_unet_time_embeddings_scratch_bytes(net, M) bytes of device scratch,
+ * and binds the table with the device step counter that picks the row: while a table is bound, dlpm_unet_forward_uniform_t /
+ * dlpm_unet_forward_update read row *row_index_dev instead of running the four time-path launches (same kernels produced the
+ * rows: same bits).  Bind (NULL, NULL) to unbind.  The pointers are baked into a captured graph like every other argument. */
+int64_t dlpm_unet_time_embedding_width(const dlpm_unet *net);
+int64_t dlpm_unet_time_embeddings_scratch_bytes(const dlpm_unet *net, int64_t M);
+int dlpm_unet_time_embeddings(dlpm_unet *net, const float *t_dev, int64_t M, float *out_dev, void *scratch_dev, int64_t scratch_bytes,
+                              dlpm_stream_t stream);
+int dlpm_unet_bind_time_table(dlpm_unet *net, const float *table_dev, const int32_t *row_index_dev);
 /* The same forward for a batch that shares ONE timestep (what every step of the sampling loop is: t = [i] * B,
  * GenerativeLevyProcess.py:319): only t_dev[0] is read, and the time-embedding MLP and the per-ResBlock emb linears
  * (unet.py:147-150, 336-338) are evaluated for one row instead of B identical ones.  Same bits as dlpm_unet_forward. */
