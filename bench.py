@@ -173,12 +173,43 @@ def cpu_baseline(cfg_name, T, alpha, B=32, steps=21, warm=2):
                                        'noise of one B=%d, T=%d trajectory' % (B, T)))
 
 
+def _proc_table():
+    """{pid: (ppid, starttime)} of every process visible in /proc."""
+    tab = {}
+    for d in os.listdir('/proc'):
+        if d.isdigit():
+            try:
+                f = open('/proc/%s/stat' % d).read()
+                rest = f[f.rindex(')') + 2:].split()      # fields after "(comm)": state ppid ... starttime is the 20th of them
+                tab[int(d)] = (int(rest[1]), rest[19])
+            except (OSError, ValueError, IndexError):
+                pass
+    return tab
+
+
+def _descendants(root):
+    tab = _proc_table()
+    kids = {}
+    for pid, (ppid, st) in tab.items():
+        kids.setdefault(ppid, []).append(pid)
+    out, todo = {}, [root]
+    while todo:
+        for c in kids.get(todo.pop(), []):
+            if c not in out:
+                out[c] = tab[c][1]
+                todo.append(c)
+    return out
+
+
 def spawn_ranks(n, argv, timeout_s=None):
     """`bench.py --gpus N` started plainly: launch the N ranks as FRESH children.  This process has not initialised the GPU
     (importing torch does not), and it never execs: it waits and hands the children's exit code on.  A rank that dies
     mid-trajectory leaves its peers in a barrier: torch.distributed.run notices the dead worker, terminates the others
-    and exits non-zero; should that ever not happen, the deadline (--rank-timeout, default 2 h) ends the children's own
-    process group -- never a pattern kill -- and the parent exits 124."""
+    and exits non-zero; should the ranks still be running at the deadline (--rank-timeout, default 2 h), the launcher gets
+    SIGTERM and the parent exits 124.  torch.distributed.run puts every rank into a session of its own, so neither a process
+    group nor the launcher's death reaches them (a rank orphaned in a gloo / RCCL barrier spins on its cores for the 30 minutes
+    of the collective's timeout): the parent therefore keeps the set of the launcher's descendants it has SEEN -- exact PIDs with
+    their start times, never a pattern -- and ends whichever of them outlive the launcher."""
     import signal
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
@@ -188,25 +219,53 @@ def spawn_ranks(n, argv, timeout_s=None):
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', '8')
-    child = subprocess.Popen(cmd, env=env, start_new_session=True)      # its own process group: the only thing ever signalled
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    seen = {}                       # pid -> start time of every descendant of the launcher observed so far
+    deadline = None if timeout_s is None else time.monotonic() + timeout_s
+
+    def sweep():
+        tab = _proc_table()
+        for pid, st in seen.items():
+            if pid in tab and tab[pid][1] == st:      # still the process we saw (same start time), still alive
+                try:
+                    os.kill(pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+
+    def on_term(signum, frame):     # the parent itself is being ended (a driver's timeout): take the ranks along
+        raise KeyboardInterrupt
+    signal.signal(signal.SIGTERM, on_term)
+    rc = None
     try:
-        return child.wait(timeout=timeout_s)
-    except subprocess.TimeoutExpired:
-        sys.stderr.write('bench.py: ranks still running after %.0f s -- terminating process group %d\n' % (timeout_s, child.pid))
-        for sig in (signal.SIGTERM, signal.SIGKILL):
-            try:
-                os.killpg(child.pid, sig)
-            except ProcessLookupError:
+        while True:
+            rc = child.poll()
+            if rc is not None:
                 break
-            try:
-                child.wait(timeout=20)
+            seen.update(_descendants(child.pid))
+            if deadline is not None and time.monotonic() > deadline:
+                sys.stderr.write('bench.py: ranks still running after %.0f s -- terminating the launcher (pid %d) and its %d descendants\n'
+                                 % (timeout_s, child.pid, len(seen)))
+                child.send_signal(signal.SIGTERM)       # the launcher's handler terminates its workers
+                try:
+                    child.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    child.kill()
+                    child.wait()
+                rc = 124
                 break
-            except subprocess.TimeoutExpired:
-                continue
-        return 124
+            time.sleep(0.25)
     except KeyboardInterrupt:
-        os.killpg(child.pid, signal.SIGTERM)
-        raise
+        seen.update(_descendants(child.pid))
+        child.send_signal(signal.SIGTERM)
+        try:
+            child.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            child.kill()
+        rc = 130
+    finally:
+        time.sleep(0.2)
+        sweep()
+    return rc
 
 
 class NativeRunner:
