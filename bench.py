@@ -89,6 +89,24 @@ def parse_prof(txt):
     return out
 
 
+def physical_cores():
+    """Distinct (package, core) pairs of the CPUs this process may run on, from /proc/cpuinfo; None if it cannot be read."""
+    try:
+        allowed = os.sched_getaffinity(0)
+        seen, cur = set(), {}
+        for line in open('/proc/cpuinfo').read().splitlines() + ['']:
+            if ':' in line:
+                k, v = line.split(':', 1)
+                cur[k.strip()] = v.strip()
+            elif cur:
+                if int(cur.get('processor', -1)) in allowed:
+                    seen.add((cur.get('physical id', '0'), cur.get('core id', cur.get('processor'))))
+                cur = {}
+        return len(seen) or None
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg_name, T, alpha, B=32, steps=21, warm=2):
     """The oracle (a torch-CPU port of the reference loop) on this box's host cores -- SURVEY.md 8d / BASELINE.md 4:
     B = 32, the real T-step schedule and tables, `warm` untimed reverse steps, then `steps` >= 20 reverse steps timed ONE BY ONE;
@@ -108,7 +126,11 @@ def cpu_baseline(cfg_name, T, alpha, B=32, steps=21, warm=2):
     heads = p['model']['num_heads']
     shape = [B, p['data']['channels'], p['data']['image_size'], p['data']['image_size']]
     model = lambda x, t: nets.unet_forward(sd, x, t, heads)
-    cores = torch.get_num_threads()
+    # one torch thread per PHYSICAL core (OpenMP's spinning barriers lose badly to SMT siblings and to any core the host does not
+    # actually schedule: the figure moved by 15 % between boxes with every logical CPU in use)
+    logical = torch.get_num_threads()
+    cores = physical_cores() or logical
+    torch.set_num_threads(cores)
     ev = p['eval']['dlpm']
     with torch.inference_mode():
         streams = osampler.Streams(0, 0)
@@ -159,8 +181,8 @@ def cpu_baseline(cfg_name, T, alpha, B=32, steps=21, warm=2):
     traj_full, traj_scal = init_full + (T - 1) * med_full, init_scalar + (T - 1) * med_scal
     return dict(value=round(B / traj_full, 6), unit='samples/s at T=1000', cores=cores, kind='port',
                 sample='oracle (torch-CPU port of the reference loop), same UNet and schedule, B=%d, %d untimed + %d timed reverse '
-                       'steps (t = %d..%d) on %d torch threads; value = B / (table set-up + 999 x MEDIAN step) in the reference\'s '
-                       'full-size [T,B,C,H,W] layout' % (B, warm, steps, T - 1 - warm, T - warm - steps, cores),
+                       'steps (t = %d..%d) on %d torch threads = physical cores (%d logical CPUs); value = B / (table set-up + 999 x MEDIAN step) '
+                       'in the reference\'s full-size [T,B,C,H,W] layout' % (B, warm, steps, T - 1 - warm, T - warm - steps, cores, logical),
                 median_step_s=round(med_full, 4), median_step_s_interleaved_thirds=thirds,
                 step_s_min_max=[round(float((net_t + full_t).min()), 4), round(float((net_t + full_t).max()), 4)],
                 network_share_of_step=round(float(np.median(net_t)) / med_full, 4),

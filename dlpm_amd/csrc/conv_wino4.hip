@@ -65,6 +65,11 @@ constexpr int F4_PAD = 8;         // float4 fragments of zero padding behind the
                     // (profiles/r03/conv_layers_transposed_epilogue.txt: the same 512 cache-line accesses per wave either way);
                     // 0 (the build): lane = channel, 4 tiles
 #endif
+#ifndef F4_SKIP_TAIL
+#define F4_SKIP_TAIL 0   // 1: skip the look-ahead staging / transform of the last phases (they feed chunks that do not exist): 2 of 16 phases'
+                         // side work on the K = 128 layers -- measured 1.3-2.5 % SLOWER (the two uniform branches cost the phase its schedule:
+                         // 256 VGPRs; profiles/r03/conv_layers_skip_tail_phases.txt, +0.45 ms on the whole step in alternating runs)
+#endif
 #ifndef F4_X
 #define F4_X 13    // position pair behind which waves 0..2 run the input transform (placement sweep, DLPM_BUILD_DEFS="F4_S0=..
                    // F4_X=..": X = 13 is 3-8 % faster than 3, 9, 11, 12, 14..17 for every S0; S0 = 3, 5, 7 are within 0.5 %)
@@ -304,9 +309,17 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
         if (ABL & 64) aq[F4_AAHEAD] = make_float4(1.f, 2.f, 1.f, 2.f);
 #pragma unroll
         for (int pp = 0; pp < 18; pp++) {
+#if F4_SKIP_TAIL
+            // the pipeline's look-ahead work of the LAST phases feeds chunks that do not exist: S(chunk+2) in the last two phases and
+            // X(chunk+1) in the last one are skipped (one-sided wave-uniform branches; the loads stay unconditional)
+            if (!(ABL & 1) && pp >= F4_S0 && pp < F4_S0 + F4_QNIT && chunk + 2 < nch) store_raw_item(cur, pp - F4_S0);
+            if (!(ABL & 4) && pp == F4_S0 + F4_QNIT) load_raw_into(xr, min(chunk + 3, last));
+            if (!(ABL & 2) && pp == F4_X && chunk + 1 < nch) transform(nxt);
+#else
             if (!(ABL & 1) && pp >= F4_S0 && pp < F4_S0 + F4_QNIT) store_raw_item(cur, pp - F4_S0);   // S(chunk+2): raw[cur] was read by X(chunk), a barrier ago
             if (!(ABL & 4) && pp == F4_S0 + F4_QNIT) load_raw_into(xr, min(chunk + 3, last));        // G(chunk+3)
             if (!(ABL & 2) && pp == F4_X) transform(nxt);                                             // X(chunk+1): raw[nxt] -> V[nxt]
+#endif
             if (!(ABL & 16)) bq[(pp + AHEAD) % F4_RING] = wp[AHEAD * 64 + lane];
             wp += 64;
             // A fragments are read F4_AAHEAD position pairs ahead (left to the compiler each ds_read sat directly in
