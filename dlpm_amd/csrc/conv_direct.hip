@@ -225,74 +225,111 @@ __global__ void __launch_bounds__(128) k_conv3x3_head(ConvLaunch p, HeadUpdate u
 // x <- (x - c_eps eps) / gamma + c_noise z with the Philox counters of k_update_rows (a thread owns four consecutive pixels of
 // one row = element quads of the NCHW state), and writes x: eps never reaches HBM.  HBM-bound.
 // ---------------------------------------------------------------------------------------------
-constexpr int HG_LD = 33;   // LDS words per halo pixel (odd: the 9 Cout values of neighbouring pixels fall into different banks)
+constexpr int HG_LD = 29;   // LDS words per halo pixel (odd: the 9 Cout values of neighbouring pixels fall into different banks; >= 4 ceil(27 / 4) = 28)
 
+// Persistent workgroups (HG_MINBLOCKS = 3 per CU) walk the tiles: the P rows of tile i + 1 are in flight into registers while tile i is summed,
+// updated and stored, so the HBM latency of the 134-MB read is off the critical path.  Tile ids are dealt so that the row tiles of one
+// image run on ONE XCD back to back (ids t, t + 8, t + 16, ...: the halo rows a tile shares with its neighbours are L2 hits).
+#ifndef HG_MINBLOCKS
+#define HG_MINBLOCKS 3   // workgroups per CU the register budget is set for (4 fits the LDS but needs 128 VGPRs: 14 spill, 88 instead of 38 us)
+#endif
 template <int COUT>
-__global__ void __launch_bounds__(256) k_head_gather(const float *__restrict__ P, int Np, const float *__restrict__ bias, float *out,
+__global__ void __launch_bounds__(256, HG_MINBLOCKS) k_head_gather(const float *__restrict__ P, int Np, const float *__restrict__ bias, float *out,
                                                      int out_nchw, HeadUpdate u, int B, int H, int W, int TH) {
     extern __shared__ __attribute__((aligned(16))) float hg[];
-    constexpr int NV = 9 * COUT, NQ4 = (NV + 3) / 4;
-    const int tpi = H / TH, b = blockIdx.x / tpi, y0 = (blockIdx.x % tpi) * TH;
-    const int tid = threadIdx.x, nthr = blockDim.x, W2 = W + 2;
-    // ---- P rows y0 - 1 .. y0 + TH of this image -> LDS [row][x + 1][HG_LD]; outside the image: zeros.  All 256 threads load.
+    constexpr int NV = 9 * COUT, NQ4 = (NV + 3) / 4, NPF = 10;   // NPF: float4 a thread holds of the next tile (launcher: items <= 256 NPF)
+    static_assert(4 * NQ4 <= HG_LD, "a pixel's tap values must fit its LDS slot");
+    const int tpi = H / TH, W2 = W + 2, tid = threadIdx.x;
     const int items = (TH + 2) * W2 * NQ4;
-    const float *Pb = P + (int64_t)b * H * W * Np;
-    for (int it = tid; it < items; it += nthr) {
+    const int ntiles = ((B + 7) / 8) * 8 * tpi;                   // ids beyond the batch are skipped
+    const int nq = W >> 2, per_co = TH * nq;
+    const bool computes = tid < COUT * per_co;
+    const int co = computes ? tid / per_co : 0, rq = tid - co * per_co, r = rq / nq, q = rq - r * nq;
+    const float bv = bias ? bias[co] : 0.f;
+    const int64_t HW = (int64_t)H * W, D = (int64_t)COUT * HW;
+    // per-thread geometry of its load items (the same for every tile), one packed word each: hy [31:24] | hx [23:16] | k [15:12] | valid [0]
+    uint32_t geo[NPF];
+#pragma unroll
+    for (int j = 0; j < NPF; j++) {
+        const int it = tid + j * 256;
         const int k = it % NQ4, pix = it / NQ4;
         const int hy = pix / W2, hx = pix - hy * W2;
-        const int iy = y0 + hy - 1, ix = hx - 1;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = *reinterpret_cast<const float4 *>(Pb + (int64_t)(iy * W + ix) * Np + 4 * k);
-        float *d = hg + pix * HG_LD + 4 * k;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;   // (HG_LD is odd: no 16-byte stores; slots NV .. 4 NQ4 - 1 are padding)
+        geo[j] = ((uint32_t)hy << 24) | ((uint32_t)hx << 16) | ((uint32_t)k << 12) | (it < items ? 1u : 0u);
     }
-    __syncthreads();
-    // ---- a thread = (output channel, row, quad of four consecutive pixels): one Philox counter of the update each
-    const int nq = W >> 2, per_co = TH * nq;
-    if (tid >= COUT * per_co) return;
-    const int co = tid / per_co, rq = tid - co * per_co, r = rq / nq, q = rq - r * nq;
-    const float bv = bias ? bias[co] : 0.f;
-    float acc[4] = {bv, bv, bv, bv};
+    auto tile_of = [&](int t, int &b, int &y0) {
+        const int grp = t / (8 * tpi), rem = t - grp * 8 * tpi;
+        b = grp * 8 + (rem & 7);
+        y0 = (rem >> 3) * TH;
+    };
+    float4 pf[NPF];
+    auto prefetch = [&](int t) {
+        int b, y0;
+        tile_of(t, b, y0);
+        const float *Pb = P + (int64_t)min(b, B - 1) * HW * Np;
 #pragma unroll
-    for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-        for (int kx = 0; kx < 3; kx++) {
-            const float *src = hg + ((r + ky) * W2 + 4 * q + kx) * HG_LD + (ky * 3 + kx) * COUT + co;
-#pragma unroll
-            for (int px = 0; px < 4; px++) acc[px] += src[px * HG_LD];
+        for (int j = 0; j < NPF; j++) {
+            const int hy = geo[j] >> 24, hx = (geo[j] >> 16) & 255, k = (geo[j] >> 12) & 15;
+            const int iy = y0 + hy - 1, ix = hx - 1;
+            const bool ok = (geo[j] & 1u) && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && b < B;
+            const float4 v = *reinterpret_cast<const float4 *>(Pb + (int64_t)(ok ? iy * W + ix : 0) * Np + 4 * k);   // unconditional load
+            pf[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-    const int64_t HW = (int64_t)H * W;
-    const int64_t pix = (int64_t)(y0 + r) * W + 4 * q;
-    const int64_t e0 = (int64_t)co * HW + pix;       // element index inside the sample (NCHW); e0 % 4 == 0
-    if (u.x) {
-        // the reverse update on this thread's element quad: same arithmetic, same Philox counters as k_update_rows (noise.hip)
-        const int t = *u.t;
-        const float g = u.g[t], rg = 1.0f / g;
-        const float ce = u.c_eps[(int64_t)t * u.B + b], cn = u.c_noise[(int64_t)t * u.B + b];
-        const uint64_t seed = u.key ? u.key[0] : u.seed;
-        const uint64_t gidx = (uint64_t)((u.key ? (int64_t)u.key[1] : u.sample_offset) + b);
-        float *hr = u.hist_pp ? *u.hist_pp : nullptr;
-        const int64_t D = (int64_t)COUT * HW;
-        if (hr) hr += ((int64_t)(u.T - t) * u.B + b) * D;
-        const float4 x = *reinterpret_cast<const float4 *>(u.x + (int64_t)b * D + e0);
-        float4 z;
-        if (u.z) z = *reinterpret_cast<const float4 *>(u.z + (int64_t)b * D + e0);
-        else z = (cn != 0.0f) ? philox_normal4(seed, gidx, (uint32_t)(e0 >> 2), kPurposeStepZ, (uint32_t)t) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 o;
-        o.x = fmaf(cn, z.x, div_by(x.x - ce * acc[0], g, rg));
-        o.y = fmaf(cn, z.y, div_by(x.y - ce * acc[1], g, rg));
-        o.z = fmaf(cn, z.z, div_by(x.z - ce * acc[2], g, rg));
-        o.w = fmaf(cn, z.w, div_by(x.w - ce * acc[3], g, rg));
-        *reinterpret_cast<float4 *>(u.x + (int64_t)b * D + e0) = o;
-        if (hr) *reinterpret_cast<float4 *>(hr + e0) = o;
-        if (u.eps_out) *reinterpret_cast<float4 *>(u.eps_out + (int64_t)b * D + e0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        return;
-    }
-    if (out_nchw) {
-        *reinterpret_cast<float4 *>(out + (int64_t)b * COUT * HW + e0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    } else {
+    };
+    int t = blockIdx.x;
+    if (t < ntiles) prefetch(t);
+    for (; t < ntiles; t += gridDim.x) {
+        int b, y0;
+        tile_of(t, b, y0);
 #pragma unroll
-        for (int px = 0; px < 4; px++) out[((int64_t)b * HW + pix + px) * COUT + co] = acc[px];
+        for (int j = 0; j < NPF; j++)
+            if (geo[j] & 1u) {
+                const int hy = geo[j] >> 24, hx = (geo[j] >> 16) & 255, k = (geo[j] >> 12) & 15;
+                float *d = hg + (hy * W2 + hx) * HG_LD + 4 * k;
+                d[0] = pf[j].x; d[1] = pf[j].y; d[2] = pf[j].z; d[3] = pf[j].w;   // (HG_LD is odd: no 16-byte stores)
+            }
+        __syncthreads();
+        if (t + (int)gridDim.x < ntiles) prefetch(t + gridDim.x);   // in flight while this tile is summed and stored
+        if (computes && b < B) {
+            float acc[4] = {bv, bv, bv, bv};
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    const float *src = hg + ((r + ky) * W2 + 4 * q + kx) * HG_LD + (ky * 3 + kx) * COUT + co;
+#pragma unroll
+                    for (int px = 0; px < 4; px++) acc[px] += src[px * HG_LD];
+                }
+            const int64_t pix = (int64_t)(y0 + r) * W + 4 * q;
+            const int64_t e0 = (int64_t)co * HW + pix;       // element index inside the sample (NCHW); e0 % 4 == 0
+            if (u.x) {
+                // the reverse update on this thread's element quad: same arithmetic, same Philox counters as k_update_rows (noise.hip)
+                const int tt = *u.t;
+                const float g = u.g[tt], rg = 1.0f / g;
+                const float ce = u.c_eps[(int64_t)tt * u.B + b], cn = u.c_noise[(int64_t)tt * u.B + b];
+                const uint64_t seed = u.key ? u.key[0] : u.seed;
+                const uint64_t gidx = (uint64_t)((u.key ? (int64_t)u.key[1] : u.sample_offset) + b);
+                float *hr = u.hist_pp ? *u.hist_pp : nullptr;
+                if (hr) hr += ((int64_t)(u.T - tt) * u.B + b) * D;
+                const float4 x = *reinterpret_cast<const float4 *>(u.x + (int64_t)b * D + e0);
+                float4 z;
+                if (u.z) z = *reinterpret_cast<const float4 *>(u.z + (int64_t)b * D + e0);
+                else z = (cn != 0.0f) ? philox_normal4(seed, gidx, (uint32_t)(e0 >> 2), kPurposeStepZ, (uint32_t)tt) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 o;
+                o.x = fmaf(cn, z.x, div_by(x.x - ce * acc[0], g, rg));
+                o.y = fmaf(cn, z.y, div_by(x.y - ce * acc[1], g, rg));
+                o.z = fmaf(cn, z.z, div_by(x.z - ce * acc[2], g, rg));
+                o.w = fmaf(cn, z.w, div_by(x.w - ce * acc[3], g, rg));
+                *reinterpret_cast<float4 *>(u.x + (int64_t)b * D + e0) = o;
+                if (hr) *reinterpret_cast<float4 *>(hr + e0) = o;
+                if (u.eps_out) *reinterpret_cast<float4 *>(u.eps_out + (int64_t)b * D + e0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            } else if (out_nchw) {
+                *reinterpret_cast<float4 *>(out + (int64_t)b * D + e0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            } else {
+#pragma unroll
+                for (int px = 0; px < 4; px++) out[((int64_t)b * HW + pix + px) * COUT + co] = acc[px];
+            }
+        }
+        __syncthreads();   // the tile's LDS image is dead: the next one may overwrite it
     }
 }
 
@@ -377,7 +414,8 @@ bool head_gemm_ok(const ConvLaunch &c) {
     const int W = c.Wout, H = c.Hout;
     if (W < 16 || W > 64 || (W & 3) || (H & (H - 1)) || ((int64_t)H * W) % 128 != 0) return false;
     const int TH = head_gather_rows(c);
-    return H % TH == 0 && (TH + 2) * (W + 2) * HG_LD * 4 <= 48 * 1024 && c.Cout * TH * (W / 4) <= 256;
+    const int items = (TH + 2) * (W + 2) * ((9 * c.Cout + 3) / 4);
+    return H % TH == 0 && (TH + 2) * (W + 2) * HG_LD * 4 <= 48 * 1024 && c.Cout * TH * (W / 4) <= 256 && items <= 256 * 10;
 }
 
 int64_t head_gemm_scratch_floats(const ConvLaunch &c) { return (int64_t)c.B * c.Hout * c.Wout * head_taps_rows(c.Cout); }
@@ -396,7 +434,8 @@ int launch_conv_head_gemm(const ConvLaunch &c, const HeadUpdate *hu, float *P, h
     ProfScope ps(hu ? "head_gather+update" : "head_gather", 2.0 * M * c.Cout * 9.0, bytes, st);
     HeadUpdate none{};
     const size_t shmem = (size_t)(TH + 2) * (W + 2) * HG_LD * sizeof(float);
-    const unsigned grid = (unsigned)(c.B * (H / TH)), nthr = 256;
+    const int ntiles = ((c.B + 7) / 8) * 8 * (H / TH);
+    const unsigned grid = (unsigned)std::min(ntiles, 256 * HG_MINBLOCKS), nthr = 256;   // persistent: four workgroups per CU walk the tiles
 #define DLPM_HG(CO)                                                                                                          \
     do {                                                                                                                     \
         r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_head_gather<CO>), 64 * 1024);                               \
