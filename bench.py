@@ -20,6 +20,11 @@ between barriers in the same run (`full_trajectory_s`, max over ranks) and value
 `--no-full-trajectory` skips it; value is then init + 999 * ms_per_step + gather and says so
 (`value_source`).  With --steps 999 --warmup 0 the K-step region is itself a whole trajectory.
 """
+import os as _os
+# (before torch is imported: the CPU-baseline leg's OpenMP barriers wait passively -- spinning threads lose whole steps to any
+#  core a neighbour on the GPU box's shared host takes; the GPU path does not use OpenMP)
+_os.environ.setdefault('OMP_WAIT_POLICY', 'PASSIVE')
+_os.environ.setdefault('GOMP_SPINCOUNT', '10000')
 import argparse
 import ctypes as C
 import hashlib
@@ -107,9 +112,10 @@ def physical_cores():
         return None
 
 
-def cpu_baseline(cfg_name, T, alpha, B=32, steps=21, warm=2):
+def cpu_baseline(cfg_name, T, alpha, B=32, steps=30, warm=2, threads=None):
     """The oracle (a torch-CPU port of the reference loop) on this box's host cores -- SURVEY.md 8d / BASELINE.md 4:
-    B = 32, the real T-step schedule and tables, `warm` untimed reverse steps, then `steps` >= 20 reverse steps timed ONE BY ONE;
+    B = 32, the real T-step schedule and tables, the thread count that runs it fastest, `warm` untimed reverse steps, then `steps` >= 20
+    reverse steps timed ONE BY ONE;
     the figure is built from the MEDIAN step (and the three 7-step thirds are printed, to show the spread).  Both data
     layouts are timed on the same steps: "reference-faithful" (full-size [T,B,C,H,W] A / Sigma tensors, the schedule
     re-broadcast by `repeat` twice per step: what the reference executes, and the reported `value`) and "scalar-table"
@@ -128,8 +134,26 @@ def cpu_baseline(cfg_name, T, alpha, B=32, steps=21, warm=2):
     model = lambda x, t: nets.unet_forward(sd, x, t, heads)
     # one torch thread per PHYSICAL core (OpenMP's spinning barriers lose badly to SMT siblings and to any core the host does not
     # actually schedule: the figure moved by 15 % between boxes with every logical CPU in use)
+    # The GPU boxes are slices of a shared two-socket host (256 logical CPUs, neighbours at load 30): the oracle's step at B = 32 takes
+    # 0.90 s on 128 threads, 0.42 s on 64 and 0.28 s on 32 (profiles/r03/cpu_baseline_thread_sweep.txt) -- more threads than the net's
+    # small per-layer work can feed only add barrier traffic across sockets.  The baseline is the BEST of a short sweep (two timed
+    # forwards per candidate), stated in the JSON; OpenMP waits passively (set at the top of this file).
     logical = torch.get_num_threads()
-    cores = physical_cores() or logical
+    phys = physical_cores() or logical
+    tried = {}
+    if threads:
+        cores = threads
+    else:
+        xs = torch.randn(shape, generator=torch.Generator().manual_seed(1))
+        ts = torch.full((B,), 0.5)
+        with torch.inference_mode():
+            for cand in [c for c in (8, 16, 24, 32, 48, 64, 96, 128) if c <= phys] or [phys]:
+                torch.set_num_threads(cand)
+                model(xs, ts)
+                t0 = time.perf_counter()
+                model(xs, ts); model(xs, ts)
+                tried[cand] = round((time.perf_counter() - t0) / 2, 4)
+        cores = min(tried, key=tried.get)
     torch.set_num_threads(cores)
     ev = p['eval']['dlpm']
     with torch.inference_mode():
@@ -181,8 +205,10 @@ def cpu_baseline(cfg_name, T, alpha, B=32, steps=21, warm=2):
     traj_full, traj_scal = init_full + (T - 1) * med_full, init_scalar + (T - 1) * med_scal
     return dict(value=round(B / traj_full, 6), unit='samples/s at T=1000', cores=cores, kind='port',
                 sample='oracle (torch-CPU port of the reference loop), same UNet and schedule, B=%d, %d untimed + %d timed reverse '
-                       'steps (t = %d..%d) on %d torch threads = physical cores (%d logical CPUs); value = B / (table set-up + 999 x MEDIAN step) '
-                       'in the reference\'s full-size [T,B,C,H,W] layout' % (B, warm, steps, T - 1 - warm, T - warm - steps, cores, logical),
+                       'steps (t = %d..%d) on %d torch threads (the fastest of a sweep over %s on a host of %d physical cores / %d default torch '
+                       'threads); value = B / (table set-up + 999 x MEDIAN step) in the reference\'s full-size [T,B,C,H,W] layout'
+                       % (B, warm, steps, T - 1 - warm, T - warm - steps, cores, sorted(tried) if tried else [cores], phys, logical),
+                threads_tried_forward_s=tried,
                 median_step_s=round(med_full, 4), median_step_s_interleaved_thirds=thirds,
                 step_s_min_max=[round(float((net_t + full_t).min()), 4), round(float((net_t + full_t).max()), 4)],
                 network_share_of_step=round(float(np.median(net_t)) / med_full, 4),
@@ -411,6 +437,8 @@ def main():
     ap.add_argument('--workload', default='cifar10_unet_b1024_T1000', choices=list(WORKLOADS))
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the workload\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-threads', type=int, default=0, help='torch threads of the cpu_baseline leg (default: min(physical cores, 32))')
+    ap.add_argument('--cpu-baseline-only', action='store_true', help='print only the cpu_baseline block (no GPU work)')
     ap.add_argument('--no-prof', action='store_true', help='skip the instrumented eager pass (roofline = null)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-full-trajectory', action='store_true',
@@ -431,6 +459,10 @@ def main():
                          'not the headline config')
     args = ap.parse_args()
 
+    if args.cpu_baseline_only:
+        cfg_name, _, T, alpha = WORKLOADS[args.workload]
+        print(json.dumps(cpu_baseline(cfg_name, T, alpha, threads=args.cpu_threads or None)), flush=True)
+        return
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:], args.rank_timeout))
 
@@ -596,7 +628,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
-        cpu = cpu_baseline(cfg_name, T, alpha)
+        cpu = cpu_baseline(cfg_name, T, alpha, threads=args.cpu_threads or None)
 
     if rank == 0:
         step_tflops = run.flops_per_sample * B * world / (ms_per_step * 1e-3) / 1e12

@@ -267,3 +267,28 @@ def test_activation_arena_recycles_buffers():
         assert abs(L.dlpm_unet_workspace_bytes(h, 1024) * 8 - need) < 0.01 * need
     finally:
         L.dlpm_unet_destroy(h)
+
+
+def test_split_epilogue_ragged_tile_addresses_stay_inside_the_tensor():
+    """conv_split.hip, split_store_from_registers<MASKED>: on a ragged last tile (B * HW not a multiple of 128) every lane's
+    residual READ and output WRITE must land on a row below M, also for lanes whose first row already lies beyond it (round-2
+    advisor finding: the clamp was relative to the lane's first row and read up to 48 rows behind the tensor).  The kernel's
+    index arithmetic, restated: row0 = m0 + wm * 64 + 4 * kh, lane rows i * 32 + (r & 3) + 8 * (r >> 2); residual rows are
+    clamped to min(row, rlim) >= 0 from the lane's clamped first row min(wm * 64 + 4 * kh, mrem - 1); writes are masked by row <= rlim."""
+    for M in (16, 48, 64, 100, 127, 129, 192, 3 * 64 + 16, 5 * 16):
+        m0 = (M // 128) * 128
+        mrem = min(128, M - m0)
+        if mrem == 128 or mrem <= 0:
+            continue
+        for wm in (0, 1):
+            for kh in (0, 1):
+                first = wm * 64 + 4 * kh
+                rlim = mrem - 1 - first
+                rres0 = min(first, mrem - 1)
+                for i in (0, 1):
+                    for r in range(16):
+                        row = i * 32 + (r & 3) + 8 * (r >> 2)
+                        read_row = m0 + rres0 + max(min(row, rlim), 0)
+                        assert 0 <= read_row < M, (M, wm, kh, i, r, read_row)
+                        if row <= rlim:
+                            assert m0 + first + row < M
