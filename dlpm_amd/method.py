@@ -472,7 +472,10 @@ class GenerativeLevyProcess:
             else:
                 out = self._run_callable(model, list(shape), flags, eta, clamp_a, clamp_eps, noise, history, progress,
                                          denoised_fn=denoised_fn, model_kwargs=model_kwargs)
-        self.calls += 1
+        if self._dataset is not None:
+            self._dataset['next'] += shape[0]
+        else:
+            self.calls += 1
         return out
 
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=False, denoised_fn=None, model_kwargs=None, progress=False,
