@@ -112,11 +112,12 @@ def physical_cores():
         return None
 
 
-def cpu_baseline(cfg_name, T, alpha, B=32, steps=30, warm=2, threads=None):
+def cpu_baseline(cfg_name, T, alpha, B=32, steps=60, warm=2, threads=None):
     """The oracle (a torch-CPU port of the reference loop) on this box's host cores -- SURVEY.md 8d / BASELINE.md 4:
     B = 32, the real T-step schedule and tables, the thread count that runs it fastest, `warm` untimed reverse steps, then `steps` >= 20
     reverse steps timed ONE BY ONE;
-    the figure is built from the MEDIAN step (and the three 7-step thirds are printed, to show the spread).  Both data
+    the figure is the MEDIAN OF THREE: the steps form three consecutive blocks of `steps` / 3 >= 20, each block gives B / (set-up +
+    999 x its median step), and the middle one is reported (all three are printed).  Both data
     layouts are timed on the same steps: "reference-faithful" (full-size [T,B,C,H,W] A / Sigma tensors, the schedule
     re-broadcast by `repeat` twice per step: what the reference executes, and the reported `value`) and "scalar-table"
     ([T,B] tables); the network forward is common to both.  The table set-up (A expansion + Sigma recursion) is timed
@@ -151,8 +152,8 @@ def cpu_baseline(cfg_name, T, alpha, B=32, steps=30, warm=2, threads=None):
                 torch.set_num_threads(cand)
                 model(xs, ts)
                 t0 = time.perf_counter()
-                model(xs, ts); model(xs, ts)
-                tried[cand] = round((time.perf_counter() - t0) / 2, 4)
+                model(xs, ts); model(xs, ts); model(xs, ts)
+                tried[cand] = round((time.perf_counter() - t0) / 3, 4)
         cores = min(tried, key=tried.get)
     torch.set_num_threads(cores)
     ev = p['eval']['dlpm']
@@ -200,16 +201,21 @@ def cpu_baseline(cfg_name, T, alpha, B=32, steps=30, warm=2, threads=None):
         _lib.check(L.dlpm_skewed_levy_host_f32(C.byref(mt), float(alpha), na, -1.0, buf.ctypes.data))
         levy_rate = na / (time.perf_counter() - t0)
     D = shape[1] * shape[2] * shape[3]
-    med_full, med_scal = float(np.median(net_t + full_t)), float(np.median(net_t + scal_t))
-    thirds = [round(float(np.median((net_t + full_t)[j::3])), 4) for j in range(3)]
+    nb = steps // 3
+    blocks_full = [float(np.median((net_t + full_t)[j * nb:(j + 1) * nb])) for j in range(3)]     # three runs of >= 20 steps
+    blocks_scal = [float(np.median((net_t + scal_t)[j * nb:(j + 1) * nb])) for j in range(3)]
+    med_full, med_scal = sorted(blocks_full)[1], sorted(blocks_scal)[1]                           # ... and their median
+    thirds = [round(v, 4) for v in blocks_full]
     traj_full, traj_scal = init_full + (T - 1) * med_full, init_scalar + (T - 1) * med_scal
     return dict(value=round(B / traj_full, 6), unit='samples/s at T=1000', cores=cores, kind='port',
                 sample='oracle (torch-CPU port of the reference loop), same UNet and schedule, B=%d, %d untimed + %d timed reverse '
                        'steps (t = %d..%d) on %d torch threads (the fastest of a sweep over %s on a host of %d physical cores / %d default torch '
-                       'threads); value = B / (table set-up + 999 x MEDIAN step) in the reference\'s full-size [T,B,C,H,W] layout'
-                       % (B, warm, steps, T - 1 - warm, T - warm - steps, cores, sorted(tried) if tried else [cores], phys, logical),
+                       'threads); value = the median of three blocks of %d steps, each B / (table set-up + 999 x its median step), in the reference\'s '
+                       'full-size [T,B,C,H,W] layout'
+                       % (B, warm, steps, T - 1 - warm, T - warm - steps, cores, sorted(tried) if tried else [cores], phys, logical, steps // 3),
                 threads_tried_forward_s=tried,
-                median_step_s=round(med_full, 4), median_step_s_interleaved_thirds=thirds,
+                median_step_s=round(med_full, 4), median_step_s_of_the_three_blocks=thirds,
+                value_of_the_three_blocks=[round(B / (init_full + (T - 1) * v), 6) for v in blocks_full],
                 step_s_min_max=[round(float((net_t + full_t).min()), 4), round(float((net_t + full_t).max()), 4)],
                 network_share_of_step=round(float(np.median(net_t)) / med_full, 4),
                 table_setup_s=round(init_full, 3), timed_cpu_seconds=round(float((net_t + full_t + scal_t).sum()), 1),
