@@ -34,6 +34,11 @@ SHAPES = [s for s in [
     ('3x3 wino H32 128->128', 1024, 128, 0, 32, 128, 3, True, True),
     ('3x3 wino H16 256->256', 1024, 256, 0, 16, 256, 3, True, True),
     ('3x3 wino H32 128+128->128', 1024, 128, 128, 32, 128, 3, True, False),
+    # the MNIST net's launch shapes (B = 256): PHASE_ONLY=mnist
+    ('3x3 mnist H16 64->64', 256, 64, 0, 16, 64, 3, True, True),
+    ('3x3 mnist H8 64->64', 256, 64, 0, 8, 64, 3, True, True),
+    ('3x3 mnist H4 64->64', 256, 64, 0, 4, 64, 3, True, True),
+    ('3x3 mnist H32 32->32', 256, 32, 0, 32, 32, 3, True, True),
 ] if os.environ.get('PHASE_ONLY', '') in s[0]]
 
 
@@ -79,6 +84,9 @@ def run(name, B, C0, C1, H, Cout, ks, coef, res, reps=5):
     n = ph[base + 3]
     pro, main, epi = (ph[base + i] / max(n, 1) for i in range(3))
     tot = pro + main + epi
+    if tot == 0:
+        print('%-30s %8.3f ms/call(+relayout)  (this shape\'s kernel carries no phase counters)' % (name, e0.elapsed_time(e1) / reps))
+        return
     print('%-30s %8.3f ms/call(+relayout)  wgs/launch %6d  cycles/wg: prologue %7.0f (%4.1f%%)  loop %7.0f (%4.1f%%)  epilogue %7.0f (%4.1f%%)'
           % (name, e0.elapsed_time(e1) / reps, n // reps, pro, 100 * pro / tot, main, 100 * main / tot, epi, 100 * epi / tot))
     if any(ph[4 + i] for i in range(4)):
