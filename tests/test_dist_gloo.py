@@ -124,3 +124,24 @@ def test_bench_rank_dying_mid_trajectory_fails_the_parent_within_the_deadline():
     r, out = _run_bench(env, '--gpus', '2', '--steps', '5', '--warmup', '2', '--batch', '4', '--rank-timeout', '25', timeout=400)
     assert r.returncode == 124 and not out, (r.returncode, r.stdout)
     assert time.time() - t0 < 120
+
+
+def test_bench_under_the_drivers_own_launcher_command():
+    """The driver's N > 1 command verbatim: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- every process is ONE rank (RANK / LOCAL_RANK / WORLD_SIZE from the
+    environment, no second spawn), rank 0 prints the single JSON line."""
+    import json
+    import subprocess
+    env = dict(os.environ, DLPM_BENCH_DRY_RUN='1', OMP_NUM_THREADS='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    port = 29600 + os.getpid() % 300
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--batch', '4'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(out) == 1, r.stdout
+    j = out[0]
+    assert j['n_gpus'] == 2 and j['steps'] == 3 and j['warmup'] == 1 and j['config']['global_batch'] == 8
+    assert 'cpu_baseline' not in j or j['cpu_baseline'] is None      # rank 0 at N = 1 only
