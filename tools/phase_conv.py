@@ -43,6 +43,7 @@ SHAPES = [s for s in [
 
 
 def run(name, B, C0, C1, H, Cout, ks, coef, res, reps=5):
+    B = int(os.environ.get('PHASE_B', B))    # e.g. 8: a launch of 32 workgroups, every one alone on its CU and (nearly) alone on the HBM
     Cin = C0 + C1
     x0 = torch.randn(B, H, H, C0, device=DEV)
     x1 = torch.randn(B, H, H, C1, device=DEV) if C1 else None
