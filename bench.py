@@ -182,6 +182,7 @@ def cpu_baseline(cfg_name, T, alpha, B=32, steps=60, warm=2, threads=None):
         x = bs[-1] * torch.clamp(torch.sqrt(streams.skewed_levy(alpha, B, None)).view(-1, 1, 1, 1) * streams.randn(shape),
                                  -ev['clamp_eps'], ev['clamp_eps'])
         net_t, full_t, scal_t = [], [], []
+        same_bits = True          # the two data layouts step to the same bits (recorded, not asserted: a NaN must not void the bench line)
         i = T - 1
         for k in range(warm + steps):
             t0 = time.perf_counter()
@@ -192,7 +193,7 @@ def cpu_baseline(cfg_name, T, alpha, B=32, steps=60, warm=2, threads=None):
             t2 = time.perf_counter()
             xs, _, _ = P.dlpm_step(x, eps, i, Sig, g, bs, z)
             t3 = time.perf_counter()
-            assert torch.equal(xf, xs)
+            same_bits = same_bits and bool(torch.equal(torch.nan_to_num(xf, nan=7.0), torch.nan_to_num(xs, nan=7.0)))
             x, i = xf, i - 1
             if k >= warm:
                 net_t.append(t1 - t0); full_t.append(t2 - t1); scal_t.append(t3 - t2)
@@ -216,7 +217,8 @@ def cpu_baseline(cfg_name, T, alpha, B=32, steps=60, warm=2, threads=None):
     med_full, med_scal = sorted(blocks_full)[1], sorted(blocks_scal)[1]                           # ... and their median
     thirds = [round(v, 4) for v in blocks_full]
     traj_full, traj_scal = init_full + (T - 1) * med_full, init_scalar + (T - 1) * med_scal
-    return dict(value=round(B / traj_full, 6), unit='samples/s at T=1000', cores=cores, kind='port',
+    return dict(value=round(B / traj_full, 6), unit='samples/s at T=1000', cores=cores, threads=cores, physical_cores=phys,
+                logical_cpus=logical, layouts_bit_identical=same_bits, kind='port',
                 sample='oracle (torch-CPU port of the reference loop), same UNet and schedule, B=%d, %d untimed + %d timed reverse '
                        'steps (t = %d..%d) on %d torch threads (the fastest of a sweep over %s, 32 kept unless another count is > 10 %% faster, on a host of %d physical cores / %d default torch '
                        'threads); value = the median of three blocks of %d steps, each B / (table set-up + 999 x its median step), in the reference\'s '
@@ -452,7 +454,7 @@ def main():
     ap.add_argument('--workload', default='cifar10_unet_b1024_T1000', choices=list(WORKLOADS))
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the workload\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-threads', type=int, default=0, help='torch threads of the cpu_baseline leg (default: min(physical cores, 32))')
+    ap.add_argument('--cpu-threads', type=int, default=0, help='torch threads of the cpu_baseline leg (default: the fastest of a sweep over 8..128 <= physical cores; 32 kept unless another count is > 10 %% faster)')
     ap.add_argument('--cpu-baseline-only', action='store_true', help='print only the cpu_baseline block (no GPU work)')
     ap.add_argument('--no-prof', action='store_true', help='skip the instrumented eager pass (roofline = null)')
     ap.add_argument('--no-graph', action='store_true')
@@ -505,6 +507,17 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     from dlpm_amd.dist import all_gather_samples
 
+    def device_identity():
+        """What tells this rank's GPU from every other GPU of the node: UUID and PCI address from the driver."""
+        if dev.type != 'cuda':
+            return dict(device_index=None, device_uuid=None, pci_bus_id=None, device_name='cpu (dry run)')
+        pr = torch.cuda.get_device_properties(dev)
+        pci = None
+        if hasattr(pr, 'pci_bus_id'):
+            pci = '%04x:%02x:%02x' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, getattr(pr, 'pci_device_id', 0))
+        uuid = getattr(pr, 'uuid', None)
+        return dict(device_index=dev.index, device_uuid=None if uuid is None else str(uuid), pci_bus_id=pci, device_name=pr.name)
+
     cfg_name, B, T, alpha = WORKLOADS[args.workload]
     if args.batch:
         B = args.batch
@@ -540,6 +553,7 @@ def main():
     run.steps(K)
     barrier()
     dt = time.perf_counter() - t0
+    own_ms_per_step = dt / K * 1e3          # this rank's clock (the line's ms_per_step is the max over ranks)
     dt, init_s = max_over_ranks(dt, init_s)
     ms_per_step = dt / K * 1e3
     # ---- final gather of the finished samples: ONE RCCL all-gather (nothing to gather on one GPU)
@@ -555,6 +569,31 @@ def main():
         full = x
     finite = bool(torch.isfinite(full).all().item())
     assert full.shape[0] == B * world
+    # ---- who ran: one record per rank (rank, device index, UUID / PCI address, its own step time, a checksum of ITS shard and of
+    # the same rows of the gathered batch), collected with ONE all_gather_object -- so that the line proves N distinct devices and
+    # that the collective of the stated backend delivered every rank's shard
+    me = dict(rank=rank, local_rank=local, pid=os.getpid(), ms_per_step=round(own_ms_per_step, 4), **device_identity())
+    me['shard_checksum'] = float(x.double().sum().item())
+    me['gathered_rows_checksum'] = float(full[rank * B:(rank + 1) * B].double().sum().item())
+    if world > 1:
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
+        dist_info = dict(backend=dist.get_backend(), world_size=dist.get_world_size(),
+                         collective='all_gather_into_tensor (dlpm_amd.dist.all_gather_samples)',
+                         allgather_bytes=int(full.numel() * full.element_size()),
+                         allgather_bytes_per_rank_sent=int(x.numel() * x.element_size()))
+        # every rank holds the same gathered batch: each rank's shard checksum must reappear in EVERY rank's copy of those rows
+        mine = [float(full[r * B:(r + 1) * B].double().sum().item()) for r in range(world)]
+        shard_sums = [ri['shard_checksum'] for ri in ranks_info]
+        dist_info['gather_verified'] = bool(all(a == b for a, b in zip(mine, shard_sums)))
+        assert dist_info['gather_verified'], 'the gathered batch does not hold the shards the ranks produced'
+        ids = [ri['device_uuid'] or ri['pci_bus_id'] for ri in ranks_info]
+        dist_info['distinct_devices'] = len(set(ids)) if all(i is not None for i in ids) else None
+        if backend == 'nccl' and os.environ.get('DLPM_BENCH_SINGLE_DEVICE') != '1':
+            assert dist_info['distinct_devices'] == world, 'RCCL ranks share a device: %s' % ids
+    else:
+        ranks_info, dist_info = [me], dict(backend=None, world_size=1, collective=None, allgather_bytes=0,
+                                           allgather_bytes_per_rank_sent=0, gather_verified=None, distinct_devices=1)
 
     # ---- one WHOLE trajectory, timed end to end: init + every reverse step + gather
     full_s = None
@@ -668,6 +707,8 @@ def main():
             'whole_step_tflops': round(step_tflops, 3),
             'whole_step_frac_of_fp32_peak': round(step_tflops / (PEAK_FP32_MFMA_TFLOPS * world), 4),
             'samples_finite': finite,
+            'ranks': ranks_info, 'backend': dist_info['backend'], 'rccl_world_size': dist_info['world_size'],
+            'allgather_bytes': dist_info['allgather_bytes'], 'distributed': dist_info,
             'roofline': roofline, 'split_gemm_kernel': split, 'update_kernel': upd, 'attention_kernel': att, 'ms_per_step_by_kernel_class': breakdown, 'cpu_baseline': cpu,
         }
         if dry:

@@ -6,10 +6,16 @@
 //
 //     Y = A^T [ (G g G^T) .* (B^T d B) ] A        d: 6x6 input tile, g: 3x3 filter, Y: 4x4 output tile
 //
-// with the transform matrices of Lavin & Gray (interpolation points 0, +-1, +-2, inf): rows of B^T above transform(),
-// rows of A^T in the epilogue, G in k_relayout_weight_wino4.
-// The price is numerical: the transforms amplify rounding (|B^T| rows sum to 10, |A^T| to 19); through the whole CIFAR
-// UNet the result differs from the reference's own output by 1.6e-5 (F(2x2): 3e-6; the path's budget is 1e-4).
+// with Toom-Cook transform matrices for the interpolation points {0, +-a, +-b, inf}, (a, b) = (11/16, 3/2) (F4_PA, F4_PB below;
+// Lavin & Gray's matrices are a = 1, b = 2): rows of B^T above transform(), rows of A^T in the epilogue, G in
+// k_relayout_weight_wino4.
+// The price is numerical: the products are accumulated over the input channels IN the Winograd domain, where the partial sums
+// are larger than the result they cancel to, and the point set fixes by how much.  tools/err_wino4_points.py (round 4,
+// profiles/r04/err_wino4_points.txt) emulates the kernel's arithmetic for the whole symmetric family -- every member costs
+// the same VALU instructions in the loop, only the constants change -- and finds a flat optimum around a in [0.62, 0.71],
+// b in [1.4, 1.6]: 2.2x lower rms and 3.5-4x lower max error than (1, 2) (8.3e-7 / 6e-6 against 1.8e-6 / 2.1-3.0e-5 of the fp64
+// convolution at 128-256 channels; fp32 direct convolution: 5e-7).  All constants (a, b, their squares, cubes, a^2 + b^2,
+// a^2 b^2) are exact in fp32.  F4_POINTS_LAVIN (DLPM_BUILD_DEFS) rebuilds the round-1..3 point set for A/B error measurements.
 //
 // Work split (one workgroup per CU, 8 waves, 16 tiles x 128 output channels):
 //   * the 36 transform positions are 36 independent GEMMs  M_pos[tile][cout] = sum_cin V_pos[tile][cin] U_pos[cin][cout];
@@ -40,7 +46,8 @@ constexpr int F4_KC = 8;          // input channels per phase (2 MFMA k-steps)
 constexpr int F4_RAWPIX = 576;    // halo pixels per phase: one 18x18 patch, 4 x 10x10 or 16 x 6x6 (whole small images)
 constexpr int F4_PRLD = F4_KC + 4;
 constexpr int F4_NT = 512;
-constexpr int F4_QNIT = (F4_RAWPIX * 2 + F4_NT - 1) / F4_NT;   // staging items (pixel, channel quad) per thread: 3
+constexpr int F4_QNIT = (F4_RAWPIX * 2 + F4_NT - 1) / F4_NT;   // staging items (pixel, channel quad) per thread for a full 576-pixel patch: 3
+                                                               // (only 16 one-tile images fill it; every other block shape is <= 512 pixels: QN = 2)
 constexpr int F4_RAWBUF = F4_RAWPIX * F4_PRLD + 16;   // floats per raw buffer, row skew included
 constexpr int F4_CFS = 16 * 2 * F4_KC;   // floats per GroupNorm-coefficient slot: [16 images][A | B][8]
 constexpr int F4_VBUF = 36 * F4_TILES * F4_KC;   // floats per V buffer: [18 position pairs][4 channel pairs][16 tiles][4]
@@ -75,17 +82,33 @@ constexpr int F4_PAD = 8;         // float4 fragments of zero padding behind the
                    // F4_X=..": X = 13 is 3-8 % faster than 3, 9, 11, 12, 14..17 for every S0; S0 = 3, 5, 7 are within 0.5 %)
 #endif
 
+// Interpolation points {0, +-a, +-b, inf}.  Row j of B^T holds the coefficients of prod_{l != j} (x - p_l) (the inf row: of the
+// product over all finite points), A^T[i][j] = p_j^i, G[j][k] = p_j^k / prod_{l != j} (p_j - p_l):
 // one line of B^T d (or of T B): the six transform rows from six samples x0..x5
-//   r0 = 4 x0 - 5 x2 + x4          r5 = 4 x1 - 5 x3 + x5
-//   r1 = (x4 - 4 x2) + (x3 - 4 x1) r2 = (x4 - 4 x2) - (x3 - 4 x1)
-//   r3 = (x4 - x2) + 2 (x3 - x1)   r4 = (x4 - x2) - 2 (x3 - x1)
+//   r0 = a^2 b^2 x0 - (a^2 + b^2) x2 + x4              r5 = a^2 b^2 x1 - (a^2 + b^2) x3 + x5
+//   r1 = (x4 - b^2 x2) + a (x3 - b^2 x1)               r2 = (x4 - b^2 x2) - a (x3 - b^2 x1)
+//   r3 = (x4 - a^2 x2) + b (x3 - a^2 x1)               r4 = (x4 - a^2 x2) - b (x3 - a^2 x1)
+// and of A^T m:  y0 = m0 + (m1 + m2) + (m3 + m4)         y1 = a (m1 - m2) + b (m3 - m4)
+//                y2 = a^2 (m1 + m2) + b^2 (m3 + m4)      y3 = a^3 (m1 - m2) + b^3 (m3 - m4) + m5
+#ifdef F4_POINTS_LAVIN
+#define F4_PA 1.0
+#define F4_PB 2.0
+#else
+#define F4_PA 0.6875
+#define F4_PB 1.5
+#endif
+constexpr float PA = (float)F4_PA, PB = (float)F4_PB, PA2 = (float)(F4_PA * F4_PA), PB2 = (float)(F4_PB * F4_PB);
+constexpr float PA3 = (float)(F4_PA * F4_PA * F4_PA), PB3 = (float)(F4_PB * F4_PB * F4_PB);
+constexpr float PS2 = (float)(F4_PA * F4_PA + F4_PB * F4_PB), PP2 = (float)(F4_PA * F4_PA * F4_PB * F4_PB);
 __device__ __forceinline__ float2 f2fma(float a, float2 x, float2 y) { return make_float2(fmaf(a, x.x, y.x), fmaf(a, x.y, y.y)); }
 __device__ __forceinline__ float2 f2add(float2 x, float2 y) { return make_float2(x.x + y.x, x.y + y.y); }
 __device__ __forceinline__ float2 f2sub(float2 x, float2 y) { return make_float2(x.x - y.x, x.y - y.y); }
 
 // ABL (DLPM_WINO_ABLATIONS builds, DLPM_WABL): timing-only ablations, results are wrong: 1 no staging stores, 2 no transform,
 // 4 no raw loads, 8 no barrier, 16 no weight loads, 32 no MFMA, 64 no A-fragment reads
-template <bool UPS, int ABL = 0>
+// QN: staging items per thread (2 for halo patches of <= 512 pixels -- every block shape but 16 whole 4x4 images; round 4: the third
+// item's geometry registers and its dead branch per phase pushed the main instantiation into a scratch reload inside the loop)
+template <bool UPS, int ABL = 0, int QN = F4_QNIT>
 __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh, int bw, int nimg) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float *V = wsm;                               // [2][18][4][16][4]
@@ -130,30 +153,29 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
     // transform's lanes are 16 tiles x 2 channel pairs per LDS pass; without the skew the four tile rows of a block start
     // 864 ty floats apart = the same 16-bank group for ty and ty + 2 (2-way to 4-way conflicts on its 84 reads per phase).
     const bool skewed = !UPS && nimg == 1 && bh <= 4;   // (18 patch rows: the skew stays inside the 16 floats of slack)
-    int off[F4_QNIT], cfo[F4_QNIT], lo[F4_QNIT];
+    int off[QN], lo[QN];   // lo: LDS float offset of the item (bits 0..15) | its image's coefficient offset (bits 16..)
 #pragma unroll
-    for (int it = 0; it < F4_QNIT; it++) {
+    for (int it = 0; it < QN; it++) {
         const int pix = pix_of(it);
         const int img = min(pix / rpi, nimg - 1), r = pix - img * rpi;
         const int ry = r / RW, rx = r - ry * RW;
         const int iy = oy + ry, ix = ox + rx;
         const bool pad = iy < 0 || iy >= Hs || ix < 0 || ix >= Ws || (img0 + img) >= p.B;
         off[it] = pix >= npix ? -2 : (pad ? -1 : (((img0 + img) * Hs + iy) * Ws + ix));
-        cfo[it] = img * 2 * F4_KC + squad * 4;
-        lo[it] = pix * F4_PRLD + squad * 4 + (skewed ? 4 * (ry >> 2) : 0);
+        lo[it] = (pix * F4_PRLD + squad * 4 + (skewed ? 4 * (ry >> 2) : 0)) | ((img * 2 * F4_KC + squad * 4) << 16);
     }
     const bool has_coef = p.coefA != nullptr;
     const int cf_img = tid >> 2, cf_isb = (tid >> 1) & 1;
     const bool cf_mine = has_coef && tid < nimg * 4;
     const float *cf_base = has_coef ? ((cf_isb ? p.coefB : p.coefA) + (int64_t)min(img0 + cf_img, p.B - 1) * Cin + squad * 4) : nullptr;
-    float4 xr[F4_QNIT], cfr = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto load_raw_into = [&](float4 (&dst)[F4_QNIT], int chunk) {
+    float4 xr[QN], cfr = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_raw_into = [&](float4 (&dst)[QN], int chunk) {
         const int c = chunk * F4_KC + squad * 4;
         const bool first = c < p.C0;
         const float *sb = first ? p.src0 + c : p.src1 + (c - p.C0);
         const int ld = first ? p.C0 : p.C1;
 #pragma unroll
-        for (int it = 0; it < F4_QNIT; it++) dst[it] = *reinterpret_cast<const float4 *>(sb + (int64_t)max(off[it], 0) * ld);
+        for (int it = 0; it < QN; it++) dst[it] = *reinterpret_cast<const float4 *>(sb + (int64_t)max(off[it], 0) * ld);
     };
     auto load_coef = [&](int chunk) {
         if (cf_mine) cfr = *reinterpret_cast<const float4 *>(cf_base + chunk * F4_KC);
@@ -166,8 +188,8 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
         float *rb = raw + slot * F4_RAWBUF;
         float4 x = xr[it];
         if (has_coef) {
-            const float4 ca = *reinterpret_cast<const float4 *>(Cf + slot * F4_CFS + cfo[it]);
-            const float4 cb = *reinterpret_cast<const float4 *>(Cf + slot * F4_CFS + cfo[it] + F4_KC);
+            const float4 ca = *reinterpret_cast<const float4 *>(Cf + slot * F4_CFS + (lo[it] >> 16));
+            const float4 cb = *reinterpret_cast<const float4 *>(Cf + slot * F4_CFS + (lo[it] >> 16) + F4_KC);
             x.x = fmaf(x.x, ca.x, cb.x);
             x.y = fmaf(x.y, ca.y, cb.y);
             x.z = fmaf(x.z, ca.z, cb.z);
@@ -180,11 +202,11 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
             x.w = silu_f(x.w);
         }
         if (off[it] < 0) x = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding applies AFTER the activation
-        *reinterpret_cast<float4 *>(rb + lo[it]) = x;
+        *reinterpret_cast<float4 *>(rb + (lo[it] & 0xffff)) = x;
     };
     auto store_raw = [&](int slot) {
 #pragma unroll
-        for (int it = 0; it < F4_QNIT; it++) store_raw_item(slot, it);
+        for (int it = 0; it < QN; it++) store_raw_item(slot, it);
     };
 
     // ---- input transform V = B^T d B: waves 0..2 take the row pairs (0,5), (1,2), (3,4) of B^T; lane = (channel pair, tile),
@@ -212,36 +234,34 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
         if (wave == 0) {
 #pragma unroll
             for (int c = 0; c < 6; c++) {
-                Ta[c] = f2fma(4.f, d(0, c), f2fma(-5.f, d(2, c), d(4, c)));
-                Tb[c] = f2fma(4.f, d(1, c), f2fma(-5.f, d(3, c), d(5, c)));
+                Ta[c] = f2fma(PP2, d(0, c), f2fma(-PS2, d(2, c), d(4, c)));
+                Tb[c] = f2fma(PP2, d(1, c), f2fma(-PS2, d(3, c), d(5, c)));
             }
             a0 = 0; a1 = 5;
         } else if (wave == 1) {
 #pragma unroll
             for (int c = 0; c < 6; c++) {
-                const float2 e = f2fma(-4.f, d(2, c), d(4, c)), o = f2fma(-4.f, d(1, c), d(3, c));
-                Ta[c] = f2add(e, o);
-                Tb[c] = f2sub(e, o);
+                const float2 e = f2fma(-PB2, d(2, c), d(4, c)), o = f2fma(-PB2, d(1, c), d(3, c));
+                Ta[c] = f2fma(PA, o, e);
+                Tb[c] = f2fma(-PA, o, e);
             }
             a0 = 1; a1 = 2;
         } else {
 #pragma unroll
             for (int c = 0; c < 6; c++) {
-                const float2 e = f2sub(d(4, c), d(2, c)), o0 = f2sub(d(3, c), d(1, c));
-                const float2 o = make_float2(2.f * o0.x, 2.f * o0.y);
-                Ta[c] = f2add(e, o);
-                Tb[c] = f2sub(e, o);
+                const float2 e = f2fma(-PA2, d(2, c), d(4, c)), o = f2fma(-PA2, d(1, c), d(3, c));
+                Ta[c] = f2fma(PB, o, e);
+                Tb[c] = f2fma(-PB, o, e);
             }
             a0 = 3; a1 = 4;
         }
         // positions (a, 0..5) of row a = position pairs 3 a .. 3 a + 2: one float4 {pos 2 pp: 2 channels, pos 2 pp + 1: 2 channels} each
         auto row_out = [&](const float2 (&T)[6], int a) {
             float *vr = vb + a * 3 * (4 * F4_TILES * 4);
-            const float2 e1 = f2fma(-4.f, T[2], T[4]), o1 = f2fma(-4.f, T[1], T[3]);
-            const float2 e2 = f2sub(T[4], T[2]), q2 = f2sub(T[3], T[1]);
-            const float2 o2 = make_float2(2.f * q2.x, 2.f * q2.y);
-            const float2 v0 = f2fma(4.f, T[0], f2fma(-5.f, T[2], T[4])), v1 = f2add(e1, o1), v2 = f2sub(e1, o1);
-            const float2 v3 = f2add(e2, o2), v4 = f2sub(e2, o2), v5 = f2fma(4.f, T[1], f2fma(-5.f, T[3], T[5]));
+            const float2 e1 = f2fma(-PB2, T[2], T[4]), o1 = f2fma(-PB2, T[1], T[3]);
+            const float2 e2 = f2fma(-PA2, T[2], T[4]), o2 = f2fma(-PA2, T[1], T[3]);
+            const float2 v0 = f2fma(PP2, T[0], f2fma(-PS2, T[2], T[4])), v1 = f2fma(PA, o1, e1), v2 = f2fma(-PA, o1, e1);
+            const float2 v3 = f2fma(PB, o2, e2), v4 = f2fma(-PB, o2, e2), v5 = f2fma(PP2, T[1], f2fma(-PS2, T[3], T[5]));
             *reinterpret_cast<float4 *>(vr + 0 * (4 * F4_TILES * 4)) = make_float4(v0.x, v0.y, v1.x, v1.y);
             *reinterpret_cast<float4 *>(vr + 1 * (4 * F4_TILES * 4)) = make_float4(v2.x, v2.y, v3.x, v3.y);
             *reinterpret_cast<float4 *>(vr + 2 * (4 * F4_TILES * 4)) = make_float4(v4.x, v4.y, v5.x, v5.y);
@@ -269,7 +289,7 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
     // ---- prologue: S(0), S(1), X(0), G(2) and the coefficient slots; everything the first two phases need is
     // requested at once (one exposed round trip)
     const int last = nch - 1;
-    float4 xr1[F4_QNIT], cfr1 = make_float4(0.f, 0.f, 0.f, 0.f), cfr2 = cfr1;
+    float4 xr1[QN], cfr1 = make_float4(0.f, 0.f, 0.f, 0.f), cfr2 = cfr1;
     load_raw_into(xr, 0);
     load_raw_into(xr1, min(1, last));
     load_coef(0);
@@ -285,7 +305,7 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
     __syncthreads();
     store_raw(0);
 #pragma unroll
-    for (int it = 0; it < F4_QNIT; it++) xr[it] = xr1[it];
+    for (int it = 0; it < QN; it++) xr[it] = xr1[it];
     store_raw(1);
     load_raw_into(xr, min(2, last));
     __syncthreads();
@@ -312,12 +332,12 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
 #if F4_SKIP_TAIL
             // the pipeline's look-ahead work of the LAST phases feeds chunks that do not exist: S(chunk+2) in the last two phases and
             // X(chunk+1) in the last one are skipped (one-sided wave-uniform branches; the loads stay unconditional)
-            if (!(ABL & 1) && pp >= F4_S0 && pp < F4_S0 + F4_QNIT && chunk + 2 < nch) store_raw_item(cur, pp - F4_S0);
-            if (!(ABL & 4) && pp == F4_S0 + F4_QNIT) load_raw_into(xr, min(chunk + 3, last));
+            if (!(ABL & 1) && pp >= F4_S0 && pp < F4_S0 + QN && chunk + 2 < nch) store_raw_item(cur, pp - F4_S0);
+            if (!(ABL & 4) && pp == F4_S0 + QN) load_raw_into(xr, min(chunk + 3, last));
             if (!(ABL & 2) && pp == F4_X && chunk + 1 < nch) transform(nxt);
 #else
-            if (!(ABL & 1) && pp >= F4_S0 && pp < F4_S0 + F4_QNIT) store_raw_item(cur, pp - F4_S0);   // S(chunk+2): raw[cur] was read by X(chunk), a barrier ago
-            if (!(ABL & 4) && pp == F4_S0 + F4_QNIT) load_raw_into(xr, min(chunk + 3, last));        // G(chunk+3)
+            if (!(ABL & 1) && pp >= F4_S0 && pp < F4_S0 + QN) store_raw_item(cur, pp - F4_S0);   // S(chunk+2): raw[cur] was read by X(chunk), a barrier ago
+            if (!(ABL & 4) && pp == F4_S0 + QN) load_raw_into(xr, min(chunk + 3, last));        // G(chunk+3)
             if (!(ABL & 2) && pp == F4_X) transform(nxt);                                             // X(chunk+1): raw[nxt] -> V[nxt]
 #endif
             if (!(ABL & 16)) bq[(pp + AHEAD) % F4_RING] = wp[AHEAD * 64 + lane];
@@ -403,17 +423,17 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
                 const float m3 = acc[3 * 6 + b][r], m4 = acc[4 * 6 + b][r], m5 = acc[5 * 6 + b][r];
                 const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
                 Z[0][b] = m0 + s12 + s34;
-                Z[1][b] = fmaf(2.f, d34, d12);
-                Z[2][b] = fmaf(4.f, s34, s12);
-                Z[3][b] = fmaf(8.f, d34, d12) + m5;
+                Z[1][b] = fmaf(PB, d34, PA * d12);
+                Z[2][b] = fmaf(PB2, s34, PA2 * s12);
+                Z[3][b] = fmaf(PB3, d34, PA3 * d12) + m5;
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const float s12 = Z[i][1] + Z[i][2], d12 = Z[i][1] - Z[i][2], s34 = Z[i][3] + Z[i][4], d34 = Z[i][3] - Z[i][4];
                 Y[r][i * 4 + 0] = Z[i][0] + s12 + s34;
-                Y[r][i * 4 + 1] = fmaf(2.f, d34, d12);
-                Y[r][i * 4 + 2] = fmaf(4.f, s34, s12);
-                Y[r][i * 4 + 3] = fmaf(8.f, d34, d12) + Z[i][5];
+                Y[r][i * 4 + 1] = fmaf(PB, d34, PA * d12);
+                Y[r][i * 4 + 2] = fmaf(PB2, s34, PA2 * s12);
+                Y[r][i * 4 + 3] = fmaf(PB3, d34, PA3 * d12) + Z[i][5];
             }
         }
         float4 K = make_float4(0.f, 0.f, 0.f, 0.f), s1 = K, s2 = K;
@@ -513,9 +533,9 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
                 const float m3 = acc[3 * 6 + b][r], m4 = acc[4 * 6 + b][r], m5 = acc[5 * 6 + b][r];
                 const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
                 Z[0][b] = m0 + s12 + s34;
-                Z[1][b] = fmaf(2.f, d34, d12);
-                Z[2][b] = fmaf(4.f, s34, s12);
-                Z[3][b] = fmaf(8.f, d34, d12) + m5;
+                Z[1][b] = fmaf(PB, d34, PA * d12);
+                Z[2][b] = fmaf(PB2, s34, PA2 * s12);
+                Z[3][b] = fmaf(PB3, d34, PA3 * d12) + m5;
             }
             if (!ok) continue;
 #pragma unroll
@@ -523,9 +543,9 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
                 const float s12 = Z[i][1] + Z[i][2], d12 = Z[i][1] - Z[i][2], s34 = Z[i][3] + Z[i][4], d34 = Z[i][3] - Z[i][4];
                 float y[4];
                 y[0] = Z[i][0] + s12 + s34;
-                y[1] = fmaf(2.f, d34, d12);
-                y[2] = fmaf(4.f, s34, s12);
-                y[3] = fmaf(8.f, d34, d12) + Z[i][5];
+                y[1] = fmaf(PB, d34, PA * d12);
+                y[2] = fmaf(PB2, s34, PA2 * s12);
+                y[3] = fmaf(PB3, d34, PA3 * d12) + Z[i][5];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     float v = y[j] + bias_v;
@@ -588,14 +608,16 @@ __global__ void k_relayout_weight_wino4(const float *oihw, float *dst, int Cout,
     const int pos = 2 * pp + (e >> 1);
     const int cin = chunk * F4_KC + 2 * lk + (e & 1), cout = nt * F4_NQ + wave * 16 + li;
     const float *g = oihw + ((int64_t)cout * Cin + cin) * 9;
-    const double G[6][3] = {{0.25, 0., 0.},          {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
-                            {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
-    const int a = pos / 6, b = pos % 6;
+    const double a = F4_PA, b = F4_PB, a2 = a * a, b2 = b * b;
+    const double n0 = a2 * b2, na = 2. * a2 * (a2 - b2), nb = 2. * b2 * (b2 - a2);    // prod_{l != j} (p_j - p_l) for p_j = 0, +-a, +-b
+    const double G[6][3] = {{1. / n0, 0., 0.},         {1. / na, a / na, a2 / na}, {1. / na, -a / na, a2 / na},
+                            {1. / nb, b / nb, b2 / nb}, {1. / nb, -b / nb, b2 / nb}, {0., 0., 1.}};
+    const int ra = pos / 6, rb = pos % 6;
     double u = 0.;
     for (int ii = 0; ii < 3; ii++) {
         double row = 0.;
-        for (int jj = 0; jj < 3; jj++) row += (double)g[ii * 3 + jj] * G[b][jj];
-        u += G[a][ii] * row;
+        for (int jj = 0; jj < 3; jj++) row += (double)g[ii * 3 + jj] * G[rb][jj];
+        u += G[ra][ii] * row;
     }
     dst[i] = (float)u;
 }
@@ -663,7 +685,9 @@ int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
     const_cast<ConvLaunch &>(c).phase = phase_buffer();
 #endif
     using KFn = void (*)(ConvLaunch, int, int, int);
-    KFn fn = c.ups ? &k_conv3x3_wino4<true> : &k_conv3x3_wino4<false>;
+    const int RHp = c.ups ? 2 * bh + 2 : 4 * bh + 2, RWp = c.ups ? 2 * bw + 2 : 4 * bw + 2;
+    const bool small = nimg * RHp * RWp <= F4_NT;      // two staging items per thread cover the patch
+    KFn fn = c.ups ? (small ? &k_conv3x3_wino4<true, 0, 2> : &k_conv3x3_wino4<true>) : (small ? &k_conv3x3_wino4<false, 0, 2> : &k_conv3x3_wino4<false>);
 
 #ifdef DLPM_WINO_ABLATIONS
     static int abl = -1;

@@ -63,8 +63,43 @@ __global__ void k_set_ptr(float **cell, float *v) {
         if (_r != DLPM_OK) return _r; \
     } while (0)
 
-// The net's launch plan may change under a live sampler (dlpm_unet_set_conv_policy): drop the captured graph and
-// re-size the activation workspace before the next step.
+// The time path (time embedding -> MLP -> per-ResBlock emb linears) is a function of the step index alone: one row per step,
+// computed with the kernels the forward would run (t = float(i) * (1 / T), k_fill_t's arithmetic), replaces four launches of
+// every step.  DLPM loop only (the LIM loop feeds its own time grid).  DLPM_NO_TIME_TABLE=1: off.  The rows depend on the net's
+// WEIGHTS and on its GEMM policy, so sync_plan() rebuilds them whenever the net's plan version moved under a live sampler
+// (dlpm_unet_set_param + dlpm_unet_finalize, dlpm_unet_set_gemm_policy): round 3 built them once at create, and a sampler that
+// outlived a weight upload or a pipe switch kept conditioning on the old rows.
+int build_time_table(dlpm_sampler *s) {
+    if (!s->cfg.unet || s->lim) return DLPM_OK;
+    const char *nt = getenv("DLPM_NO_TIME_TABLE");
+    const int64_t ew = dlpm_unet_time_embedding_width(s->cfg.unet);
+    if ((nt && nt[0] == '1') || ew <= 0) return DLPM_OK;
+    const int T = s->cfg.T;
+    std::vector<float> tv(T);
+    for (int i = 0; i < T; i++) tv[i] = (float)i * (1.0f / (float)T);
+    float *tv_dev = nullptr;
+    void *scr = nullptr;
+    const int64_t scr_bytes = dlpm_unet_time_embeddings_scratch_bytes(s->cfg.unet, T);
+    int r = DLPM_OK;
+    hipError_t e = hipMalloc(&tv_dev, T * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(tv_dev, tv.data(), T * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&scr, (size_t)scr_bytes);
+    if (e == hipSuccess && !s->emb_tab) e = hipMalloc(&s->emb_tab, (size_t)T * ew * sizeof(float));
+    if (e == hipSuccess) {
+        r = dlpm_unet_time_embeddings(s->cfg.unet, tv_dev, T, s->emb_tab, scr, scr_bytes, nullptr);
+        e = hipDeviceSynchronize();
+    }
+    if (tv_dev) (void)hipFree(tv_dev);
+    if (scr) (void)hipFree(scr);
+    if (e != hipSuccess) {
+        set_error("dlpm_sampler: time table: %s", hipGetErrorString(e));
+        return DLPM_ERR_HIP;
+    }
+    return r;
+}
+
+// The net's launch plan may change under a live sampler (dlpm_unet_set_conv_policy / set_gemm_policy, re-uploaded weights):
+// drop the captured graph, re-size the activation workspace and rebuild the time table before the next step.
 int sync_plan(dlpm_sampler *s) {
     if (!s->cfg.unet) return DLPM_OK;
     const int64_t v = dlpm_unet_plan_version(s->cfg.unet);
@@ -82,6 +117,7 @@ int sync_plan(dlpm_sampler *s) {
         DLPM_HIP(hipMalloc(&s->ws, (size_t)need));
         s->ws_bytes = need;
     }
+    if (s->emb_tab) TRY(build_time_table(s));
     s->plan_version = v;
     return DLPM_OK;
 }
@@ -298,27 +334,10 @@ extern "C" int dlpm_sampler_create(const dlpm_sampler_config *cfg, dlpm_sampler 
         }
         if ((e = hipMalloc(&s->ws, (size_t)s->ws_bytes)) != hipSuccess) return fail(e);
         s->plan_version = dlpm_unet_plan_version(cfg->unet);
-        // The time path (time embedding -> MLP -> per-ResBlock emb linears) is a function of the step index alone: one row per
-        // step, computed here with the kernels the forward would run (t = float(i) * (1 / T), k_fill_t's arithmetic), replaces
-        // four launches of every step.  DLPM loop only (the LIM loop feeds its own time grid).  DLPM_NO_TIME_TABLE=1: off.
-        const char *nt = getenv("DLPM_NO_TIME_TABLE");
-        const int64_t ew = dlpm_unet_time_embedding_width(cfg->unet);
-        if (!is_lim && !(nt && nt[0] == '1') && ew > 0) {
-            std::vector<float> tv(T);
-            for (int i = 0; i < T; i++) tv[i] = (float)i * (1.0f / (float)T);
-            float *tv_dev = nullptr;
-            void *scr = nullptr;
-            const int64_t scr_bytes = dlpm_unet_time_embeddings_scratch_bytes(cfg->unet, T);
-            if ((e = hipMalloc(&tv_dev, T * sizeof(float))) != hipSuccess) return fail(e);
-            if ((e = hipMemcpy(tv_dev, tv.data(), T * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) { (void)hipFree(tv_dev); return fail(e); }
-            if ((e = hipMalloc(&scr, (size_t)scr_bytes)) != hipSuccess) { (void)hipFree(tv_dev); return fail(e); }
-            if ((e = hipMalloc(&s->emb_tab, (size_t)T * ew * sizeof(float))) != hipSuccess) { (void)hipFree(tv_dev); (void)hipFree(scr); return fail(e); }
-            int r = dlpm_unet_time_embeddings(cfg->unet, tv_dev, T, s->emb_tab, scr, scr_bytes, nullptr);
-            hipError_t es = hipDeviceSynchronize();
-            (void)hipFree(tv_dev);
-            (void)hipFree(scr);
-            if (r != DLPM_OK) { dlpm_sampler_destroy(s); return r; }
-            if (es != hipSuccess) return fail(es);
+        int r = build_time_table(s);
+        if (r != DLPM_OK) {
+            dlpm_sampler_destroy(s);
+            return r;
         }
     }
     *out = s;

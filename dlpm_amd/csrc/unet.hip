@@ -179,10 +179,6 @@ struct dlpm_unet {
     int64_t dispatch_B = 0;
     int gemm = DLPM_GEMM_AUTO;       // dlpm_unet_set_gemm_policy
     int64_t plan_version = 0;
-    // optional [T][emb_total] table of the time path's output (time embedding -> time MLP -> the per-ResBlock emb linears) and the
-    // device step counter that picks its row: bound by the sampler around its forward calls (dlpm_unet_bind_time_table)
-    const float *time_table = nullptr;
-    const int32_t *time_index = nullptr;
 
     int add(const std::string &key, int64_t numel) {
         Param p;
@@ -564,6 +560,12 @@ int time_path(dlpm_unet *u, const float *t, int M, float *e0, float *e1, float *
     return run_conv(u, u->embcat, g, st);
 }
 
+// optional [T][emb_total] table of the time path's output (time embedding -> time MLP -> the per-ResBlock emb linears) and the device
+// step counter that picks its row: bound by the sampler around its forward calls (dlpm_unet_bind_time_table), per host thread
+thread_local const dlpm_unet *tl_time_net = nullptr;
+thread_local const float *tl_time_table = nullptr;
+thread_local const int32_t *tl_time_index = nullptr;
+
 int walk(dlpm_unet *u, Ctx &cx, const float *x, const float *t, float *eps) {
     const int B = cx.B, mc = u->cfg.model_channels, ted = u->ted;
     // time embedding -> time MLP -> the per-ResBlock emb linears (unet.py:147-150, 336-338, 470).  In the sampling loop t is
@@ -573,10 +575,10 @@ int walk(dlpm_unet *u, Ctx &cx, const float *x, const float *t, float *eps) {
     float *e0 = cx.ws.alloc((int64_t)B * mc), *e1 = cx.ws.alloc((int64_t)B * ted), *e2 = cx.ws.alloc((int64_t)B * ted);
     cx.embout = cx.ws.alloc((int64_t)B * u->emb_total);
     if (!cx.dry()) {
-        if (cx.uniform_t && u->time_table) {
+        if (cx.uniform_t && tl_time_net == u && tl_time_table) {
             // the whole time path is a function of the step index alone: its output for every step was computed once
             // (dlpm_unet_time_embeddings, same kernels, one row per step -- same bits) and the step reads its row
-            k_table_row<<<(unsigned)ceil_div(u->emb_total, 256), 256, 0, cx.st>>>(u->time_table, u->time_index, u->emb_total, cx.embout);
+            k_table_row<<<(unsigned)ceil_div(u->emb_total, 256), 256, 0, cx.st>>>(tl_time_table, tl_time_index, u->emb_total, cx.embout);
             DLPM_LAUNCH_CHECK();
         } else {
             TRY(time_path(u, t, Bt, e0, e1, e2, cx.embout, cx.st));
@@ -851,8 +853,11 @@ extern "C" int dlpm_unet_time_embeddings(dlpm_unet *net, const float *t_dev, int
 
 extern "C" int dlpm_unet_bind_time_table(dlpm_unet *net, const float *table_dev, const int32_t *row_index_dev) {
     DLPM_CHECK_ARG(net && ((table_dev == nullptr) == (row_index_dev == nullptr)), "dlpm_unet_bind_time_table: give both pointers or neither");
-    net->time_table = table_dev;
-    net->time_index = row_index_dev;
+    // per HOST THREAD, not per net: two samplers that share one net from different threads each see their own binding while
+    // they enqueue (round 3 kept it in the net, where one thread's table could be baked into the other's captured graph)
+    tl_time_net = table_dev ? net : nullptr;
+    tl_time_table = table_dev;
+    tl_time_index = row_index_dev;
     return DLPM_OK;
 }
 

@@ -107,6 +107,20 @@ def test_bench_eight_rank_control_flow_of_the_driver_commands(workload, per_gpu)
     assert j['n_gpus'] == 8 and j['scaling'] == 'weak' and j['config']['global_batch'] == 8 * per_gpu
     assert j['config']['workload'] == workload and j['config']['allgather_ms'] is not None and j['samples_finite']
     assert j['full_trajectory_s'] is not None
+    # round 4: the line validates itself -- one record per rank, the backend that carried the gather, its size, and the proof
+    # that every rank's shard arrived (checksums of the shards == checksums of the same rows of the gathered batch)
+    assert j['backend'] == 'gloo' and j['rccl_world_size'] == 8
+    ranks = j['ranks']
+    assert [r['rank'] for r in ranks] == list(range(8)) and len({r['pid'] for r in ranks}) == 8
+    for r in ranks:
+        assert set(r) >= {'rank', 'local_rank', 'device_index', 'device_uuid', 'pci_bus_id', 'device_name', 'ms_per_step',
+                          'shard_checksum', 'gathered_rows_checksum'}
+        assert r['ms_per_step'] > 0 and r['ms_per_step'] <= j['ms_per_step'] + 1e-3
+        assert r['shard_checksum'] == r['gathered_rows_checksum']
+    assert len({r['shard_checksum'] for r in ranks}) == 8          # the stub's shards differ by rank
+    shape = j['config']['state_shape_per_gpu']
+    assert j['allgather_bytes'] == 8 * per_gpu * shape[1] * shape[2] * shape[3] * 4
+    assert j['distributed']['gather_verified'] is True and j['distributed']['allgather_bytes_per_rank_sent'] * 8 == j['allgather_bytes']
 
 
 def test_bench_rank_dying_mid_trajectory_fails_the_parent_within_the_deadline():

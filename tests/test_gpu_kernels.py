@@ -168,23 +168,30 @@ WINO4_CASES = [
 ]
 
 
-# max |F(4x4) kernel - fp64 reference| measured on MI355X (round 2, gpurun_out/r2a/pytest.log)
-F4_MEASURED = {'f4_16x16_block': 4.49e-05,
-               'f4_32x32_four_blocks_gn_silu_res': 1.57e-05,
-               'f4_concat_cout256': 1.7e-05,
-               'f4_8x8_four_images': 9.95e-06,
-               'f4_4x4_sixteen_images': 2.72e-05,
-               'f4_upsample_8to16': 3.65e-05,
-               'f4_upsample_16to32_coef_res': 2.12e-05,
-               'f4_upsample_2to4_multiimage': 2e-05,
-               'f4_64x64': 1.7e-05,
-               'f4_long_k': 2.42e-05}
+# max |F(4x4) kernel - fp64 reference| measured on MI355X.  Round 4 (interpolation points {0, +-11/16, +-3/2, inf}, profiles/r04/
+# kernels_f4_points.txt); with rounds 1-3's {0, +-1, +-2, inf} the same cases measured 1.0-4.5e-5 (F4_MEASURED_LAVIN_POINTS, kept
+# for the record: the F4_POINTS_LAVIN build reproduces them bit for bit).
+F4_MEASURED = {'f4_16x16_block': 9.30e-06,
+               'f4_32x32_four_blocks_gn_silu_res': 3.99e-06,
+               'f4_concat_cout256': 4.23e-06,
+               'f4_8x8_four_images': 3.10e-06,
+               'f4_4x4_sixteen_images': 5.74e-06,
+               'f4_upsample_8to16': 5.28e-06,
+               'f4_upsample_16to32_coef_res': 5.96e-06,
+               'f4_upsample_2to4_multiimage': 4.14e-06,
+               'f4_64x64': 3.34e-06,
+               'f4_long_k': 8.94e-06}
+F4_MEASURED_LAVIN_POINTS = {'f4_16x16_block': 4.49e-05, 'f4_32x32_four_blocks_gn_silu_res': 1.57e-05, 'f4_concat_cout256': 1.7e-05,
+                            'f4_8x8_four_images': 9.95e-06, 'f4_4x4_sixteen_images': 2.72e-05, 'f4_upsample_8to16': 3.65e-05,
+                            'f4_upsample_16to32_coef_res': 2.12e-05, 'f4_upsample_2to4_multiimage': 2e-05, 'f4_64x64': 1.7e-05,
+                            'f4_long_k': 2.42e-05}
 
 
 @pytest.mark.parametrize('case', WINO4_CASES, ids=[c[0] for c in WINO4_CASES])
 def test_conv_winograd_f4(case):
-    """F(4x4,3x3): same convolution, larger transform constants (|B^T| rows sum to 10, |A^T| to 19).  Bound = twice the
-    error measured on MI355X for each case (F4_MEASURED, O(1) outputs), never above the path's 1e-4 budget."""
+    """F(4x4,3x3): same convolution, products accumulated in the Winograd domain (partial sums larger than the result).  Bound =
+    twice the error measured on MI355X for each case (F4_MEASURED, O(1) outputs: 3-9e-6 with the round-4 interpolation points),
+    never above 2e-5 -- a fifth of the path's 1e-4 budget."""
     name, B, C0, C1, H, Cout, ups, act, use_res = case
     g = torch.Generator().manual_seed(sum(map(ord, name)))
     Cin = C0 + C1
@@ -200,7 +207,7 @@ def test_conv_winograd_f4(case):
     got2 = run_conv(x0, w, bias, x1, 1, ups, coef, act, res)
     assert got.shape == want.shape
     e4, e2 = (got - want).abs().max().item(), (got2 - want).abs().max().item()
-    tol = min(1e-4, 2 * F4_MEASURED[name])
+    tol = min(2e-5, 2 * F4_MEASURED[name])
     print('%s: F(4x4) err %.2e, default path err %.2e, tol %.2e' % (name, e4, e2, tol))
     assert e4 < tol, name
     assert not torch.equal(got, got2), 'the F(4x4) kernel did not run (identical to the default path)'
