@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('DLPM_LIB') or os.path.join(_HERE, 'lib', 'libdlpm_amd
 
 vp, i32, i64, u32, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
 
-ABI_VERSION = 5   # must equal dlpm_abi_version(): struct layouts below mirror include/dlpm_amd.h at this version
+ABI_VERSION = 6   # must equal dlpm_abi_version(): struct layouts below mirror include/dlpm_amd.h at this version
 UPD_DLIM, UPD_CLIP, UPD_ADVANCE, SMP_NO_FUSED_MLP, UPD_ELEMENTWISE, SMP_LIM = 1, 2, 4, 8, 16, 32
 MEAN_TYPES = {'EPSILON': 0, 'START_X': 1, 'Z': 2, 'PREVIOUS_X': 3}   # dlpm_mean_type
 PRED_TO_XSTART, PRED_CLIP, PRED_TO_EPS, PRED_ELEMENTWISE = 1, 2, 4, 16
@@ -53,6 +53,17 @@ class ConvArgs(C.Structure):
                 ('Hout', i32), ('Wout', i32), ('ksize', i32), ('stride', i32), ('upsample', i32), ('weight', vp),
                 ('bias', vp), ('coefA', vp), ('coefB', vp), ('act_silu', i32), ('res0', vp), ('res1', vp), ('R0', i32),
                 ('out', vp), ('Cout', i32), ('in_nchw', i32), ('out_nchw', i32), ('force_direct', i32), ('scratch_floats', i64)]
+
+
+class ResBlockArgs(C.Structure):
+    _fields_ = [('x0', vp), ('x1', vp), ('C0', i32), ('C1', i32), ('B', i32), ('H', i32), ('W', i32), ('gn1_w', vp), ('gn1_b', vp),
+                ('conv1_w', vp), ('conv1_b', vp), ('ss', vp), ('ss_stride', i64), ('gn2_w', vp), ('gn2_b', vp), ('conv2_w', vp),
+                ('conv2_b', vp), ('skip_w', vp), ('skip_b', vp), ('out', vp), ('stats_out', vp)]
+
+
+class AttnBlockArgs(C.Structure):
+    _fields_ = [('x', vp), ('C', i32), ('heads', i32), ('B', i32), ('H', i32), ('W', i32), ('gn_w', vp), ('gn_b', vp),
+                ('qkv_w', vp), ('qkv_b', vp), ('proj_w', vp), ('proj_b', vp), ('out', vp), ('stats_out', vp)]
 
 
 class SamplerConfig(C.Structure):
@@ -122,6 +133,8 @@ SIGNATURES = {
     'dlpm_conv2d_f32': (C.c_int, [C.POINTER(ConvArgs), vp, vp]),
     'dlpm_groupnorm_coeffs_f32': (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i64, i64, vp, vp, vp]),
     'dlpm_attention_f32': (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+    'dlpm_resblock_small_f32': (C.c_int, [C.POINTER(ResBlockArgs), vp, i64, vp]),
+    'dlpm_attnblock_small_f32': (C.c_int, [C.POINTER(AttnBlockArgs), vp, i64, vp]),
     'dlpm_timestep_embedding_f32': (C.c_int, [vp, vp, i64, i32, vp]),
     'dlpm_nchw_to_nhwc_f32': (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     'dlpm_nhwc_to_nchw_f32': (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),

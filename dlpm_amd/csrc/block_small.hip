@@ -1,0 +1,545 @@
+// block_small.hip -- whole UNet blocks of SMALL images in one launch, activations resident in LDS (round 4).
+//
+// Replaces, for 64-output-channel blocks on 8x8 / 4x4 images (the MNIST net's two coarsest levels and its middle block;
+// dlpm/models/unet.py:105-196 ResBlock with use_scale_shift_norm, :199-250 AttentionBlock + QKVAttention):
+//
+//   ResBlock      h = conv3x3(silu(GN(x)));  h = conv3x3(silu(GN(h) * (1 + scale) + shift));  out = skip(x) + h
+//                 (x may be the virtual concat [x0 | x1] of the output blocks; skip = identity or a 1x1 convolution)
+//   AttentionBlock  qkv = conv1(GN(x));  a = softmax(q k^T / sqrt(ch)) v per head;  out = x + conv1(a)
+//
+// Why a different kernel family: at these sizes a launch of the tiled kernels is ONE workgroup's serial life -- prologue,
+// 8 K-chunks with their barriers, epilogue: 23 of a launch's 26 us (profiles/r03/mnist_where_the_step_goes/) -- and a ResBlock
+// is two of them plus two GroupNorm launches plus (output blocks) a 1x1 launch.  An 8x8 x 64-channel image is 16 KB; with its
+// halo, both activated copies and the concat input it is 115 KB: the whole block fits one CU's LDS, so ONE workgroup per image
+// walks the block with no HBM round trip, no launch gap and no grid-wide dependency (GroupNorm is per image).  A sample's
+// result depends on nothing but the sample: bits are independent of the batch.
+//
+// Work split (8 waves, 2 per SIMD): a convolution is the implicit GEMM  D[pixel][cout] = sum_{tap, cin} act[pixel + tap][cin] W
+// on v_mfma_f32_16x16x4_f32; wave w (0..3) owns output channels 16 w .. 16 w + 15 for ALL pixels (MT = HW / 16 accumulator tiles),
+// waves 4..7 own the same channels for the SECOND HALF of K (fragments) and hand their partial sums over through LDS (fixed
+// order).  Weights are pre-arranged in B-fragment order Wf[cout / 16][fragment = tap * Cin / 16 + j][lane][4] and stream
+// L2 -> registers through a ring, every fragment read by exactly one wave; the MFMA's free k-permutation (slot lk of MFMA e is
+// channel 16 j + 4 lk + e) lets one ds_read_b128 of four consecutive channels feed four MFMAs.  The activated images live in LDS
+// as zero-bordered halo tiles [(H + 2)(W + 2)][C + 4] (row pitch = 4 mod 32 words: the 16 pixels of an A read hit distinct
+// bank quads).
+#include "conv.h"
+
+namespace dlpm {
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int RS_NT = 512;     // threads per workgroup
+constexpr int RS_CO = 64;      // output channels of a block
+constexpr int RS_LDO = RS_CO + 4;
+
+// One pass of the implicit GEMM over `nf` weight fragments starting at global fragment index f_first (this wave's share):
+// acc[mt] += A[pixels of tile mt][k] B[k][this wave's 16 channels].  halo: abuf is a halo tile and fragment (tap, j) reads the
+// pixel shifted by the tap; otherwise (1x1) fragment j reads the pixel itself.  R = weight fragments in flight (divides nf).
+template <int R>
+__device__ __forceinline__ void ring_fill(float4 (&ring)[R], const float4 *__restrict__ wp, int nf) {
+#pragma unroll
+    for (int r = 0; r < R; r++) ring[r] = wp[(int64_t)min(r, nf - 1) * 64];
+}
+
+// (the ring arrives FILLED -- ring_fill, issued as early as the caller can, so the L2 round trip of the first fragments is behind
+//  the phase that precedes the pass)
+template <int MT, int R>
+__device__ __forceinline__ void mfma_pass(floatx4 (&acc)[MT], float4 (&ring)[R], const float *abuf, const int (&abase)[MT], int LD, int WP,
+                                          bool halo, const float4 *__restrict__ wp, int f_first, int nf, int jc_shift) {
+    for (int f = 0; f < nf; f += R) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const float4 bq = ring[r];
+            ring[r] = wp[(int64_t)min(f + r + R, nf - 1) * 64];        // unconditional (clamped): no branch around a load
+            const int fg = f_first + f + r;
+            const int tap = fg >> jc_shift, j = fg & ((1 << jc_shift) - 1);
+            const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;          // tap / 3, tap % 3 for tap < 9
+            const int aoff = (halo ? (ky * WP + kx) * LD : 0) + 16 * j;
+            float4 a[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) a[mt] = *reinterpret_cast<const float4 *>(abuf + abase[mt] + aoff);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, bq.x, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, bq.y, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, bq.z, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, bq.w, acc[mt], 0, 0, 0);
+        }
+    }
+}
+
+// sum over the lanes that share (channel pair, all pixel groups): xor 1 (the group's other channel), 16, 32 (the four row groups)
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+template <int HS>
+__global__ void __launch_bounds__(RS_NT, 1) k_resblock_small(ResSmallLaunch p) {
+    constexpr int HW = HS * HS, MT = HW / 16, WP = HS + 2, HP = WP * WP;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Cin = p.C0 + p.C1, LDI = Cin + 4, JC = Cin >> 4, jc_shift = 31 - __builtin_clz(JC);
+    float *raw = sm;                         // [HW][LDI]       x as it arrives (skip path, GroupNorm statistics)
+    float *a1 = raw + HW * LDI;              // [HP][LDI]       silu(GN1(x)), zero border
+    float *a2 = a1 + HP * LDI;               // [HP][RS_LDO]    silu(GN2(h) (1 + scale) + shift), zero border
+    float *red = a2 + HP * RS_LDO;           // [4][MT][4][64]  partial sums of waves 4..7
+    float *cf = red + 4 * MT * 256;          // [2][Cin]        GroupNorm-1 coefficients
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w4 = wave & 3, half = wave >> 2, ln = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.x;
+    // weight streams of this wave: output channels 16 w4 .., fragment half `half`; the first ring of conv1 is requested now
+    const int F1 = 9 * JC, nf1 = F1 >> 1;
+    const float4 *wp1 = reinterpret_cast<const float4 *>(p.w1f) + ((int64_t)w4 * F1 + half * nf1) * 64 + lane;
+    const float4 *wp2 = reinterpret_cast<const float4 *>(p.w2f) + ((int64_t)w4 * 36 + half * 18) * 64 + lane;
+    float4 ring6[6];
+    ring_fill<6>(ring6, wp1, nf1);
+
+    // ---- phase 0: zero the halo tiles (their borders stay zero), x -> raw
+    {
+        float4 *z = reinterpret_cast<float4 *>(a1);
+        for (int i = tid; i < (HP * LDI + HP * RS_LDO) / 4; i += RS_NT) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int q4 = Cin >> 2;
+        for (int i = tid; i < HW * q4; i += RS_NT) {
+            const int pix = i / q4, c = (i - pix * q4) * 4;
+            const float *src = c < p.C0 ? p.x0 + ((int64_t)b * HW + pix) * p.C0 + c : p.x1 + ((int64_t)b * HW + pix) * p.C1 + (c - p.C0);
+            *reinterpret_cast<float4 *>(raw + pix * LDI + c) = *reinterpret_cast<const float4 *>(src);
+        }
+    }
+    __syncthreads();
+    // ---- phase 1: GroupNorm-1 statistics, two passes over the LDS copy: 32 groups x 16 threads
+    {
+        const int cg = Cin >> 5, g = tid >> 4, i = tid & 15;
+        const float inv_n = 1.0f / (float)(cg * HW);
+        float s = 0.f;
+        for (int pp = i; pp < HW; pp += 16)
+            for (int k = 0; k < cg; k++) s += raw[pp * LDI + g * cg + k];
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+        const float mean = s * inv_n;
+        float v = 0.f;
+        for (int pp = i; pp < HW; pp += 16)
+            for (int k = 0; k < cg; k++) {
+                const float d = raw[pp * LDI + g * cg + k] - mean;
+                v = fmaf(d, d, v);
+            }
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        const float rstd = 1.0f / sqrtf(v * inv_n + 1e-5f);
+        if (i < cg) {
+            const int c = g * cg + i;
+            const float a = rstd * p.gn1_w[c];
+            cf[c] = a;
+            cf[Cin + c] = p.gn1_b[c] - mean * a;
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: a1 = silu(x A + B) into the halo tile's interior
+    {
+        const int q4 = Cin >> 2;
+        for (int i = tid; i < HW * q4; i += RS_NT) {
+            const int pix = i / q4, c = (i - pix * q4) * 4;
+            const float4 x = *reinterpret_cast<const float4 *>(raw + pix * LDI + c);
+            const float4 A = *reinterpret_cast<const float4 *>(cf + c), Bc = *reinterpret_cast<const float4 *>(cf + Cin + c);
+            float4 v;
+            v.x = silu_f(fmaf(x.x, A.x, Bc.x));
+            v.y = silu_f(fmaf(x.y, A.y, Bc.y));
+            v.z = silu_f(fmaf(x.z, A.z, Bc.z));
+            v.w = silu_f(fmaf(x.w, A.w, Bc.w));
+            const int y = pix / HS, xx = pix - y * HS;
+            *reinterpret_cast<float4 *>(a1 + ((y + 1) * WP + xx + 1) * LDI + c) = v;
+        }
+    }
+    __syncthreads();
+    // ---- phase 3: conv1 (all waves, K split over the wave halves), partial sums of waves 4..7 through LDS
+    floatx4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[mt][r] = 0.f;
+    int ab1[MT], ab2[MT], abr[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        const int pix = 16 * mt + ln, y = pix / HS, xx = pix - y * HS;
+        ab1[mt] = (y * WP + xx) * LDI + 4 * lq;
+        ab2[mt] = (y * WP + xx) * RS_LDO + 4 * lq;
+        abr[mt] = pix * LDI + 4 * lq;
+    }
+    mfma_pass<MT, 6>(acc, ring6, a1, ab1, LDI, WP, true, wp1, half * nf1, nf1, jc_shift);
+    float4 ring4[4];
+    if (half) {
+        if (p.wsf) ring_fill<4>(ring4, reinterpret_cast<const float4 *>(p.wsf) + ((int64_t)w4 * JC) * 64 + lane, JC);
+    } else {
+        ring_fill<6>(ring6, wp2, 18);       // conv2's first fragments travel while GroupNorm-2 runs
+    }
+    if (half) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[((w4 * MT + mt) * 4 + r) * 64 + lane] = acc[mt][r];
+    }
+    __syncthreads();
+    const int c_out = 16 * w4 + ln;      // this lane's output channel (waves 0..3 and 4..7 alike)
+    if (!half) {
+        // ---- phase 4a (waves 0..3): h = conv1 + bias; GroupNorm-2 (groups of two channels = lane pairs) with scale-shift; a2
+        const float b1 = p.b1[c_out];
+        float s = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                acc[mt][r] = (acc[mt][r] + red[((w4 * MT + mt) * 4 + r) * 64 + lane]) + b1;
+                s += acc[mt][r];
+            }
+        const float inv_n = 1.0f / (float)(2 * HW);
+        const float mean = group_sum(s) * inv_n;
+        float v = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float d = acc[mt][r] - mean;
+                v = fmaf(d, d, v);
+            }
+        const float rstd = 1.0f / sqrtf(group_sum(v) * inv_n + 1e-5f);
+        float a = rstd * p.gn2_w[c_out];
+        float bb = p.gn2_b[c_out] - mean * a;
+        const float *ss = p.emb + (int64_t)b * p.emb_stride + p.emb_off;
+        const float sc = 1.0f + ss[c_out], sft = ss[RS_CO + c_out];
+        a = a * sc;
+        bb = fmaf(bb, sc, sft);
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int pix = 16 * mt + 4 * lq + r, y = pix / HS, xx = pix - y * HS;
+                a2[((y + 1) * WP + xx + 1) * RS_LDO + c_out] = silu_f(fmaf(acc[mt][r], a, bb));
+                acc[mt][r] = 0.f;
+            }
+    } else {
+        // ---- phase 4b (waves 4..7, meanwhile): the 1x1 skip convolution of the raw input opens their conv2 accumulators
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[mt][r] = 0.f;
+        if (p.wsf) {
+            const float4 *wp = reinterpret_cast<const float4 *>(p.wsf) + ((int64_t)w4 * JC) * 64 + lane;
+            mfma_pass<MT, 4>(acc, ring4, raw, abr, LDI, WP, false, wp, 0, JC, jc_shift);
+        }
+        ring_fill<6>(ring6, wp2, 18);
+    }
+    __syncthreads();
+    // ---- phase 5: conv2 over a2 (64 channels: 36 fragments, 18 per wave half)
+    mfma_pass<MT, 6>(acc, ring6, a2, ab2, RS_LDO, WP, true, wp2, half * 18, 18, 2);
+    if (half) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[((w4 * MT + mt) * 4 + r) * 64 + lane] = acc[mt][r];
+    }
+    __syncthreads();
+    if (!half) {
+        // ---- epilogue (waves 0..3): + bias (+ skip bias | + x), store NHWC, optional per-image GroupNorm statistics of the output
+        const float bias = p.b2[c_out] + (p.wsf ? p.bs[c_out] : 0.f);
+        float *o = p.out + (int64_t)b * HW * RS_CO + c_out;
+        float s = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int pix = 16 * mt + 4 * lq + r;
+                float v = (acc[mt][r] + red[((w4 * MT + mt) * 4 + r) * 64 + lane]) + bias;
+                if (!p.wsf) v += raw[pix * LDI + c_out];
+                acc[mt][r] = v;
+                s += v;
+                o[pix * RS_CO] = v;
+            }
+        if (p.stats_out) {
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            const float mean = s * (1.0f / (float)HW);
+            float m2 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float d = acc[mt][r] - mean;
+                    m2 = fmaf(d, d, m2);
+                }
+            m2 += __shfl_xor(m2, 16);
+            m2 += __shfl_xor(m2, 32);
+            if (lq == 0) p.stats_out[(int64_t)b * RS_CO + c_out] = make_float2(mean, m2);
+        }
+    }
+}
+
+// AttentionBlock of a small image (unet.py:199-250): GroupNorm -> qkv 1x1 -> per-head softmax(q k^T) v -> proj 1x1 -> + x, one
+// workgroup per image, T = HS^2 tokens, 64 channels, 4 heads of 16 channels.  qkv channel order is the reference's head-major
+// [head][q | k | v][16] (unet.py:224,243-244), i.e. 16-channel output tile nt = 3 head + {q, k, v}.  The attention core is
+// attention.hip's (S^T = K Q^T tile by tile with the query on the lane, softmax in registers, probabilities already in the
+// A-operand layout of P V), with q, k, v read from the LDS copy of qkv; q and k are pre-scaled by ch^(-1/4) as the reference does.
+constexpr int AB_C = 64, AB_LD = AB_C + 4, AB_QLD = 3 * AB_C + 4, AB_HEADS = 4, AB_CH = 16;
+
+template <int HS>
+__global__ void __launch_bounds__(RS_NT, 1) k_attnblock_small(AttnSmallLaunch p) {
+    constexpr int T = HS * HS, MT = T / 16;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *raw = sm;                       // [T][AB_LD]   x
+    float *xn = raw + T * AB_LD;           // [T][AB_LD]   GN(x); later the attention output a
+    float *qkvs = xn + T * AB_LD;          // [T][AB_QLD]  qkv (q, k scaled)
+    float *cf = qkvs + T * AB_QLD;         // [2][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.x;
+    for (int i = tid; i < T * (AB_C / 4); i += RS_NT) {
+        const int pix = i >> 4, c = (i & 15) * 4;
+        *reinterpret_cast<float4 *>(raw + pix * AB_LD + c) = *reinterpret_cast<const float4 *>(p.x + ((int64_t)b * T + pix) * AB_C + c);
+    }
+    __syncthreads();
+    {   // GroupNorm: 32 groups of two channels x 16 threads, two passes over the LDS copy
+        const int g = tid >> 4, i = tid & 15;
+        const float inv_n = 1.0f / (float)(2 * T);
+        float s = 0.f;
+        for (int pp = i; pp < T; pp += 16) s += raw[pp * AB_LD + 2 * g] + raw[pp * AB_LD + 2 * g + 1];
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+        const float mean = s * inv_n;
+        float v = 0.f;
+        for (int pp = i; pp < T; pp += 16) {
+            const float d0 = raw[pp * AB_LD + 2 * g] - mean, d1 = raw[pp * AB_LD + 2 * g + 1] - mean;
+            v = fmaf(d0, d0, v);
+            v = fmaf(d1, d1, v);
+        }
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        const float rstd = 1.0f / sqrtf(v * inv_n + 1e-5f);
+        if (i < 2) {
+            const int c = 2 * g + i;
+            const float a = rstd * p.gn_w[c];
+            cf[c] = a;
+            cf[AB_C + c] = p.gn_b[c] - mean * a;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < T * (AB_C / 4); i += RS_NT) {
+        const int pix = i >> 4, c = (i & 15) * 4;
+        const float4 x = *reinterpret_cast<const float4 *>(raw + pix * AB_LD + c);
+        const float4 A = *reinterpret_cast<const float4 *>(cf + c), Bc = *reinterpret_cast<const float4 *>(cf + AB_C + c);
+        *reinterpret_cast<float4 *>(xn + pix * AB_LD + c) = make_float4(fmaf(x.x, A.x, Bc.x), fmaf(x.y, A.y, Bc.y), fmaf(x.z, A.z, Bc.z), fmaf(x.w, A.w, Bc.w));
+    }
+    __syncthreads();
+    int abx[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) abx[mt] = (16 * mt + ln) * AB_LD + 4 * lq;
+    // ---- qkv = conv1(GN(x)): 12 output tiles of 16 channels over the 8 waves
+    const float scale = 0.5f;   // ch^(-1/4), ch = 16 (exact)
+    for (int nt = wave; nt < 3 * AB_HEADS; nt += 8) {
+        floatx4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+        const float4 *wp = reinterpret_cast<const float4 *>(p.wqkv) + (int64_t)nt * 4 * 64 + lane;
+        float4 ring[4];
+        ring_fill<4>(ring, wp, 4);
+        mfma_pass<MT, 4>(acc, ring, xn, abx, AB_LD, 0, false, wp, 0, 4, 2);
+        const int co = 16 * nt + ln;
+        const float bias = p.bqkv[co];
+        const bool scaled = (nt % 3) != 2;      // q and k tiles
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = acc[mt][r] + bias;
+                if (scaled) v *= scale;
+                qkvs[(16 * mt + 4 * lq + r) * AB_QLD + co] = v;
+            }
+    }
+    __syncthreads();
+    // ---- attention: units (head, query tile) over the waves; a -> xn
+    for (int u = wave; u < AB_HEADS * MT; u += 8) {
+        const int h = u / MT, t0 = (u - h * MT) * 16;
+        const float *qb = qkvs + h * 3 * AB_CH, *kb = qb + AB_CH, *vb = qb + 2 * AB_CH;
+        const float4 qv = *reinterpret_cast<const float4 *>(qb + (t0 + ln) * AB_QLD + 4 * lq);
+        const float qf[4] = {qv.x, qv.y, qv.z, qv.w};
+        floatx4 acc[MT];
+#pragma unroll
+        for (int j = 0; j < MT; j++) {
+            acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+            const float4 kv = *reinterpret_cast<const float4 *>(kb + (16 * j + ln) * AB_QLD + 4 * lq);
+            const float kf[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kk], qf[kk], acc[j], 0, 0, 0);
+        }
+        // acc[j][r] = S[query t0 + ln][key 16 j + 4 lq + r]: softmax over the keys = registers (j, r) and the four lane groups
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < MT; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) mx = fmaxf(mx, acc[j][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < MT; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                acc[j][r] = __expf(acc[j][r] - mx);
+                sum += acc[j][r];
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float rsum = 1.0f / sum;
+        floatx4 o = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < MT; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float pv = acc[j][r] * rsum;
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vb[(16 * j + 4 * lq + r) * AB_QLD + ln], o, 0, 0, 0);
+            }
+        // D: row = query 4 lq + r of the tile, column = channel ln of the head
+#pragma unroll
+        for (int r = 0; r < 4; r++) xn[(t0 + 4 * lq + r) * AB_LD + h * AB_CH + ln] = o[r];
+    }
+    __syncthreads();
+    // ---- out = x + proj(a): four output tiles on waves 0..3
+    if (wave < 4) {
+        floatx4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+        const float4 *wp = reinterpret_cast<const float4 *>(p.wproj) + (int64_t)wave * 4 * 64 + lane;
+        float4 ring[4];
+        ring_fill<4>(ring, wp, 4);
+        mfma_pass<MT, 4>(acc, ring, xn, abx, AB_LD, 0, false, wp, 0, 4, 2);
+        const int co = 16 * wave + ln;
+        const float bias = p.bproj[co];
+        float *o = p.out + (int64_t)b * T * AB_C + co;
+        float s = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int pix = 16 * mt + 4 * lq + r;
+                const float v = raw[pix * AB_LD + co] + (acc[mt][r] + bias);
+                acc[mt][r] = v;
+                s += v;
+                o[pix * AB_C] = v;
+            }
+        if (p.stats_out) {
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            const float mean = s * (1.0f / (float)T);
+            float m2 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float d = acc[mt][r] - mean;
+                    m2 = fmaf(d, d, m2);
+                }
+            m2 += __shfl_xor(m2, 16);
+            m2 += __shfl_xor(m2, 32);
+            if (lq == 0) p.stats_out[(int64_t)b * AB_C + co] = make_float2(mean, m2);
+        }
+    }
+}
+
+// OIHW (taps = ks * ks) -> Wf[cout / 16][fragment = tap * Cin / 16 + j][lane = lk * 16 + li][e]:
+//   W[cout = 16 w + li][cin = 16 j + 4 lk + e][tap]
+__global__ void k_relayout_weight_small(const float *oihw, float *dst, int Cout, int Cin, int taps) {
+    const int64_t total = (int64_t)Cout * Cin * taps;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int e = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    const int JC = Cin >> 4, F = taps * JC;
+    const int64_t rest = i >> 8;
+    const int f = (int)(rest % F), w = (int)(rest / F);
+    const int tap = f / JC, j = f - tap * JC;
+    const int cin = 16 * j + 4 * (lane >> 4) + e, cout = 16 * w + (lane & 15);
+    dst[i] = oihw[((int64_t)cout * Cin + cin) * taps + tap];
+}
+
+size_t res_small_lds_bytes(int HS, int Cin) {
+    const int HW = HS * HS, HP = (HS + 2) * (HS + 2), LDI = Cin + 4, MT = HW / 16;
+    return (size_t)(HW * LDI + HP * LDI + HP * RS_LDO + 4 * MT * 256 + 2 * Cin) * sizeof(float);
+}
+
+}  // namespace
+
+bool small_blocks_enabled() {   // DLPM_NO_FUSED_BLOCKS=1: every block through the tiled per-layer kernels (A/B runs)
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("DLPM_NO_FUSED_BLOCKS"); off = (e && e[0] == '1') ? 1 : 0; }
+    return !off;
+}
+
+bool small_weight_ok(int Cout, int Cin, int ks) {
+    return (ks == 1 || ks == 3) && ((Cout == RS_CO && (Cin == 64 || Cin == 128)) || (Cout == 3 * RS_CO && Cin == 64 && ks == 1));
+}
+
+int64_t small_weight_floats(int Cout, int Cin, int ks) { return (int64_t)Cout * Cin * ks * ks; }
+
+int relayout_weight_small(const float *oihw_dev, float *dst_dev, int Cout, int Cin, int ks, hipStream_t st) {
+    const int64_t n = (int64_t)Cout * Cin * ks * ks;
+    k_relayout_weight_small<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin, ks * ks);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+bool res_small_ok(const ResSmallLaunch &r) {
+    if (!small_blocks_enabled() || !r.w1f || !r.w2f) return false;
+    const int Cin = r.C0 + r.C1;
+    if (r.H != r.W || (r.H != 8 && r.H != 4)) return false;
+    if ((Cin != 64 && Cin != 128) || (r.C0 & 3) || (r.C1 & 3)) return false;
+    if ((Cin == 64) == (r.wsf != nullptr)) return false;      // 64 -> 64: identity skip; 128 -> 64: the 1x1 skip convolution
+    return true;
+}
+
+bool attn_small_ok(const AttnSmallLaunch &a) {
+    return small_blocks_enabled() && a.wqkv && a.wproj && a.C == AB_C && a.heads == AB_HEADS && a.H == a.W && (a.H == 8 || a.H == 4);
+}
+
+int launch_attnblock_small(const AttnSmallLaunch &a, hipStream_t st) {
+    if (!attn_small_ok(a)) {
+        set_error("launch_attnblock_small: unsupported block shape");
+        return DLPM_ERR_UNSUPPORTED;
+    }
+    const int T = a.H * a.W;
+    const double fl = 2.0 * a.B * T * (4.0 * AB_C * AB_C + 2.0 * T * AB_C);
+    ProfScope ps(a.H == 8 ? "attnblock_small:H8" : "attnblock_small:H4", fl, 4.0 * (2.0 * a.B * T * AB_C + 4.0 * AB_C * AB_C), st);
+    const size_t lds = (size_t)(2 * T * AB_LD + T * AB_QLD + 2 * AB_C) * sizeof(float);
+    if (a.H == 8) {
+        int e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_attnblock_small<8>), 160 * 1024);
+        if (e != DLPM_OK) return e;
+        k_attnblock_small<8><<<(unsigned)a.B, RS_NT, lds, st>>>(a);
+    } else {
+        int e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_attnblock_small<4>), 160 * 1024);
+        if (e != DLPM_OK) return e;
+        k_attnblock_small<4><<<(unsigned)a.B, RS_NT, lds, st>>>(a);
+    }
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+int launch_resblock_small(const ResSmallLaunch &r, hipStream_t st) {
+    if (!res_small_ok(r)) {
+        set_error("launch_resblock_small: unsupported block shape");
+        return DLPM_ERR_UNSUPPORTED;
+    }
+    const int Cin = r.C0 + r.C1, HW = r.H * r.W;
+    const double fl = 2.0 * r.B * HW * RS_CO * (9.0 * Cin + 9.0 * RS_CO + (r.wsf ? Cin : 0));
+    const double by = 4.0 * ((double)r.B * HW * (Cin + RS_CO) + RS_CO * (9.0 * Cin + 9.0 * RS_CO + (r.wsf ? Cin : 0)));
+    ProfScope ps(r.H == 8 ? "resblock_small:H8" : "resblock_small:H4", fl, by, st);
+    const size_t lds = res_small_lds_bytes(r.H, Cin);
+    if (r.H == 8) {
+        int e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_resblock_small<8>), 160 * 1024);
+        if (e != DLPM_OK) return e;
+        k_resblock_small<8><<<(unsigned)r.B, RS_NT, lds, st>>>(r);
+    } else {
+        int e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_resblock_small<4>), 160 * 1024);
+        if (e != DLPM_OK) return e;
+        k_resblock_small<4><<<(unsigned)r.B, RS_NT, lds, st>>>(r);
+    }
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+}  // namespace dlpm

@@ -122,6 +122,39 @@ int launch_gn_coeffs_from_stats(const float2 *st0, const float2 *st1, int C0, in
                                 const float *gamma, const float *beta, const float *ss, int64_t ss_stride,
                                 int64_t ss_offset, float *coefA, float *coefB, hipStream_t st);
 int launch_attention(const float *qkv, float *out, int B, int T, int C, int heads, hipStream_t st);
+
+// Whole blocks of small images in one launch, activations resident in LDS (block_small.hip): 64-output-channel ResBlocks on
+// 8x8 / 4x4 images, one workgroup per image.
+struct ResSmallLaunch {
+    const float *x0 = nullptr, *x1 = nullptr;   // NHWC input, virtual concat [x0 | x1]
+    int C0 = 0, C1 = 0, B = 0, H = 0, W = 0;
+    const float *gn1_w = nullptr, *gn1_b = nullptr, *gn2_w = nullptr, *gn2_b = nullptr;
+    const float *w1f = nullptr, *b1 = nullptr;   // in_layers.2 (3x3, Cin -> 64), fragment order (relayout_weight_small)
+    const float *w2f = nullptr, *b2 = nullptr;   // out_layers.3 (3x3, 64 -> 64)
+    const float *wsf = nullptr, *bs = nullptr;   // skip_connection (1x1, Cin -> 64) or null = identity
+    const float *emb = nullptr;                  // emb_layers output rows: scale at [emb_off + c], shift at [emb_off + 64 + c]
+    int64_t emb_stride = 0;
+    int emb_off = 0;
+    float *out = nullptr;                        // [B][H W][64]
+    float2 *stats_out = nullptr;                 // optional [B][64] (mean, M2) of the output per image and channel
+};
+struct AttnSmallLaunch {                         // AttentionBlock, 64 channels, 4 heads, 8x8 / 4x4 images
+    const float *x = nullptr;                    // [B][H W][64]
+    int C = 0, heads = 0, B = 0, H = 0, W = 0;
+    const float *gn_w = nullptr, *gn_b = nullptr;
+    const float *wqkv = nullptr, *bqkv = nullptr;    // qkv (1x1, 64 -> 192), fragment order
+    const float *wproj = nullptr, *bproj = nullptr;  // proj_out (1x1, 64 -> 64), fragment order
+    float *out = nullptr;
+    float2 *stats_out = nullptr;
+};
+bool attn_small_ok(const AttnSmallLaunch &a);
+int launch_attnblock_small(const AttnSmallLaunch &a, hipStream_t st);
+bool small_blocks_enabled();                     // DLPM_NO_FUSED_BLOCKS
+bool small_weight_ok(int Cout, int Cin, int ks);
+int64_t small_weight_floats(int Cout, int Cin, int ks);
+int relayout_weight_small(const float *oihw_dev, float *dst_dev, int Cout, int Cin, int ks, hipStream_t st);
+bool res_small_ok(const ResSmallLaunch &r);
+int launch_resblock_small(const ResSmallLaunch &r, hipStream_t st);
 int launch_timestep_embedding(const float *t, float *emb, int64_t B, int dim, hipStream_t st);
 
 __device__ __forceinline__ float silu_f(float v) {

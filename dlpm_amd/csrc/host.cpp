@@ -107,7 +107,7 @@ extern "C" int dlpm_prof_report(char *buf, int64_t n) {
 }
 
 extern "C" const char *dlpm_last_error(void) { return g_err.c_str(); }
-extern "C" int dlpm_abi_version(void) { return 5; }
+extern "C" int dlpm_abi_version(void) { return 6; }
 
 // ---------------------------------------------------------------------------------------------
 // Schedule.  The reference builds it with fp32 torch ops (dlpm.py:114-156); several entries are

@@ -47,6 +47,7 @@ struct ConvW {            // one convolution's weights
     float *w_small = nullptr;// 3x3 with cout <= 4 (head): [tap][cin][4]
     float *w_taps = nullptr; // 3x3 with cout <= 3 (head): [9 cout -> 32][cin], the head as a 1x1 GEMM + gather (conv_direct.hip)
     void *w_split = nullptr; // 1x1 with cout % 128 == 0, cin % 32 == 0: three bf16 planes in stage-tile order (conv_split.hip)
+    float *w_rs = nullptr;   // 64-channel layers: fragment order of the fused small-image blocks (block_small.hip)
     bool owns = false;
 };
 
@@ -318,6 +319,11 @@ int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 no
     const float *src = u->params[c.p_w].dev;
     if (c.use_igemm && c.ks == 1) {  // [O][I] row-major is already the igemm layout
         c.w_dev = const_cast<float *>(src);
+        if (small_weight_ok(c.cout, c.cin, 1) && boundary == 0) {
+            DLPM_HIP(hipMalloc(&c.w_rs, (size_t)small_weight_floats(c.cout, c.cin, 1) * sizeof(float)));
+            int r = relayout_weight_small(src, c.w_rs, c.cout, c.cin, 1, nullptr);
+            if (r != DLPM_OK) return r;
+        }
         if (c.cout % 128 == 0 && c.cin % 32 == 0 && boundary == 0) {
             DLPM_HIP(hipMalloc(&c.w_split, (size_t)split_weight_floats(c.cout, c.cin, 1) * sizeof(float)));
             int r = relayout_weight_split(src, c.w_split, c.cout, c.cin, 1, nullptr);
@@ -360,6 +366,11 @@ int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 no
             r = relayout_weight_wino4(src, c.w_wino4, c.cout, c.cin, nullptr);
             if (r != DLPM_OK) return r;
         }
+    }
+    if (small_weight_ok(c.cout, c.cin, c.ks) && boundary == 0) {
+        DLPM_HIP(hipMalloc(&c.w_rs, (size_t)small_weight_floats(c.cout, c.cin, c.ks) * sizeof(float)));
+        int r = relayout_weight_small(src, c.w_rs, c.cout, c.cin, c.ks, nullptr);
+        if (r != DLPM_OK) return r;
     }
     return relayout_weight(src, c.w_dev, c.cout, c.cin, c.ks, c.use_igemm, nullptr);
 }
@@ -412,6 +423,27 @@ int run_res(Ctx &cx, const Layer &L, Tensor4 x0, Tensor4 x1, Tensor4 *out) {
     dlpm_unet *u = cx.u;
     const int B = cx.B, H = x0.H, W = x0.W, HW = H * W;
     const int C0 = x0.C, C1 = x1.C, Cin = C0 + C1, Co = L.cout;
+    {
+        // small images, 64 channels: the whole block in one launch (block_small.hip).  A function of the layer and of the net's
+        // policy only -- never of the batch -- like every other kernel choice (the fused block rounds differently).
+        ResSmallLaunch r;
+        r.x0 = x0.p; r.x1 = x1.p; r.C0 = C0; r.C1 = C1; r.B = B; r.H = H; r.W = W;
+        r.w1f = L.c1.w_rs; r.w2f = L.c2.w_rs; r.wsf = L.has_skip ? L.skip.w_rs : nullptr;
+        if (u->gen == DLPM_CONV_AUTO && Co == 64 && (!L.has_skip || r.wsf) && res_small_ok(r)) {
+            float *o = cx.ws.alloc((int64_t)B * HW * Co);
+            out->p = o; out->C = Co; out->H = H; out->W = W;
+            out->stats = reinterpret_cast<float2 *>(cx.ws.alloc((int64_t)2 * B * Co));
+            out->stats_px = HW;
+            if (cx.dry()) return DLPM_OK;
+            r.gn1_w = u->params[L.p_gn1_w].dev; r.gn1_b = u->params[L.p_gn1_b].dev;
+            r.gn2_w = u->params[L.p_gn2_w].dev; r.gn2_b = u->params[L.p_gn2_b].dev;
+            r.b1 = u->params[L.c1.p_b].dev; r.b2 = u->params[L.c2.p_b].dev;
+            r.bs = L.has_skip ? u->params[L.skip.p_b].dev : nullptr;
+            r.emb = cx.embout; r.emb_stride = cx.uniform_t ? 0 : u->emb_total; r.emb_off = L.emb_off;
+            r.out = o; r.stats_out = out->stats;
+            return launch_resblock_small(r, cx.st);
+        }
+    }
     float *cA1 = cx.ws.alloc((int64_t)B * Cin), *cB1 = cx.ws.alloc((int64_t)B * Cin);
     Tensor4 h1;
     h1.C = Co; h1.H = H; h1.W = W;
@@ -454,6 +486,23 @@ int run_res(Ctx &cx, const Layer &L, Tensor4 x0, Tensor4 x1, Tensor4 *out) {
 int run_attn(Ctx &cx, const Layer &L, Tensor4 x, Tensor4 *out) {
     dlpm_unet *u = cx.u;
     const int B = cx.B, C = x.C, T = x.H * x.W;
+    {
+        // small images: GroupNorm -> qkv -> attention -> proj -> + x in one launch, one workgroup per image (block_small.hip)
+        AttnSmallLaunch a;
+        a.x = x.p; a.C = C; a.heads = u->cfg.num_heads; a.B = B; a.H = x.H; a.W = x.W;
+        a.wqkv = L.c1.w_rs; a.wproj = L.c2.w_rs;
+        if (u->gen == DLPM_CONV_AUTO && attn_small_ok(a)) {
+            *out = x;
+            out->p = cx.ws.alloc((int64_t)B * T * C);
+            out->stats = reinterpret_cast<float2 *>(cx.ws.alloc((int64_t)2 * B * C));
+            out->stats_px = T;
+            if (cx.dry()) return DLPM_OK;
+            a.gn_w = u->params[L.p_gn1_w].dev; a.gn_b = u->params[L.p_gn1_b].dev;
+            a.bqkv = u->params[L.c1.p_b].dev; a.bproj = u->params[L.c2.p_b].dev;
+            a.out = out->p; a.stats_out = out->stats;
+            return launch_attnblock_small(a, cx.st);
+        }
+    }
     float *cA = cx.ws.alloc((int64_t)B * C), *cB = cx.ws.alloc((int64_t)B * C);
     float *qkv = cx.ws.alloc((int64_t)B * T * 3 * C);
     float *av = cx.ws.alloc((int64_t)B * T * C);
@@ -716,6 +765,8 @@ static void free_conv(ConvW &c) {
     c.w_small = nullptr;
     if (c.w_taps) (void)hipFree(c.w_taps);
     c.w_taps = nullptr;
+    if (c.w_rs) (void)hipFree(c.w_rs);
+    c.w_rs = nullptr;
     if (c.w_split) (void)hipFree(c.w_split);
     c.w_split = nullptr;
     c.w_dev = nullptr;
@@ -1098,6 +1149,44 @@ extern "C" int dlpm_attention_f32(const float *qkv, float *out, int32_t B, int32
                                   dlpm_stream_t stream) {
     DLPM_CHECK_ARG(qkv && out && B > 0, "dlpm_attention_f32: null argument");
     return launch_attention(qkv, out, B, T, C, heads, as_stream(stream));
+}
+
+extern "C" int dlpm_resblock_small_f32(const dlpm_resblock_args *a, float *scratch_dev, int64_t scratch_floats, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(a && a->x0 && a->conv1_w && a->conv2_w && a->ss && a->out && scratch_dev, "dlpm_resblock_small_f32: null argument");
+    DLPM_CHECK_ARG((a->C1 == 0) == (a->x1 == nullptr), "dlpm_resblock_small_f32: x1/C1 mismatch");
+    const int Cin = a->C0 + a->C1;
+    const int64_t n1 = (int64_t)64 * Cin * 9, n2 = (int64_t)64 * 64 * 9, ns = a->skip_w ? (int64_t)64 * Cin : 0;
+    DLPM_CHECK_ARG(scratch_floats >= n1 + n2 + ns, "dlpm_resblock_small_f32: scratch of %lld floats, need %lld", (long long)scratch_floats,
+                   (long long)(n1 + n2 + ns));
+    DLPM_CHECK_ARG(small_weight_ok(64, Cin, 3), "dlpm_resblock_small_f32: %d input channels (64 or 128)", Cin);
+    hipStream_t st = as_stream(stream);
+    TRY(relayout_weight_small(a->conv1_w, scratch_dev, 64, Cin, 3, st));
+    TRY(relayout_weight_small(a->conv2_w, scratch_dev + n1, 64, 64, 3, st));
+    if (a->skip_w) TRY(relayout_weight_small(a->skip_w, scratch_dev + n1 + n2, 64, Cin, 1, st));
+    ResSmallLaunch r;
+    r.x0 = a->x0; r.x1 = a->x1; r.C0 = a->C0; r.C1 = a->C1; r.B = a->B; r.H = a->H; r.W = a->W;
+    r.gn1_w = a->gn1_w; r.gn1_b = a->gn1_b; r.gn2_w = a->gn2_w; r.gn2_b = a->gn2_b;
+    r.w1f = scratch_dev; r.b1 = a->conv1_b; r.w2f = scratch_dev + n1; r.b2 = a->conv2_b;
+    r.wsf = a->skip_w ? scratch_dev + n1 + n2 : nullptr; r.bs = a->skip_b;
+    r.emb = a->ss; r.emb_stride = a->ss_stride; r.emb_off = 0;
+    r.out = a->out; r.stats_out = reinterpret_cast<float2 *>(a->stats_out);
+    return launch_resblock_small(r, st);
+}
+
+extern "C" int dlpm_attnblock_small_f32(const dlpm_attnblock_args *a, float *scratch_dev, int64_t scratch_floats, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(a && a->x && a->qkv_w && a->proj_w && a->out && scratch_dev, "dlpm_attnblock_small_f32: null argument");
+    DLPM_CHECK_ARG(a->C == 64 && a->heads == 4, "dlpm_attnblock_small_f32: 64 channels, 4 heads (got %d, %d)", a->C, a->heads);
+    const int64_t nq = (int64_t)192 * 64, np = (int64_t)64 * 64;
+    DLPM_CHECK_ARG(scratch_floats >= nq + np, "dlpm_attnblock_small_f32: scratch of %lld floats, need %lld", (long long)scratch_floats,
+                   (long long)(nq + np));
+    hipStream_t st = as_stream(stream);
+    TRY(relayout_weight_small(a->qkv_w, scratch_dev, 192, 64, 1, st));
+    TRY(relayout_weight_small(a->proj_w, scratch_dev + nq, 64, 64, 1, st));
+    AttnSmallLaunch l;
+    l.x = a->x; l.C = a->C; l.heads = a->heads; l.B = a->B; l.H = a->H; l.W = a->W;
+    l.gn_w = a->gn_w; l.gn_b = a->gn_b; l.wqkv = scratch_dev; l.bqkv = a->qkv_b; l.wproj = scratch_dev + nq; l.bproj = a->proj_b;
+    l.out = a->out; l.stats_out = reinterpret_cast<float2 *>(a->stats_out);
+    return launch_attnblock_small(l, st);
 }
 
 extern "C" int dlpm_timestep_embedding_f32(const float *t, float *emb, int64_t B, int32_t dim, dlpm_stream_t stream) {

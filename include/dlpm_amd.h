@@ -439,6 +439,39 @@ int dlpm_groupnorm_coeffs_f32(const float *src0, const float *src1, int32_t C0, 
 int dlpm_attention_f32(const float *qkv_dev, float *out_dev, int32_t B, int32_t T, int32_t C, int32_t heads,
                        dlpm_stream_t stream);
 
+/* Whole blocks of SMALL images in one launch, activations resident in LDS, one workgroup per image (round 4; the UNet handle
+ * takes them for its 64-channel blocks on 8x8 / 4x4 images under DLPM_CONV_AUTO).  Weights arrive in the reference's layouts
+ * (OIHW / [O][I][1]) on the device and are re-laid out into scratch_dev on every call (test / bring-up entry points). */
+typedef struct dlpm_resblock_args {
+    const float *x0, *x1;        /* NHWC [B,H,W,C0], [B,H,W,C1] (virtual concat; x1 may be NULL); C0 + C1 = 64 or 128 */
+    int32_t C0, C1, B, H, W;     /* H = W = 8 or 4 */
+    const float *gn1_w, *gn1_b;  /* in_layers.0 */
+    const float *conv1_w, *conv1_b;   /* in_layers.2: [64][C0+C1][3][3], [64] */
+    const float *ss;             /* emb_layers output rows [B][ss_stride]: scale (64) | shift (64) -- unet.py:187-191 */
+    int64_t ss_stride;           /* 0: one row for the whole batch */
+    const float *gn2_w, *gn2_b;  /* out_layers.0 */
+    const float *conv2_w, *conv2_b;   /* out_layers.3: [64][64][3][3], [64] */
+    const float *skip_w, *skip_b;     /* skip_connection [64][C0+C1][1][1] -- required for 128 input channels, NULL for 64 */
+    float *out;                  /* NHWC [B,H,W,64] */
+    float *stats_out;            /* optional [B][64][2]: per image and channel (mean, centred sum of squares) of the output */
+} dlpm_resblock_args;
+/* ResBlock._forward with use_scale_shift_norm (unet.py:176-195): out = skip(x) + conv(silu(GN(conv(silu(GN(x)))) (1 + scale) + shift)).
+ * scratch_floats >= 64 (C0+C1) 9 + 64 64 9 + 64 (C0+C1). */
+int dlpm_resblock_small_f32(const dlpm_resblock_args *args, float *scratch_dev, int64_t scratch_floats, dlpm_stream_t stream);
+
+typedef struct dlpm_attnblock_args {
+    const float *x;              /* NHWC [B,H,W,64] */
+    int32_t C, heads, B, H, W;   /* C = 64, heads = 4, H = W = 8 or 4 */
+    const float *gn_w, *gn_b;    /* norm */
+    const float *qkv_w, *qkv_b;  /* qkv: [192][64][1], [192] (head-major channel order, unet.py:224,243-244) */
+    const float *proj_w, *proj_b;/* proj_out: [64][64][1], [64] */
+    float *out;                  /* NHWC [B,H,W,64] */
+    float *stats_out;            /* optional, as above */
+} dlpm_attnblock_args;
+/* AttentionBlock._forward (unet.py:220-228) + QKVAttention (:236-250): out = x + proj(softmax(q k^T / sqrt(ch)) v).
+ * scratch_floats >= 192 64 + 64 64. */
+int dlpm_attnblock_small_f32(const dlpm_attnblock_args *args, float *scratch_dev, int64_t scratch_floats, dlpm_stream_t stream);
+
 /* emb_dev[B,dim] = [cos(t f_i) | sin(t f_i)]: timestep_embedding, nn.py:103-121. */
 int dlpm_timestep_embedding_f32(const float *t_dev, float *emb_dev, int64_t B, int32_t dim, dlpm_stream_t stream);
 

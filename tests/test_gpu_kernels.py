@@ -768,3 +768,107 @@ def test_conv3x3_bf16_split_implicit_gemm(case):
     assert e16 <= 1.5 * e32 + 1.2e-7 * mag, name
     assert e16 < conv_tol(w, Cin), name
     assert not torch.equal(got16, got32)
+
+
+# ---------------------------------------------------------------- round 4: whole blocks of small images in one launch (block_small.hip)
+def _dev(t):
+    return t.to(DEV).contiguous()
+
+
+@pytest.mark.parametrize('cin,hs', [(64, 8), (64, 4), (128, 8), (128, 4)])
+def test_fused_small_resblock_vs_reference(cin, hs):
+    """k_resblock_small (GroupNorm + SiLU + conv3x3 + GroupNorm x (1 + scale) + shift + SiLU + conv3x3 + skip in ONE launch, one
+    workgroup per image) against the reference's ResBlock (unet.py:105-196) on the F13 fixtures -- 64 -> 64 with the identity
+    skip, 128 (= concat 64 | 64) -> 64 with the 1x1 skip convolution, 8x8 and 4x4 -- and bit-independence of the batch."""
+    import ctypes as C
+    import small_block_weights as sbw
+    from oracle import nets
+    f = golden('f13_small_blocks')
+    tag = 'res_c%d_h%d_' % (cin, hs)
+    sd = sbw.res_state(cin, hs)
+    assert sbw.digest(sd) == bytes(f[tag + 'digest']).hex()
+    x, emb, want = torch.from_numpy(f[tag + 'x']), torch.from_numpy(f[tag + 'emb']), f[tag + 'y']
+    ss = torch.nn.functional.linear(nets.silu(emb), sd['emb_layers.1.weight'], sd['emb_layers.1.bias'])   # the block's emb_layers (host)
+    L, st = _lib.lib(), _lib.stream_ptr()
+
+    def run(xb, ssb):
+        B = xb.shape[0]
+        xh = _dev(nhwc(xb))
+        keep = [xh]
+        a = _lib.ResBlockArgs()
+        if cin == 128:       # the output blocks' virtual concat: two tensors of 64 channels
+            x0, x1 = _dev(xh[..., :64]), _dev(xh[..., 64:])
+            keep += [x0, x1]
+            a.x0, a.x1, a.C0, a.C1 = x0.data_ptr(), x1.data_ptr(), 64, 64
+        else:
+            a.x0, a.x1, a.C0, a.C1 = xh.data_ptr(), None, 64, 0
+        a.B, a.H, a.W = B, hs, hs
+        w = {k: _dev(v) for k, v in sd.items()}
+        a.gn1_w, a.gn1_b = w['in_layers.0.weight'].data_ptr(), w['in_layers.0.bias'].data_ptr()
+        a.conv1_w, a.conv1_b = w['in_layers.2.weight'].data_ptr(), w['in_layers.2.bias'].data_ptr()
+        ssd = _dev(ssb)
+        a.ss, a.ss_stride = ssd.data_ptr(), 128
+        a.gn2_w, a.gn2_b = w['out_layers.0.weight'].data_ptr(), w['out_layers.0.bias'].data_ptr()
+        a.conv2_w, a.conv2_b = w['out_layers.3.weight'].data_ptr(), w['out_layers.3.bias'].data_ptr()
+        if cin == 128:
+            a.skip_w, a.skip_b = w['skip_connection.weight'].data_ptr(), w['skip_connection.bias'].data_ptr()
+        out = torch.empty(B, hs, hs, 64, device=DEV)
+        stats = torch.empty(B, 64, 2, device=DEV)
+        a.out, a.stats_out = out.data_ptr(), stats.data_ptr()
+        n = 64 * cin * 9 + 64 * 64 * 9 + 64 * cin
+        scratch = torch.empty(n, device=DEV)
+        _lib.check(L.dlpm_resblock_small_f32(C.byref(a), scratch.data_ptr(), n, st))
+        torch.cuda.synchronize()
+        return nchw(out).cpu(), stats.cpu()
+
+    got, stats = run(x, ss)
+    err = (got.numpy() - want).__abs__().max()
+    print('fused ResBlock %d -> 64 at %dx%d: max |hip - reference| = %.3g (|y| max %.3g)' % (cin, hs, hs, err, np.abs(want).max()))
+    assert err < 2e-5 * max(1.0, np.abs(want).max())
+    # per-image statistics of the output (what a GroupNorm consumer reads): mean and centred sum of squares per channel
+    g64 = got.double()
+    assert (stats[..., 0].double() - g64.mean(dim=(2, 3))).abs().max() < 1e-5
+    m2 = ((g64 - g64.mean(dim=(2, 3), keepdim=True)) ** 2).sum(dim=(2, 3))
+    assert ((stats[..., 1].double() - m2).abs() / (1 + m2)).max() < 1e-5
+    # a sample's bits do not depend on the batch it travels in
+    big = torch.cat([x[2:3], x, x[0:1]])
+    gb, _ = run(big, torch.cat([ss[2:3], ss, ss[0:1]]))
+    assert torch.equal(gb[1:4], got) and torch.equal(gb[0], got[2]) and torch.equal(gb[4], got[0])
+
+
+@pytest.mark.parametrize('hs', [8, 4])
+def test_fused_small_attention_block_vs_reference(hs):
+    """k_attnblock_small (GroupNorm -> qkv -> softmax(q k^T) v per head -> proj -> + x in one launch) against the reference's
+    AttentionBlock (unet.py:199-250), 64 channels, 4 heads, T = 64 and 16."""
+    import ctypes as C
+    import small_block_weights as sbw
+    f = golden('f13_small_blocks')
+    tag = 'attn_h%d_' % hs
+    sd = sbw.attn_state(hs)
+    assert sbw.digest(sd) == bytes(f[tag + 'digest']).hex()
+    x, want = torch.from_numpy(f[tag + 'x']), f[tag + 'y']
+    L, st = _lib.lib(), _lib.stream_ptr()
+
+    def run(xb):
+        B = xb.shape[0]
+        xh = _dev(nhwc(xb))
+        w = {k: _dev(v) for k, v in sd.items()}
+        a = _lib.AttnBlockArgs()
+        a.x, a.C, a.heads, a.B, a.H, a.W = xh.data_ptr(), 64, 4, B, hs, hs
+        a.gn_w, a.gn_b = w['norm.weight'].data_ptr(), w['norm.bias'].data_ptr()
+        a.qkv_w, a.qkv_b = w['qkv.weight'].data_ptr(), w['qkv.bias'].data_ptr()
+        a.proj_w, a.proj_b = w['proj_out.weight'].data_ptr(), w['proj_out.bias'].data_ptr()
+        out = torch.empty(B, hs, hs, 64, device=DEV)
+        a.out, a.stats_out = out.data_ptr(), None
+        n = 192 * 64 + 64 * 64
+        scratch = torch.empty(n, device=DEV)
+        _lib.check(L.dlpm_attnblock_small_f32(C.byref(a), scratch.data_ptr(), n, st))
+        torch.cuda.synchronize()
+        return nchw(out).cpu()
+
+    got = run(x)
+    err = np.abs(got.numpy() - want).max()
+    print('fused AttentionBlock at %dx%d: max |hip - reference| = %.3g (|y| max %.3g)' % (hs, hs, err, np.abs(want).max()))
+    assert err < 2e-5 * max(1.0, np.abs(want).max())
+    gb = run(torch.cat([x[1:2], x]))
+    assert torch.equal(gb[1:], got) and torch.equal(gb[0], got[1])

@@ -44,7 +44,7 @@ def test_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), 'libdlpm_amd.so does not export %s' % name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert L.dlpm_abi_version() == _lib.ABI_VERSION == 5
+    assert L.dlpm_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_error_channel():

@@ -376,3 +376,30 @@ def test_bounded_wide_unet_trajectories_oracle_vs_reference(name):
     print('%s: %.1f %% of the final pixels inside (-1, 1); oracle vs reference: states %.3g, post-processed pixels %.3g (absolute)'
           % (name, 100 * inside, err_state, err))
     assert err_state < 1e-4 and err < 1e-4
+
+
+# ---------------------------------------------------------------- F13: the blocks the fused small-image kernels replace
+@pytest.mark.parametrize('cin,hs', [(64, 8), (64, 4), (128, 8), (128, 4)])
+def test_small_resblock_oracle_vs_reference(cin, hs):
+    """nets.res_block against the reference's ResBlock (unet.py:105-196) at the fused kernel's shapes; weights from seeds
+    (tests/small_block_weights.py), pinned by the fixture's digest."""
+    import small_block_weights as sbw
+    f = golden('f13_small_blocks')
+    tag = 'res_c%d_h%d_' % (cin, hs)
+    sd = sbw.res_state(cin, hs)
+    assert sbw.digest(sd) == bytes(f[tag + 'digest']).hex()
+    with torch.no_grad():
+        y = nets.res_block(sd, '', T_(f[tag + 'x']), T_(f[tag + 'emb']))
+    assert np.abs(y.numpy() - f[tag + 'y']).max() < 2e-5 * max(1.0, np.abs(f[tag + 'y']).max())
+
+
+@pytest.mark.parametrize('hs', [8, 4])
+def test_small_attention_block_oracle_vs_reference(hs):
+    import small_block_weights as sbw
+    f = golden('f13_small_blocks')
+    tag = 'attn_h%d_' % hs
+    sd = sbw.attn_state(hs)
+    assert sbw.digest(sd) == bytes(f[tag + 'digest']).hex()
+    with torch.no_grad():
+        y = nets.attention_block(sd, '', T_(f[tag + 'x']), 4)
+    assert np.abs(y.numpy() - f[tag + 'y']).max() < 2e-5 * max(1.0, np.abs(f[tag + 'y']).max())

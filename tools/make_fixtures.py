@@ -18,6 +18,7 @@ Fixture families:
   F7 layers              GroupNorm32, QKVAttention, embedding...  dlpm/models/unet.py, nn.py
   F8 generation manager  clamp + inverse affine                   bem/GenerationManager.py:29-63
   F10 LIM sampler        VPSDE, LIM_sampler sde/ode updates        dlpm/methods/LIM/functions/{sde,sampler}.py
+  F13 small blocks       ResBlock / AttentionBlock at the fused kernels' shapes     dlpm/models/unet.py:105-250
   F12 mean types         p_mean_variance: START_X / Z / PREVIOUS_X, denoised_fn, model_kwargs   GenerativeLevyProcess.py:154-219
   F11 image quantisation PIL's float -> 8-bit path (torchvision absent)  bem/evaluate/EvaluationManager.py:188-190
   F9 checkpoints         TrainingManager.save/load, EMAHelper,    bem/TrainingManager.py:240-285, bem/utils_ema.py,
@@ -681,6 +682,46 @@ def f7_layers():
     save('f7_layers', **arrs)
 
 
+def seeded_state(module, seed):
+    """Every tensor of the module's state_dict re-drawn from its own seeded generator (norm weights around 1, everything else
+    N(0, 1 / fan_in)-ish): a recipe the tests repeat verbatim, so fixtures need not carry the weights (a digest pins them)."""
+    with torch.no_grad():
+        for i, (k, v) in enumerate(module.state_dict().items()):
+            gk = torch.Generator().manual_seed(seed * 1000 + i)
+            r = torch.randn(v.shape, generator=gk)
+            if v.dim() == 1:
+                v.copy_(1 + 0.1 * r if ('norm' in k or 'in_layers.0' in k or 'out_layers.0' in k) and k.endswith('weight') else 0.1 * r)
+            else:
+                v.copy_(r / float(np.sqrt(v[0].numel())))
+    return module
+
+
+def f13_small_blocks():
+    """Round 4: the reference's ResBlock (unet.py:105-196, use_scale_shift_norm) and AttentionBlock (:199-250) at the shapes the
+    fused small-image kernels take (block_small.hip): 64 output channels on 8x8 / 4x4 images, 64 or 128 (= concat 64 + 64)
+    input channels, 4 heads.  B = 3; weights from seeded_state (digest stored); emb is the time-embedding vector the block
+    receives (its own emb_layers Linear is part of the block)."""
+    g = torch.Generator().manual_seed(13)
+    arrs = {}
+    for cin in (64, 128):
+        for hs in (8, 4):
+            rb = seeded_state(ref_unet.ResBlock(cin, 128, 0.0, out_channels=64, dims=2, use_scale_shift_norm=True).eval(), cin + hs)
+            x = torch.randn(3, cin, hs, hs, generator=g) * 1.5 + 0.3
+            emb = torch.randn(3, 128, generator=g)
+            tag = 'res_c%d_h%d_' % (cin, hs)
+            arrs[tag + 'x'], arrs[tag + 'emb'], arrs[tag + 'y'] = x, emb, rb(x, emb)
+            arrs[tag + 'digest'] = np.frombuffer(bytes.fromhex(weight_digest(rb)), dtype=np.uint8)
+    for hs in (8, 4):
+        ab = seeded_state(ref_unet.AttentionBlock(64, num_heads=4).eval(), 500 + hs)
+        x = torch.randn(3, 64, hs, hs, generator=g) * 1.5 + 0.3
+        tag = 'attn_h%d_' % hs
+        arrs[tag + 'x'], arrs[tag + 'y'] = x, ab(x)
+        arrs[tag + 'digest'] = np.frombuffer(bytes.fromhex(weight_digest(ab)), dtype=np.uint8)
+    with torch.no_grad():
+        arrs = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in arrs.items()}
+    save('f13_small_blocks', **arrs)
+
+
 def f8_generation_manager():
     class FakeMethod:
         device = 'cpu'
@@ -870,9 +911,9 @@ def f10_lim():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f11', 'f1', 'f2', 'f3', 'f4', 'f5', 'f5u', 'f5w', 'f5k', 'f5b', 'f5c', 'f6', 'f7', 'f8', 'f9', 'f10', 'f12']
+    which = sys.argv[1:] or ['f11', 'f1', 'f2', 'f3', 'f4', 'f5', 'f5u', 'f5w', 'f5k', 'f5b', 'f5c', 'f6', 'f7', 'f8', 'f9', 'f10', 'f12', 'f13']
     table = dict(f12=f12_mean_types, f11=f11_image_quantise, f10=f10_lim, f1=f1_schedule, f2=f2_noise, f3=f3_tables, f4=f4_single_step, f5=f5_trajectories, f5u=f5_unet_trajectory, f5w=f5_wide_unet_trajectory, f5k=f5_unet_trajectories_T1000, f5b=f5_bounded_unet_trajectories, f5c=f5_cifar_teacher_forced,
-                 f6=f6_models, f7=f7_layers, f8=f8_generation_manager, f9=f9_checkpoints)
+                 f6=f6_models, f7=f7_layers, f13=f13_small_blocks, f8=f8_generation_manager, f9=f9_checkpoints)
     with torch.no_grad():
         for w in which:
             table[w]()
