@@ -652,8 +652,23 @@ def main():
                          share_of_step_ms=round(ms_ / nprof, 3),
                          note='achieved = bf16 FLOP/s EXECUTED (6 x the fp32-equivalent rate) over the dense bf16 MFMA peak; the same '
                               'launches on the fp32 MFMA (--gemm f32) run at 85-115 fp32 TFLOP/s')
-        u, hu, hg = prof.get('update'), prof.get('conv3x3_head+update'), prof.get('head_gather+update')
-        if hg:   # the default path: head convolution = 1x1 GEMM onto 9 Cout tap channels (its own launch, class conv1x1_igemm) + this kernel
+        u, hu, hg, hf = prof.get('update'), prof.get('conv3x3_head+update'), prof.get('head_gather+update'), prof.get('head_fused+update')
+        if hf:   # round 4: head convolution + reverse update as ONE pass over HBM (head_fused.hip)
+            n_el = B * shape[1] * shape[2] * shape[3]
+            moved = hf['bytes'] / hf['launches']                       # head input once + read x + write x
+            alg = moved + 4.0 * n_el                                   # + eps (12 B per state element), which never reaches HBM here
+            sec = hf['ms'] / hf['launches'] * 1e-3
+            gbs = alg / sec / 1e9
+            traffic, tnote = pmc_traffic('k_head_fused', args.workload if not args.batch else '%s@B%d' % (args.workload, B))
+            upd = dict(kernel='k_head_fused: the head convolution (GroupNorm + SiLU + 3x3 conv to the image channels, as an MFMA GEMM onto the 9 Cout '
+                              'tap channels whose result stays in LDS) and the x_{t-1} update (Philox noise) in ONE launch, one workgroup per image',
+                       bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(gbs / PEAK_HBM_GBS, 4),
+                       traffic=traffic, traffic_note=tnote, bytes_per_launch=alg, bytes_moved_per_launch=moved,
+                       achieved_on_moved_bytes=round(moved / sec / 1e9, 1), avg_launch_ms=round(sec * 1e3, 5),
+                       note='algorithmic bytes = the head\'s input once + 12 B per state element (read x, eps, write x: SURVEY 8d); eps never '
+                            'reaches HBM in this kernel, so the bytes it moves are 4 B per element fewer (achieved_on_moved_bytes); '
+                            'north-star target for the fused update: 0.60 of HBM')
+        elif hg:   # round 3 path: head convolution = 1x1 GEMM onto 9 Cout tap channels (its own launch, class conv1x1_igemm) + this kernel
             gbs = hg['bytes'] / (hg['ms'] * 1e-3) / 1e9
             traffic, tnote = pmc_traffic('k_head_gather', args.workload if not args.batch else '%s@B%d' % (args.workload, B))
             upd = dict(kernel='k_head_gather with the x_{t-1} update (Philox noise): reads the 9 Cout partial products per pixel the head GEMM '

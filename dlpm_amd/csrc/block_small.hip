@@ -44,21 +44,33 @@ __device__ __forceinline__ void ring_fill(float4 (&ring)[R], const float4 *__res
 
 // (the ring arrives FILLED -- ring_fill, issued as early as the caller can, so the L2 round trip of the first fragments is behind
 //  the phase that precedes the pass)
-template <int MT, int R>
+// RELOAD = false: the ring holds ALL nf = R fragments and is left intact (the caller runs several passes over the same weights)
+template <int MT, int R, bool RELOAD = true>
 __device__ __forceinline__ void mfma_pass(floatx4 (&acc)[MT], float4 (&ring)[R], const float *abuf, const int (&abase)[MT], int LD, int WP,
                                           bool halo, const float4 *__restrict__ wp, int f_first, int nf, int jc_shift) {
+    auto a_off = [&](int fg) {
+        const int tap = fg >> jc_shift, j = fg & ((1 << jc_shift) - 1);
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;          // tap / 3, tap % 3 for tap < 9
+        return (halo ? (ky * WP + kx) * LD : 0) + 16 * j;
+    };
+    // A fragments are read ONE weight fragment ahead (left to the compiler every ds_read sits in front of its MFMAs behind a wait)
+    float4 an[MT];
+    {
+        const int o = a_off(f_first);
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) an[mt] = *reinterpret_cast<const float4 *>(abuf + abase[mt] + o);
+    }
     for (int f = 0; f < nf; f += R) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const float4 bq = ring[r];
-            ring[r] = wp[(int64_t)min(f + r + R, nf - 1) * 64];        // unconditional (clamped): no branch around a load
-            const int fg = f_first + f + r;
-            const int tap = fg >> jc_shift, j = fg & ((1 << jc_shift) - 1);
-            const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;          // tap / 3, tap % 3 for tap < 9
-            const int aoff = (halo ? (ky * WP + kx) * LD : 0) + 16 * j;
+            if (RELOAD) ring[r] = wp[(int64_t)min(f + r + R, nf - 1) * 64];        // unconditional (clamped): no branch around a load
             float4 a[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) a[mt] = *reinterpret_cast<const float4 *>(abuf + abase[mt] + aoff);
+            for (int mt = 0; mt < MT; mt++) a[mt] = an[mt];
+            const int o = a_off(f_first + min(f + r + 1, nf - 1));
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) an[mt] = *reinterpret_cast<const float4 *>(abuf + abase[mt] + o);
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, bq.x, acc[mt], 0, 0, 0);
 #pragma unroll
@@ -98,6 +110,16 @@ __global__ void __launch_bounds__(RS_NT, 1) k_resblock_small(ResSmallLaunch p) {
     const float4 *wp2 = reinterpret_cast<const float4 *>(p.w2f) + ((int64_t)w4 * 36 + half * 18) * 64 + lane;
     float4 ring6[6];
     ring_fill<6>(ring6, wp1, nf1);
+    // every per-channel parameter this thread will need, requested NOW: left where they are used, each is a dependent global load
+    // at the head of a phase (GroupNorm weights after the statistics, biases in the epilogues, the emb row before a2): six exposed
+    // L2 / HBM round trips on a workgroup whose whole life is ~20 us
+    const int c_out = 16 * w4 + ln;      // this lane's output channel (waves 0..3 and 4..7 alike)
+    const int cg1 = Cin >> 5, g1 = tid >> 4, i1 = tid & 15, c_gn1 = min(g1 * cg1 + i1, Cin - 1);
+    const float pr_g1w = p.gn1_w[c_gn1], pr_g1b = p.gn1_b[c_gn1];
+    const float pr_b1 = p.b1[c_out], pr_g2w = p.gn2_w[c_out], pr_g2b = p.gn2_b[c_out];
+    const float *ssr = p.emb + (int64_t)b * p.emb_stride + p.emb_off;
+    const float pr_sc = ssr[c_out], pr_sft = ssr[RS_CO + c_out];
+    const float pr_bo = p.b2[c_out] + (p.wsf ? p.bs[c_out] : 0.f);
 
     // ---- phase 0: zero the halo tiles (their borders stay zero), x -> raw
     {
@@ -130,9 +152,9 @@ __global__ void __launch_bounds__(RS_NT, 1) k_resblock_small(ResSmallLaunch p) {
         const float rstd = 1.0f / sqrtf(v * inv_n + 1e-5f);
         if (i < cg) {
             const int c = g * cg + i;
-            const float a = rstd * p.gn1_w[c];
+            const float a = rstd * pr_g1w;
             cf[c] = a;
-            cf[Cin + c] = p.gn1_b[c] - mean * a;
+            cf[Cin + c] = pr_g1b - mean * a;
         }
     }
     __syncthreads();
@@ -181,10 +203,9 @@ __global__ void __launch_bounds__(RS_NT, 1) k_resblock_small(ResSmallLaunch p) {
             for (int r = 0; r < 4; r++) red[((w4 * MT + mt) * 4 + r) * 64 + lane] = acc[mt][r];
     }
     __syncthreads();
-    const int c_out = 16 * w4 + ln;      // this lane's output channel (waves 0..3 and 4..7 alike)
     if (!half) {
         // ---- phase 4a (waves 0..3): h = conv1 + bias; GroupNorm-2 (groups of two channels = lane pairs) with scale-shift; a2
-        const float b1 = p.b1[c_out];
+        const float b1 = pr_b1;
         float s = 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
@@ -204,10 +225,9 @@ __global__ void __launch_bounds__(RS_NT, 1) k_resblock_small(ResSmallLaunch p) {
                 v = fmaf(d, d, v);
             }
         const float rstd = 1.0f / sqrtf(group_sum(v) * inv_n + 1e-5f);
-        float a = rstd * p.gn2_w[c_out];
-        float bb = p.gn2_b[c_out] - mean * a;
-        const float *ss = p.emb + (int64_t)b * p.emb_stride + p.emb_off;
-        const float sc = 1.0f + ss[c_out], sft = ss[RS_CO + c_out];
+        float a = rstd * pr_g2w;
+        float bb = pr_g2b - mean * a;
+        const float sc = 1.0f + pr_sc, sft = pr_sft;
         a = a * sc;
         bb = fmaf(bb, sc, sft);
 #pragma unroll
@@ -242,7 +262,7 @@ __global__ void __launch_bounds__(RS_NT, 1) k_resblock_small(ResSmallLaunch p) {
     __syncthreads();
     if (!half) {
         // ---- epilogue (waves 0..3): + bias (+ skip bias | + x), store NHWC, optional per-image GroupNorm statistics of the output
-        const float bias = p.b2[c_out] + (p.wsf ? p.bs[c_out] : 0.f);
+        const float bias = pr_bo;
         float *o = p.out + (int64_t)b * HW * RS_CO + c_out;
         float s = 0.f;
 #pragma unroll
@@ -282,17 +302,28 @@ __global__ void __launch_bounds__(RS_NT, 1) k_resblock_small(ResSmallLaunch p) {
 // A-operand layout of P V), with q, k, v read from the LDS copy of qkv; q and k are pre-scaled by ch^(-1/4) as the reference does.
 constexpr int AB_C = 64, AB_LD = AB_C + 4, AB_QLD = 3 * AB_C + 4, AB_HEADS = 4, AB_CH = 16;
 
-template <int HS>
+// QKV_ONLY (16x16 images, T = 256: qkv would not fit LDS beside x): the kernel stops after qkv = conv1(GN(x)) and writes it
+// (unscaled, NHWC [B][T][192]) for attention.hip's kernel -- still one launch instead of GroupNorm coefficients + a 1x1 GEMM of
+// 128-pixel tiles that ran at 40 TFLOP/s (latency-bound: 40 us for 1.6 GFLOP; profiles/r04/mnist_fused_blocks/).
+template <int HS, bool QKV_ONLY>
 __global__ void __launch_bounds__(RS_NT, 1) k_attnblock_small(AttnSmallLaunch p) {
     constexpr int T = HS * HS, MT = T / 16;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *raw = sm;                       // [T][AB_LD]   x
-    float *xn = raw + T * AB_LD;           // [T][AB_LD]   GN(x); later the attention output a
+    float *xn = QKV_ONLY ? raw : raw + T * AB_LD;      // [T][AB_LD]   GN(x) (in place when x is not needed again); later the attention output a
     float *qkvs = xn + T * AB_LD;          // [T][AB_QLD]  qkv (q, k scaled)
-    float *cf = qkvs + T * AB_QLD;         // [2][64]
+    float *cf = QKV_ONLY ? xn + T * AB_LD : qkvs + T * AB_QLD;         // [2][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ln = lane & 15, lq = lane >> 4;
     const int b = blockIdx.x;
+    // parameters and the first weight fragments, requested at entry (see k_resblock_small)
+    const int c_gn = min(2 * (tid >> 4) + (tid & 15), AB_C - 1);
+    const float pr_gw = p.gn_w[c_gn], pr_gb = p.gn_b[c_gn];
+    const float pr_bq0 = p.bqkv[16 * wave + ln], pr_bq1 = p.bqkv[16 * min(wave + 8, 3 * AB_HEADS - 1) + ln];
+    const float pr_bp = p.bproj[16 * (wave & 3) + ln];
+    const float4 *wq0 = reinterpret_cast<const float4 *>(p.wqkv) + (int64_t)wave * 4 * 64 + lane;
+    float4 ringq[4];
+    ring_fill<4>(ringq, wq0, 4);
     for (int i = tid; i < T * (AB_C / 4); i += RS_NT) {
         const int pix = i >> 4, c = (i & 15) * 4;
         *reinterpret_cast<float4 *>(raw + pix * AB_LD + c) = *reinterpret_cast<const float4 *>(p.x + ((int64_t)b * T + pix) * AB_C + c);
@@ -315,9 +346,9 @@ __global__ void __launch_bounds__(RS_NT, 1) k_attnblock_small(AttnSmallLaunch p)
         const float rstd = 1.0f / sqrtf(v * inv_n + 1e-5f);
         if (i < 2) {
             const int c = 2 * g + i;
-            const float a = rstd * p.gn_w[c];
+            const float a = rstd * pr_gw;
             cf[c] = a;
-            cf[AB_C + c] = p.gn_b[c] - mean * a;
+            cf[AB_C + c] = pr_gb - mean * a;
         }
     }
     __syncthreads();
@@ -328,31 +359,43 @@ __global__ void __launch_bounds__(RS_NT, 1) k_attnblock_small(AttnSmallLaunch p)
         *reinterpret_cast<float4 *>(xn + pix * AB_LD + c) = make_float4(fmaf(x.x, A.x, Bc.x), fmaf(x.y, A.y, Bc.y), fmaf(x.z, A.z, Bc.z), fmaf(x.w, A.w, Bc.w));
     }
     __syncthreads();
-    int abx[MT];
+    // (16x16 images: the 16 pixel tiles are walked in groups of four, so the accumulators and the A read-ahead stay at 4 tiles)
+    constexpr int MG = MT > 4 ? 4 : MT;
+    int abx[MG];
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++) abx[mt] = (16 * mt + ln) * AB_LD + 4 * lq;
+    for (int mt = 0; mt < MG; mt++) abx[mt] = (16 * mt + ln) * AB_LD + 4 * lq;
     // ---- qkv = conv1(GN(x)): 12 output tiles of 16 channels over the 8 waves
     const float scale = 0.5f;   // ch^(-1/4), ch = 16 (exact)
     for (int nt = wave; nt < 3 * AB_HEADS; nt += 8) {
-        floatx4 acc[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
         const float4 *wp = reinterpret_cast<const float4 *>(p.wqkv) + (int64_t)nt * 4 * 64 + lane;
-        float4 ring[4];
-        ring_fill<4>(ring, wp, 4);
-        mfma_pass<MT, 4>(acc, ring, xn, abx, AB_LD, 0, false, wp, 0, 4, 2);
         const int co = 16 * nt + ln;
-        const float bias = p.bqkv[co];
+        const float bias = nt < 8 ? pr_bq0 : pr_bq1;
         const bool scaled = (nt % 3) != 2;      // q and k tiles
+        for (int m0 = 0; m0 < MT; m0 += MG) {
+            floatx4 acc[MG];
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
+            for (int mt = 0; mt < MG; mt++) acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (nt >= 8 && m0 == 0) ring_fill<4>(ringq, wp, 4);       // (the first tile's fragments were requested at entry)
+            mfma_pass<MG, 4, false>(acc, ringq, xn + 16 * m0 * AB_LD, abx, AB_LD, 0, false, wp, 0, 4, 2);
+            if (QKV_ONLY) {
+                float *o = p.out + ((int64_t)b * T + 16 * m0) * (3 * AB_C) + co;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float v = acc[mt][r] + bias;
-                if (scaled) v *= scale;
-                qkvs[(16 * mt + 4 * lq + r) * AB_QLD + co] = v;
+                for (int mt = 0; mt < MG; mt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[(16 * mt + 4 * lq + r) * (3 * AB_C)] = acc[mt][r] + bias;
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MG; mt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        float v = acc[mt][r] + bias;
+                        if (scaled) v *= scale;
+                        qkvs[(16 * (m0 + mt) + 4 * lq + r) * AB_QLD + co] = v;
+                    }
             }
+        }
     }
+    if constexpr (!QKV_ONLY) {
     __syncthreads();
     // ---- attention: units (head, query tile) over the waves; a -> xn
     for (int u = wave; u < AB_HEADS * MT; u += 8) {
@@ -411,7 +454,7 @@ __global__ void __launch_bounds__(RS_NT, 1) k_attnblock_small(AttnSmallLaunch p)
         ring_fill<4>(ring, wp, 4);
         mfma_pass<MT, 4>(acc, ring, xn, abx, AB_LD, 0, false, wp, 0, 4, 2);
         const int co = 16 * wave + ln;
-        const float bias = p.bproj[co];
+        const float bias = pr_bp;
         float *o = p.out + (int64_t)b * T * AB_C + co;
         float s = 0.f;
 #pragma unroll
@@ -441,6 +484,7 @@ __global__ void __launch_bounds__(RS_NT, 1) k_attnblock_small(AttnSmallLaunch p)
             if (lq == 0) p.stats_out[(int64_t)b * AB_C + co] = make_float2(mean, m2);
         }
     }
+    }   // !QKV_ONLY
 }
 
 // OIHW (taps = ks * ks) -> Wf[cout / 16][fragment = tap * Cin / 16 + j][lane = lk * 16 + li][e]:
@@ -497,6 +541,26 @@ bool attn_small_ok(const AttnSmallLaunch &a) {
     return small_blocks_enabled() && a.wqkv && a.wproj && a.C == AB_C && a.heads == AB_HEADS && a.H == a.W && (a.H == 8 || a.H == 4);
 }
 
+// 16x16 images: GroupNorm + qkv in one launch per image (a.out = qkv [B][256][192]); attention and proj_out stay separate launches
+bool gnqkv_small_ok(const AttnSmallLaunch &a) {
+    return small_blocks_enabled() && a.wqkv && a.C == AB_C && a.H == 16 && a.W == 16;
+}
+
+int launch_gnqkv_small(const AttnSmallLaunch &a, hipStream_t st) {
+    if (!gnqkv_small_ok(a)) {
+        set_error("launch_gnqkv_small: unsupported block shape");
+        return DLPM_ERR_UNSUPPORTED;
+    }
+    const int T = a.H * a.W;
+    ProfScope ps("gn_qkv_small:H16", 2.0 * a.B * T * 3.0 * AB_C * AB_C, 4.0 * (4.0 * a.B * T * AB_C + 3.0 * AB_C * AB_C), st);
+    const size_t lds = (size_t)(T * AB_LD + 2 * AB_C) * sizeof(float);
+    int e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_attnblock_small<16, true>), 160 * 1024);
+    if (e != DLPM_OK) return e;
+    k_attnblock_small<16, true><<<(unsigned)a.B, RS_NT, lds, st>>>(a);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
 int launch_attnblock_small(const AttnSmallLaunch &a, hipStream_t st) {
     if (!attn_small_ok(a)) {
         set_error("launch_attnblock_small: unsupported block shape");
@@ -507,13 +571,13 @@ int launch_attnblock_small(const AttnSmallLaunch &a, hipStream_t st) {
     ProfScope ps(a.H == 8 ? "attnblock_small:H8" : "attnblock_small:H4", fl, 4.0 * (2.0 * a.B * T * AB_C + 4.0 * AB_C * AB_C), st);
     const size_t lds = (size_t)(2 * T * AB_LD + T * AB_QLD + 2 * AB_C) * sizeof(float);
     if (a.H == 8) {
-        int e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_attnblock_small<8>), 160 * 1024);
+        int e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_attnblock_small<8, false>), 160 * 1024);
         if (e != DLPM_OK) return e;
-        k_attnblock_small<8><<<(unsigned)a.B, RS_NT, lds, st>>>(a);
+        k_attnblock_small<8, false><<<(unsigned)a.B, RS_NT, lds, st>>>(a);
     } else {
-        int e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_attnblock_small<4>), 160 * 1024);
+        int e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_attnblock_small<4, false>), 160 * 1024);
         if (e != DLPM_OK) return e;
-        k_attnblock_small<4><<<(unsigned)a.B, RS_NT, lds, st>>>(a);
+        k_attnblock_small<4, false><<<(unsigned)a.B, RS_NT, lds, st>>>(a);
     }
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;

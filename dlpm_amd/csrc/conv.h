@@ -20,6 +20,7 @@ struct ConvLaunch {
                                    // that carries it is a stride-2 downsampling convolution, or a test forcing the path
     const float *w_small = nullptr;// optional, 3x3 with Cout <= 4 (the head): [tap][Cin][4] for k_conv3x3_head
     const float *w_taps = nullptr; // optional, 3x3 with Cout <= 3 (the head): [9 Cout -> 32][Cin], the head as a 1x1 GEMM + gather (launch_conv_head_gemm)
+    const float *w_hfused = nullptr; // optional, the head: W' in MFMA fragment order for the one-pass head + update kernel (head_fused.hip)
     const float *bias = nullptr;   // [Cout] or null
     const float *coefA = nullptr, *coefB = nullptr;  // [B, Cin] fused GroupNorm affine, or null
     int act_silu = 0;
@@ -77,6 +78,11 @@ int head_taps_rows(int Cout);
 int64_t head_gemm_scratch_floats(const ConvLaunch &c);
 int launch_conv_head_gemm(const ConvLaunch &c, const HeadUpdate *hu, float *P, hipStream_t st);
 int relayout_weight_head_taps(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st);
+// the head and the reverse update in ONE pass over HBM (head_fused.hip): the tap-channel tensor stays in LDS
+bool head_fused_ok(const ConvLaunch &c);
+int64_t head_fused_weight_floats(int Cin);
+int relayout_weight_head_fused(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st);
+int launch_conv_head_fused(const ConvLaunch &c, const HeadUpdate *hu, hipStream_t st);
 // Winograd F(2x2,3x3) path (conv_wino.hip)
 bool wino_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg);
 int wino_tiles(const ConvLaunch &c);   // 2x2 output tiles per workgroup (64 or 32)
@@ -149,6 +155,8 @@ struct AttnSmallLaunch {                         // AttentionBlock, 64 channels,
 };
 bool attn_small_ok(const AttnSmallLaunch &a);
 int launch_attnblock_small(const AttnSmallLaunch &a, hipStream_t st);
+bool gnqkv_small_ok(const AttnSmallLaunch &a);   // 16x16 images: GroupNorm + qkv only, out = qkv [B][256][192]
+int launch_gnqkv_small(const AttnSmallLaunch &a, hipStream_t st);
 bool small_blocks_enabled();                     // DLPM_NO_FUSED_BLOCKS
 bool small_weight_ok(int Cout, int Cin, int ks);
 int64_t small_weight_floats(int Cout, int Cin, int ks);

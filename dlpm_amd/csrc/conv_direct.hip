@@ -401,8 +401,11 @@ int launch_conv_head(const ConvLaunch &c, const HeadUpdate *hu, hipStream_t st) 
 int head_taps_rows(int Cout) { return (9 * Cout + 31) / 32 * 32; }
 
 static int head_gather_rows(const ConvLaunch &c) {   // rows of a gather workgroup's tile: (TH + 2) (W + 2) HG_LD floats of LDS <= 48 KB,
-    int th = c.Hout;                                     // Cout TH W / 4 compute threads <= 256
-    while (th > 1 && ((th + 2) * (c.Wout + 2) * HG_LD * 4 > 48 * 1024 || c.Cout * th * (c.Wout / 4) > 256)) th >>= 1;
+    int th = c.Hout;                                     // Cout TH W / 4 compute threads <= 256, (TH + 2) (W + 2) ceil(9 Cout / 4) load items <= 2560
+    const int nq4 = (9 * c.Cout + 3) / 4;                // (without the last limit the 64x64 head stopped at TH = 4 = 2772 items, head_gemm_ok
+    while (th > 1 && ((th + 2) * (c.Wout + 2) * HG_LD * 4 > 48 * 1024 || c.Cout * th * (c.Wout / 4) > 256 ||   //  said no and the net fell
+                      (th + 2) * (c.Wout + 2) * nq4 > 256 * 10))                                                   //  back to k_conv3x3_head: ADVICE r03)
+        th >>= 1;
     return th;
 }
 

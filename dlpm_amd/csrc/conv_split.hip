@@ -162,6 +162,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split
     extern __shared__ __align__(16) unsigned char smem[];
     DLPM_PHASE_DECL;
 #ifdef DLPM_PHASE_TIMING   // loop sub-phases accumulate in registers (one atomic per counter per workgroup: atomics inside the loop
+    const long long _c0 = clock64(), _r0 = wall_clock64();   // shader cycles and 100-MHz ticks: their ratio is the clock the chip holds
     long long lp[4] = {0, 0, 0, 0};   // queue behind each other at L2 and distort the very waits being measured)
 #define SPLIT_LP(i) do { if (p.phase && threadIdx.x == 0) { const long long _n = clock64(); lp[i] += _n - _pt; _pt = _n; } } while (0)
 #else
@@ -431,6 +432,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split
     if (p.phase && tid == 0) {
         atomicAdd(p.phase + 3, 1ull);
         for (int i = 0; i < 4; i++) atomicAdd(p.phase + 4 + i, (unsigned long long)lp[i]);
+        atomicAdd(p.phase + 12, (unsigned long long)(clock64() - _c0));
+        atomicAdd(p.phase + 13, (unsigned long long)(wall_clock64() - _r0));
     }
 #endif
 }

@@ -108,8 +108,26 @@ __device__ __forceinline__ float2 f2sub(float2 x, float2 y) { return make_float2
 // 4 no raw loads, 8 no barrier, 16 no weight loads, 32 no MFMA, 64 no A-fragment reads
 // QN: staging items per thread (2 for halo patches of <= 512 pixels -- every block shape but 16 whole 4x4 images; round 4: the third
 // item's geometry registers and its dead branch per phase pushed the main instantiation into a scratch reload inside the loop)
-template <bool UPS, int ABL = 0, int QN = F4_QNIT>
-__global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh, int bw, int nimg) {
+// SPEC (round 4, VERDICT r03 next #4b): 1 / 2 = the 32x32 128 -> 128 ResBlock convolution without / with a residual -- 7 launches and
+// 7.2 of the 30.7 ms this kernel takes per CIFAR step, its worst shape (16 phases: prologue + epilogue are 19 % of a workgroup's life).
+// Channel counts (row pitches, the phase count, the single input / residual source) and the presence of the fused GroupNorm +
+// SiLU / bias / residual become compile-time constants, so the generic address arithmetic of the staging and the epilogue folds
+// away.  (The image and block geometry stay run-time values: as constants they let hipcc hoist per-lane addresses out of the
+// phase loop -- 8 to 12 spilled registers, with reloads inside the loop.)
+template <bool UPS, int ABL = 0, int QN = F4_QNIT, int SPEC = 0>
+__global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p_in, int bh_in, int bw_in, int nimg_in) {
+    ConvLaunch p = p_in;
+    int bh = bh_in, bw = bw_in, nimg = nimg_in;
+    if (SPEC) {
+        p.C0 = 128; p.C1 = 0; p.Cout = 128; p.R0 = 128; p.act_silu = 1;
+        p.src1 = nullptr; p.res1 = nullptr;
+        if (SPEC == 1) p.res0 = nullptr;
+        nimg = 1;
+        __builtin_assume(p.coefA != nullptr);
+        __builtin_assume(p.coefB != nullptr);
+        __builtin_assume(p.bias != nullptr);
+        if (SPEC == 2) __builtin_assume(p.res0 != nullptr);
+    }
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float *V = wsm;                               // [2][18][4][16][4]
     float *raw = wsm + 2 * F4_VBUF;               // [2][F4_RAWPIX][F4_PRLD] (+ skew)
@@ -318,6 +336,7 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p, int bh
 #ifdef DLPM_PHASE_TIMING
     long long _wait = 0;      // cycles this wave spends at the phase barrier (developer builds: slots 16 + wave)
 #endif
+#pragma unroll 1
     for (int chunk = 0; chunk < nch; chunk++) {
         const int cur = chunk & 1, nxt = cur ^ 1;
         const float *ab = asrc + cur * F4_VBUF;
@@ -688,22 +707,28 @@ int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
     const int RHp = c.ups ? 2 * bh + 2 : 4 * bh + 2, RWp = c.ups ? 2 * bw + 2 : 4 * bw + 2;
     const bool small = nimg * RHp * RWp <= F4_NT;      // two staging items per thread cover the patch
     KFn fn = c.ups ? (small ? &k_conv3x3_wino4<true, 0, 2> : &k_conv3x3_wino4<true>) : (small ? &k_conv3x3_wino4<false, 0, 2> : &k_conv3x3_wino4<false>);
+    static int spec_on = -1;    // DLPM_WINO_SPEC=1: the channel-specialised instantiations (same bits; measured NEUTRAL, 1.0764-1.0823 vs 1.0786-1.0850 ms
+                                // on the H32 128 -> 128 layer in three alternating runs, profiles/r04/conv_layers_specialised_h32_c128.txt: off)
+    if (spec_on < 0) { const char *e = getenv("DLPM_WINO_SPEC"); spec_on = e ? atoi(e) : 0; }
+    if (spec_on && !c.ups && c.Hout == 32 && c.Wout == 32 && c.C0 == 128 && c.C1 == 0 && c.Cout == 128 && c.coefA && c.coefB && c.bias &&
+        c.act_silu && bh == 4 && bw == 4 && nimg == 1 && !c.res1 && (!c.res0 || c.R0 == 128))
+        fn = c.res0 ? &k_conv3x3_wino4<false, 0, 2, 2> : &k_conv3x3_wino4<false, 0, 2, 1>;
 
 #ifdef DLPM_WINO_ABLATIONS
     static int abl = -1;
     if (abl < 0) { const char *e = getenv("DLPM_WABL"); abl = e ? atoi(e) : 0; }
-    if (!c.ups) {
+    if (!c.ups && small) {       // (the measured shapes: halo patches of <= 512 pixels, the QN = 2 instantiation)
         switch (abl) {
-            case 1: fn = &k_conv3x3_wino4<false, 1>; break;
-            case 2: fn = &k_conv3x3_wino4<false, 2>; break;
-            case 3: fn = &k_conv3x3_wino4<false, 3>; break;
-            case 7: fn = &k_conv3x3_wino4<false, 7>; break;
-            case 8: fn = &k_conv3x3_wino4<false, 8>; break;
-            case 16: fn = &k_conv3x3_wino4<false, 16>; break;
-            case 32: fn = &k_conv3x3_wino4<false, 32>; break;
-            case 64: fn = &k_conv3x3_wino4<false, 64>; break;
-            case 80: fn = &k_conv3x3_wino4<false, 80>; break;
-            case 87: fn = &k_conv3x3_wino4<false, 87>; break;
+            case 1: fn = &k_conv3x3_wino4<false, 1, 2>; break;
+            case 2: fn = &k_conv3x3_wino4<false, 2, 2>; break;
+            case 3: fn = &k_conv3x3_wino4<false, 3, 2>; break;
+            case 7: fn = &k_conv3x3_wino4<false, 7, 2>; break;
+            case 8: fn = &k_conv3x3_wino4<false, 8, 2>; break;
+            case 16: fn = &k_conv3x3_wino4<false, 16, 2>; break;
+            case 32: fn = &k_conv3x3_wino4<false, 32, 2>; break;
+            case 64: fn = &k_conv3x3_wino4<false, 64, 2>; break;
+            case 80: fn = &k_conv3x3_wino4<false, 80, 2>; break;
+            case 87: fn = &k_conv3x3_wino4<false, 87, 2>; break;
             default: break;
         }
     }

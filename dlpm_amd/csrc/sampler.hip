@@ -163,7 +163,8 @@ int one_step(dlpm_sampler *s, const float *z, bool advance, hipStream_t st) {
         a.hist_pp = s->hist_cell;
         return dlpm_lim_update_f32(&a, st);
     }
-    TRY(dlpm_fill_scaled_t_f32(s->tvec, s->t_dev, s->cfg.T, s->cfg.B, st));
+    // (with the time table bound the UNet reads its row by the step counter and never looks at tvec: one launch less per step)
+    if (!(s->cfg.unet && s->emb_tab)) TRY(dlpm_fill_scaled_t_f32(s->tvec, s->t_dev, s->cfg.T, s->cfg.B, st));
     dlpm_update_args a{};
     a.x_dev = s->x; a.eps_dev = s->eps; a.z_dev = z; a.t_dev = s->t_dev;
     a.g_dev = s->g; a.bg_dev = s->bg; a.bs_dev = s->bs;

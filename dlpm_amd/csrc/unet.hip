@@ -48,6 +48,7 @@ struct ConvW {            // one convolution's weights
     float *w_taps = nullptr; // 3x3 with cout <= 3 (head): [9 cout -> 32][cin], the head as a 1x1 GEMM + gather (conv_direct.hip)
     void *w_split = nullptr; // 1x1 with cout % 128 == 0, cin % 32 == 0: three bf16 planes in stage-tile order (conv_split.hip)
     float *w_rs = nullptr;   // 64-channel layers: fragment order of the fused small-image blocks (block_small.hip)
+    float *w_hfused = nullptr;  // head: fragment order of the one-pass head + update kernel (head_fused.hip)
     bool owns = false;
 };
 
@@ -345,6 +346,11 @@ int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 no
             DLPM_HIP(hipMalloc(&c.w_taps, (size_t)head_taps_rows(c.cout) * c.cin * sizeof(float)));
             r = relayout_weight_head_taps(src, c.w_taps, c.cout, c.cin, nullptr);
             if (r != DLPM_OK) return r;
+            if (c.cin <= 128) {
+                DLPM_HIP(hipMalloc(&c.w_hfused, (size_t)head_fused_weight_floats(c.cin) * sizeof(float)));
+                r = relayout_weight_head_fused(src, c.w_hfused, c.cout, c.cin, nullptr);
+                if (r != DLPM_OK) return r;
+            }
         }
     }
     if (c.use_igemm && c.ks == 3 && boundary == 4 && c.cout % 128 == 0 && c.cin % 32 == 0) {   // stride-2 downsampling convolution
@@ -383,10 +389,12 @@ int run_conv(const dlpm_unet *u, const ConvW &c, ConvLaunch L, hipStream_t st, c
     L.w_wino4 = c.w_wino4;
     L.w_small = c.w_small;
     L.w_taps = c.w_taps;
+    L.w_hfused = c.w_hfused;
     L.w_split = c.w_split;
     L.ws_gemm = (c.ks == 1 && c.w_frag) ? 1 : 0;
     L.ks = c.ks;
     L.Cout = c.cout;
+    if (head_fused_ok(L)) return launch_conv_head_fused(L, hu, st);
     if (head_scratch && head_gemm_ok(L)) return launch_conv_head_gemm(L, hu, head_scratch, st);
     if (head_conv_ok(L)) return launch_conv_head(L, hu, st);
     if (hu) { set_error("unet: the head convolution of this net cannot carry the fused update"); return DLPM_ERR_UNSUPPORTED; }
@@ -516,12 +524,20 @@ int run_attn(Ctx &cx, const Layer &L, Tensor4 x, Tensor4 *out) {
         done();
         return DLPM_OK;
     }
-    TRY(gn_any(xin, Tensor4(), B, C < 32 ? C : 32, u->params[L.p_gn1_w].dev, u->params[L.p_gn1_b].dev, nullptr, 0, 0, cA, cB,
-               cx.st));
-    ConvLaunch q;
-    q.src0 = x.p; q.C0 = C; q.B = B; q.Hin = q.Hout = x.H; q.Win = q.Wout = x.W;
-    q.bias = u->params[L.c1.p_b].dev; q.coefA = cA; q.coefB = cB; q.out = qkv;
-    TRY(run_conv(u, L.c1, q, cx.st));
+    AttnSmallLaunch gq;
+    gq.x = x.p; gq.C = C; gq.heads = u->cfg.num_heads; gq.B = B; gq.H = x.H; gq.W = x.W; gq.wqkv = L.c1.w_rs;
+    if (u->gen == DLPM_CONV_AUTO && gnqkv_small_ok(gq)) {
+        // 16x16 images: GroupNorm + qkv of one image in one launch (block_small.hip)
+        gq.gn_w = u->params[L.p_gn1_w].dev; gq.gn_b = u->params[L.p_gn1_b].dev; gq.bqkv = u->params[L.c1.p_b].dev; gq.out = qkv;
+        TRY(launch_gnqkv_small(gq, cx.st));
+    } else {
+        TRY(gn_any(xin, Tensor4(), B, C < 32 ? C : 32, u->params[L.p_gn1_w].dev, u->params[L.p_gn1_b].dev, nullptr, 0, 0, cA, cB,
+                   cx.st));
+        ConvLaunch q;
+        q.src0 = x.p; q.C0 = C; q.B = B; q.Hin = q.Hout = x.H; q.Win = q.Wout = x.W;
+        q.bias = u->params[L.c1.p_b].dev; q.coefA = cA; q.coefB = cB; q.out = qkv;
+        TRY(run_conv(u, L.c1, q, cx.st));
+    }
     TRY(launch_attention(qkv, av, B, T, C, u->cfg.num_heads, cx.st));
     ConvLaunch p;
     p.src0 = av; p.C0 = C; p.B = B; p.Hin = p.Hout = x.H; p.Win = p.Wout = x.W;
@@ -664,7 +680,8 @@ int walk(dlpm_unet *u, Ctx &cx, const float *x, const float *t, float *eps) {
     {
         ConvLaunch a;
         a.C0 = h.C; a.B = B; a.Hin = a.Hout = h.H; a.Win = a.Wout = h.W; a.ks = 3; a.Cout = u->head.cout; a.w_taps = u->head.w_taps; a.out_nchw = 1;
-        if (head_gemm_ok(a)) P = cx.ws.alloc(head_gemm_scratch_floats(a));
+        a.w_hfused = u->head.w_hfused; a.coefA = cA; a.coefB = cB; a.act_silu = 1;
+        if (!head_fused_ok(a) && head_gemm_ok(a)) P = cx.ws.alloc(head_gemm_scratch_floats(a));
     }
     if (!cx.dry()) {
         TRY(gn_any(h, Tensor4(), B, h.C < 32 ? h.C : 32, u->params[u->p_head_gn_w].dev, u->params[u->p_head_gn_b].dev, nullptr,
@@ -767,6 +784,8 @@ static void free_conv(ConvW &c) {
     c.w_taps = nullptr;
     if (c.w_rs) (void)hipFree(c.w_rs);
     c.w_rs = nullptr;
+    if (c.w_hfused) (void)hipFree(c.w_hfused);
+    c.w_hfused = nullptr;
     if (c.w_split) (void)hipFree(c.w_split);
     c.w_split = nullptr;
     c.w_dev = nullptr;
@@ -948,7 +967,10 @@ static bool head_fusable(const dlpm_unet *u) {
     L.C0 = u->head.cin; L.Hin = L.Hout = H; L.Win = L.Wout = H; L.ks = 3; L.Cout = u->head.cout; L.out_nchw = 1;
     L.w_small = u->head.w_small;
     L.w_taps = u->head.w_taps;
-    return head_gemm_ok(L) || head_conv_ok(L);
+    L.w_hfused = u->head.w_hfused;
+    L.coefA = L.coefB = reinterpret_cast<const float *>(u);   // (the head always carries its GroupNorm: only non-null matters here)
+    L.act_silu = 1;
+    return head_fused_ok(L) || head_gemm_ok(L) || head_conv_ok(L);
 }
 
 extern "C" int dlpm_unet_forward_update(dlpm_unet *net, const float *x_in_dev, const float *t_dev, const dlpm_update_args *upd,
@@ -1107,6 +1129,16 @@ extern "C" int dlpm_conv2d_f32(const dlpm_conv_args *a, float *scratch_dev, dlpm
                 L.w_wino = nullptr;   // no F(2x2) alternative: every qualifying geometry takes the F(4x4) kernel
             }
         }
+    }
+    if ((a->force_direct & 64) && a->ksize == 3 && a->Cout <= 3 && a->C0 % 32 == 0 && a->C1 == 0) {
+        // bit 64: the one-pass head kernel (head_fused.hip; in the UNet it also carries the sampler's update): W' fragments in scratch
+        L.w_hfused = scratch_dev;
+        if (a->scratch_floats >= head_fused_weight_floats(a->C0) && head_fused_ok(L)) {
+            TRY(relayout_weight_head_fused(a->weight, scratch_dev, a->Cout, a->C0, st));
+            return launch_conv_head_fused(L, nullptr, st);
+        }
+        set_error("dlpm_conv2d_f32: the one-pass head kernel does not take this shape / scratch size");
+        return DLPM_ERR_UNSUPPORTED;
     }
     if ((a->force_direct & 32) && a->ksize == 3 && a->Cout <= 3 && a->C0 % 32 == 0 && a->C1 == 0) {
         // bit 32: the head as a 1x1 GEMM onto 9 Cout tap channels + gather: W' at the front of the scratch buffer, P behind it

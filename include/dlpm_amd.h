@@ -413,7 +413,8 @@ typedef struct dlpm_conv_args {
                                    bit 2: 1x1 through the weight-streaming kernel; bit 3: 3x3 through the
                                    Winograd F(4x4,3x3) kernel where the shape qualifies (needs scratch for it);
                                    bit 4: 1x1, or 3x3 as an implicit GEMM, through the bf16-split kernel where the shape
-                                   qualifies (scratch: + 1.5x weight) */
+                                   qualifies (scratch: + 1.5x weight); bit 5: the head (Cout <= 3) as a 1x1 GEMM onto its tap
+                                   channels + gather; bit 6: the head as the one-pass kernel (tap channels stay in LDS) */
     int64_t scratch_floats;     /* size of scratch_dev in floats; room for a second, fragment-ordered copy of a
                                    3x3 weight (+1 KB per 32 output channels) enables the weight-streaming kernel */
 } dlpm_conv_args;

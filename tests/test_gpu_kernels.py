@@ -335,7 +335,7 @@ def test_head_conv_kernel(B, C, H, Cout, nchw):
 
 
 @pytest.mark.parametrize('B,C,H,Cout,nchw', [(3, 64, 16, 3, True), (2, 32, 32, 3, True), (2, 128, 32, 1, True), (1, 32, 64, 2, False),
-                                             (5, 128, 32, 3, True)])
+                                             (5, 128, 32, 3, True), (2, 128, 64, 3, True)])   # last: the CelebA-64 head (TH = 2 gather tiles)
 def test_head_conv_as_gemm_plus_gather(B, C, H, Cout, nchw):
     """The head (unet.py:435) as a 1x1 GEMM onto its 9 Cout tap channels (fused GN affine + SiLU) + the 9-point gather
     (force_direct bit 32), against the fp64 reference and next to the dedicated VALU kernel it replaces in the UNet plan."""
@@ -350,6 +350,12 @@ def test_head_conv_as_gemm_plus_gather(B, C, H, Cout, nchw):
     old = run_conv(h, w, b, coef=coef, silu=True, out_nchw=nchw)
     e_new, e_old = (got - want).abs().max().item(), (old - want).abs().max().item()
     print('head %dx%d C%d -> %d: GEMM + gather err %.2e, VALU kernel err %.2e, tol %.2e' % (H, H, C, Cout, e_new, e_old, conv_tol(w, C)))
+    if H % 32 == 0 and C <= 128:
+        # round 4: the ONE-PASS head kernel (force_direct bit 64; head_fused.hip): the tap channels never leave the CU
+        one = run_conv(h, w, b, coef=coef, silu=True, out_nchw=nchw, force_direct=64, scratch_extra=extra)
+        e_one = (one - want).abs().max().item()
+        print('    one-pass head kernel err %.2e' % e_one)
+        assert e_one < conv_tol(w, C)
     assert e_new < conv_tol(w, C) and e_old < conv_tol(w, C)
     got2 = run_conv(h, w, None, out_nchw=nchw, force_direct=32, scratch_extra=extra)       # no activation, no bias
     assert (got2 - ref_conv(h, w, None)).abs().max().item() < conv_tol(w, C)

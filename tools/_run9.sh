@@ -1,0 +1,18 @@
+# validation of a build: full GPU suite (verbose), the driver's bench line, the MNIST workload, rocprof stats + PMC traffic
+tag=${1:-r4m}
+mkdir -p gpurun_out/$tag
+python -m pytest tests -m gpu -q -s > gpurun_out/$tag/gpu_tests_verbose.log 2>&1
+tail -3 gpurun_out/$tag/gpu_tests_verbose.log
+python bench.py > gpurun_out/$tag/bench_cifar.json 2> gpurun_out/$tag/bench_cifar.err
+python bench.py --workload mnist_unet_b256_T1000 --no-cpu-baseline > gpurun_out/$tag/bench_mnist.json 2>&1
+bash tools/profile_bench.sh gpurun_out/$tag/prof > gpurun_out/$tag/profile_bench.log 2>&1
+cp profiles/pmc_traffic.json gpurun_out/$tag/pmc_traffic.json
+cp profiles/r04/pmc_hbm_traffic.txt gpurun_out/$tag/pmc_hbm_traffic.txt 2>/dev/null
+python bench.py --no-cpu-baseline > gpurun_out/$tag/bench_cifar_with_traffic.json 2>&1
+python -c "
+import json
+for f in ['bench_cifar','bench_mnist','bench_cifar_with_traffic']:
+    try:
+        j=json.loads([l for l in open('gpurun_out/$tag/%s.json'%f) if l.startswith('{')][-1]); print(f, j['ms_per_step'], j['value'], j['roofline']['frac'], j['roofline']['traffic'], j['update_kernel']['frac'], j['update_kernel'].get('traffic'), (j.get('cpu_baseline') or {}).get('value'))
+    except Exception as e: print(f, 'ERR', e)
+"

@@ -13,6 +13,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -- python3 $R/bench.py --steps 2 --warmup 2 --no-graph --no-prof --no-cpu-baseline --no-full-trajectory > $out/pmc_$c.log 2>&1
 done
 cd $R
-python3 tools/pmc_summarize.py --json cifar10_unet_b1024_T1000 profiles/r03/pmc_hbm_traffic.txt $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE > $out/pmc_hbm_traffic.txt
+python3 tools/pmc_summarize.py --json cifar10_unet_b1024_T1000 profiles/r04/pmc_hbm_traffic.txt $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE > $out/pmc_hbm_traffic.txt
 cp profiles/pmc_traffic.json $out/pmc_traffic.json
 rm -rf $out/stats $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
