@@ -32,6 +32,7 @@
 //   * epilogue: A^T M A per lane (36 -> 16 values), then bias / residual / fused GroupNorm statistics / stores straight
 //     from the registers (a lane owns 64 outputs of one channel): no LDS, no barrier.
 #include <cstdlib>
+#include <type_traits>
 
 #include "conv.h"
 
@@ -114,7 +115,13 @@ __device__ __forceinline__ float2 f2sub(float2 x, float2 y) { return make_float2
 // SiLU / bias / residual become compile-time constants, so the generic address arithmetic of the staging and the epilogue folds
 // away.  (The image and block geometry stay run-time values: as constants they let hipcc hoist per-lane addresses out of the
 // phase loop -- 8 to 12 spilled registers, with reloads inside the loop.)
-template <bool UPS, int ABL = 0, int QN = F4_QNIT, int SPEC = 0>
+// VS = 1 (round 4; measured neutral, off -- see wino4_vsplit): waves = 2 POSITION HALVES (transform rows 0-2 / 3-5) x 4 channel quarters of 32 instead of 8
+// channel eighths for all 36 positions: a wave still owns 36 accumulator tiles (18 positions x 2 channel tiles) and streams the same
+// weight bytes, but reads only ITS half of V -- every V fragment is read by 4 waves instead of 8 (the held-clock ablations put 12 % of
+// the clock on that LDS traffic).  Y = A^T M A splits by rows of A^T: each wave of a pair turns its 18 positions into 16 partial outputs
+// per (tile, channel), hands the partials of the channel tile its PARTNER finalises over through LDS (one barrier pair, 128 KB: the
+// loop's buffers are dead by then) and runs the unchanged register epilogue on the other.
+template <bool UPS, int ABL = 0, int QN = F4_QNIT, int SPEC = 0, int VS = 0>
 __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p_in, int bh_in, int bw_in, int nimg_in) {
     ConvLaunch p = p_in;
     int bh = bh_in, bw = bw_in, nimg = nimg_in;
@@ -344,8 +351,33 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p_in, int
         float4 aq[F4_AAHEAD + 1];
 #pragma unroll
         for (int a = 0; a < F4_AAHEAD; a++)
-            aq[a] = (ABL & 64) ? make_float4(1.f, 2.f, 1.f, 2.f) : *reinterpret_cast<const float4 *>(ab + a * (4 * F4_TILES * 4));
+            if (!VS) aq[a] = (ABL & 64) ? make_float4(1.f, 2.f, 1.f, 2.f) : *reinterpret_cast<const float4 *>(ab + a * (4 * F4_TILES * 4));
         if (ABL & 64) aq[F4_AAHEAD] = make_float4(1.f, 2.f, 1.f, 2.f);
+        if (VS) {
+            // slot s = (position pair pp = s / 2 of this wave's nine, channel tile nt = s % 2): 18 slots, one weight fragment and four
+            // MFMAs each, side work keyed on the slot exactly as on the position pair of the VS = 0 loop
+            const float *abh = ab + (wave >> 2) * 9 * (4 * F4_TILES * 4);
+            aq[0] = *reinterpret_cast<const float4 *>(abh);
+#pragma unroll
+            for (int sl = 0; sl < 18; sl++) {
+                const int pp = sl >> 1, nt = sl & 1;
+                if (sl >= F4_S0 && sl < F4_S0 + QN) store_raw_item(cur, sl - F4_S0);
+                if (sl == F4_S0 + QN) load_raw_into(xr, min(chunk + 3, last));
+                if (sl == F4_X) transform(nxt);
+                bq[(sl + AHEAD) % F4_RING] = wp[AHEAD * 64 + lane];
+                wp += 64;
+                if (nt == 0 && pp + 1 < 9) aq[(pp + 1) & 1] = *reinterpret_cast<const float4 *>(abh + (pp + 1) * (4 * F4_TILES * 4));
+                const float4 aa = aq[pp & 1];
+                const float2 a0 = make_float2(aa.x, aa.y), a1 = make_float2(aa.z, aa.w);
+                const float4 b = bq[sl % F4_RING];
+                if (F4_PRIO) __builtin_amdgcn_s_setprio(0);
+                acc[4 * pp + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc[4 * pp + nt], 0, 0, 0);
+                acc[4 * pp + 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.z, acc[4 * pp + 2 + nt], 0, 0, 0);
+                acc[4 * pp + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc[4 * pp + nt], 0, 0, 0);
+                acc[4 * pp + 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.w, acc[4 * pp + 2 + nt], 0, 0, 0);
+                if (F4_PRIO) __builtin_amdgcn_s_setprio(1);
+            }
+        } else {
 #pragma unroll
         for (int pp = 0; pp < 18; pp++) {
 #if F4_SKIP_TAIL
@@ -391,6 +423,7 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p_in, int
                 acc[2 * pp + 1][0] += a1.x * b.z + a1.y * b.w;
             }
             if (F4_PRIO) __builtin_amdgcn_s_setprio(1);
+        }
         }
         store_coef(nxt);
 #ifdef DLPM_PHASE_TIMING
@@ -515,10 +548,51 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p_in, int
         // epilogue staged the block through a 135-KB LDS row image for whole-row stores: 3 % slower once the loop's own LDS
         // traffic had been cut, profiles/r02/conv_layers_register_epilogue*.txt.)
         const int64_t pix0 = ((int64_t)img0 * H + 4 * ty0) * W + 4 * tx0;      // wave-uniform
-        const int ch = n0 + 16 * wave + li;
+        // VS: wave (q = wave & 3, ph = wave >> 2) finalises channel tile ph of its quarter: channels 32 q + 16 ph ..
+        const int vph = wave >> 2, cw = VS ? 32 * (wave & 3) + 16 * vph : 16 * wave;
+        const int ch = n0 + cw + li;
         const float bias_v = p.bias ? p.bias[ch] : 0.f;
         const bool has_res = p.res0 != nullptr;
-        const bool res_first = __builtin_amdgcn_readfirstlane(n0 + 16 * wave) < p.R0;   // R0 % 16 == 0 (wino4_geometry)
+        const bool res_first = __builtin_amdgcn_readfirstlane(n0 + cw) < p.R0;   // R0 % 16 == 0 (wino4_geometry)
+        // VS: the 16 partial outputs of tile r and channel tile nt from this wave's three transform rows (ph = 0: the points 0, +a, -a;
+        // ph = 1: +b, -b, inf), then the partner's channel tile goes to LDS: xb[writer wave][r][k][lane]
+        float *xb = wsm;
+        // (nt arrives as a compile-time constant: a run-time index into acc[] would move the accumulators to scratch memory)
+        auto partial = [&](int r, auto nt_c, float (&y)[16]) {
+            constexpr int nt = decltype(nt_c)::value;
+            float Z[4][6];
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                const float ma = acc[(0 * 6 + b) * 2 + nt][r], mb = acc[(1 * 6 + b) * 2 + nt][r], mc = acc[(2 * 6 + b) * 2 + nt][r];
+                if (vph == 0) {
+                    const float sm = mb + mc, df = mb - mc;
+                    Z[0][b] = ma + sm; Z[1][b] = PA * df; Z[2][b] = PA2 * sm; Z[3][b] = PA3 * df;
+                } else {
+                    const float sm = ma + mb, df = ma - mb;
+                    Z[0][b] = sm; Z[1][b] = PB * df; Z[2][b] = PB2 * sm; Z[3][b] = fmaf(PB3, df, mc);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float s12 = Z[i][1] + Z[i][2], d12 = Z[i][1] - Z[i][2], s34 = Z[i][3] + Z[i][4], d34 = Z[i][3] - Z[i][4];
+                y[i * 4 + 0] = Z[i][0] + s12 + s34;
+                y[i * 4 + 1] = fmaf(PB, d34, PA * d12);
+                y[i * 4 + 2] = fmaf(PB2, s34, PA2 * s12);
+                y[i * 4 + 3] = fmaf(PB3, d34, PA3 * d12) + Z[i][5];
+            }
+        };
+        if (VS) {
+            // (the loop's last phase barrier is behind every wave: V / raw are dead, the exchange buffer may overwrite them)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float yo[16];
+                if (vph == 0) partial(r, std::integral_constant<int, 1>(), yo);
+                else partial(r, std::integral_constant<int, 0>(), yo);
+#pragma unroll
+                for (int k = 0; k < 16; k++) xb[((wave * 4 + r) * 16 + k) * 64 + lane] = yo[k];
+            }
+            __syncthreads();
+        }
         const float *res_u = has_res ? (res_first ? p.res0 : p.res1 - p.R0) : nullptr;
         const int res_ld = res_first ? p.R0 : p.Cout - p.R0;
         const int lbw = 31 - __builtin_clz(bw), lbhw = 31 - __builtin_clz(bh * bw);      // block shapes are powers of two
@@ -545,26 +619,37 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p_in, int
                     for (int j = 0; j < 4; j++)
                         rs[i * 4 + j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(res_blk + (i * W + j) * res_ld) + bo_r);
             }
-            float Z[4][6];
+            float Yt[16];
+            if (VS) {
+                if (vph == 0) partial(r, std::integral_constant<int, 0>(), Yt);
+                else partial(r, std::integral_constant<int, 1>(), Yt);
 #pragma unroll
-            for (int b = 0; b < 6; b++) {
-                const float m0 = acc[0 * 6 + b][r], m1 = acc[1 * 6 + b][r], m2 = acc[2 * 6 + b][r];
-                const float m3 = acc[3 * 6 + b][r], m4 = acc[4 * 6 + b][r], m5 = acc[5 * 6 + b][r];
-                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-                Z[0][b] = m0 + s12 + s34;
-                Z[1][b] = fmaf(PB, d34, PA * d12);
-                Z[2][b] = fmaf(PB2, s34, PA2 * s12);
-                Z[3][b] = fmaf(PB3, d34, PA3 * d12) + m5;
+                for (int k = 0; k < 16; k++) Yt[k] += xb[(((wave ^ 4) * 4 + r) * 16 + k) * 64 + lane];
+            } else {
+                float Z[4][6];
+#pragma unroll
+                for (int b = 0; b < 6; b++) {
+                    const float m0 = acc[0 * 6 + b][r], m1 = acc[1 * 6 + b][r], m2 = acc[2 * 6 + b][r];
+                    const float m3 = acc[3 * 6 + b][r], m4 = acc[4 * 6 + b][r], m5 = acc[5 * 6 + b][r];
+                    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                    Z[0][b] = m0 + s12 + s34;
+                    Z[1][b] = fmaf(PB, d34, PA * d12);
+                    Z[2][b] = fmaf(PB2, s34, PA2 * s12);
+                    Z[3][b] = fmaf(PB3, d34, PA3 * d12) + m5;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float s12 = Z[i][1] + Z[i][2], d12 = Z[i][1] - Z[i][2], s34 = Z[i][3] + Z[i][4], d34 = Z[i][3] - Z[i][4];
+                    Yt[i * 4 + 0] = Z[i][0] + s12 + s34;
+                    Yt[i * 4 + 1] = fmaf(PB, d34, PA * d12);
+                    Yt[i * 4 + 2] = fmaf(PB2, s34, PA2 * s12);
+                    Yt[i * 4 + 3] = fmaf(PB3, d34, PA3 * d12) + Z[i][5];
+                }
             }
             if (!ok) continue;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const float s12 = Z[i][1] + Z[i][2], d12 = Z[i][1] - Z[i][2], s34 = Z[i][3] + Z[i][4], d34 = Z[i][3] - Z[i][4];
-                float y[4];
-                y[0] = Z[i][0] + s12 + s34;
-                y[1] = fmaf(PB, d34, PA * d12);
-                y[2] = fmaf(PB2, s34, PA2 * s12);
-                y[3] = fmaf(PB3, d34, PA3 * d12) + Z[i][5];
+                const float *y = Yt + 4 * i;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     float v = y[j] + bias_v;
@@ -611,7 +696,9 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p_in, int
 // OIHW (3x3) -> U = G g G^T (6x6 per filter) in the kernel's fragment order Wf[ntile][wave][phase][18][lane][4]:
 // lane = lk*16 + li holds, for position pair pp and e = 0..3, U_pos[cin = phase*8 + 2 lk + (e & 1)][cout = ntile*128 + wave*16 + li]
 // with pos = 2 pp + (e >> 1).  Computed in double, rounded once.
-__global__ void k_relayout_weight_wino4(const float *oihw, float *dst, int Cout, int Cin) {
+// vs = 1 (the VS kernel): Wf[ntile][wave = 4 ph + q][phase][slot = 2 pp + nt][lane][4]: lane holds, for e = 0..3,
+// U_pos[cin = phase*8 + 2 lk + (e & 1)][cout = ntile*128 + 32 q + 16 nt + li] with pos = 18 ph + 2 pp + (e >> 1)
+__global__ void k_relayout_weight_wino4(const float *oihw, float *dst, int Cout, int Cin, int vs) {
     const int nch = Cin / F4_KC;
     const int64_t total = (int64_t)Cout * Cin * 36;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -624,8 +711,9 @@ __global__ void k_relayout_weight_wino4(const float *oihw, float *dst, int Cout,
     const int wave = (int)(r & 7);
     const int nt = (int)(r >> 3);
     const int lk = lane >> 4, li = lane & 15;
-    const int pos = 2 * pp + (e >> 1);
-    const int cin = chunk * F4_KC + 2 * lk + (e & 1), cout = nt * F4_NQ + wave * 16 + li;
+    const int pos = vs ? 18 * (wave >> 2) + 2 * (pp >> 1) + (e >> 1) : 2 * pp + (e >> 1);
+    const int cin = chunk * F4_KC + 2 * lk + (e & 1);
+    const int cout = vs ? nt * F4_NQ + 32 * (wave & 3) + 16 * (pp & 1) + li : nt * F4_NQ + wave * 16 + li;
     const float *g = oihw + ((int64_t)cout * Cin + cin) * 9;
     const double a = F4_PA, b = F4_PB, a2 = a * a, b2 = b * b;
     const double n0 = a2 * b2, na = 2. * a2 * (a2 - b2), nb = 2. * b2 * (b2 - a2);    // prod_{l != j} (p_j - p_l) for p_j = 0, +-a, +-b
@@ -650,6 +738,18 @@ int f4_mode() {   // DLPM_WINO_F4=0: keep every 3x3 layer on the F(2x2,3x3) kern
 }  // namespace
 
 bool wino4_enabled() { return f4_mode() != 0; }
+// DLPM_WINO_VS=1: waves = 2 position halves x 4 channel quarters (every V fragment read by 4 waves instead of 8).  Built in round 4
+// because the held-clock ablations blamed 12 % of the clock on the V reads; with REAL operands halving that LDS traffic is worth
+// nothing: 12.25 / 12.31 / 12.29 ms against 12.20 / 12.25 / 12.27 over the eight layer shapes in three alternating pairs (long-K layers
+// -0.4 %, K = 128 layers +3 %: the LDS hand-over of the split output transform), profiles/r04/conv_layers_vsplit.txt -- what the
+// ablation had measured was the MFMA's own data activity (it replaces the A fragments by constants), not the LDS.  Off; same
+// results to rounding (the output transform sums two partial transforms).  Read once per process: the weight fragment order built
+// at finalize and the instantiation launched must agree.
+bool wino4_vsplit() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DLPM_WINO_VS"); v = e ? atoi(e) : 0; }
+    return v != 0;
+}
 bool wino4_image_stats() { return F4_EPI_T == 0; }
 
 bool wino4_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
@@ -707,10 +807,12 @@ int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
     const int RHp = c.ups ? 2 * bh + 2 : 4 * bh + 2, RWp = c.ups ? 2 * bw + 2 : 4 * bw + 2;
     const bool small = nimg * RHp * RWp <= F4_NT;      // two staging items per thread cover the patch
     KFn fn = c.ups ? (small ? &k_conv3x3_wino4<true, 0, 2> : &k_conv3x3_wino4<true>) : (small ? &k_conv3x3_wino4<false, 0, 2> : &k_conv3x3_wino4<false>);
+    if (wino4_vsplit()) fn = c.ups ? (small ? &k_conv3x3_wino4<true, 0, 2, 0, 1> : &k_conv3x3_wino4<true, 0, F4_QNIT, 0, 1>)
+                                   : (small ? &k_conv3x3_wino4<false, 0, 2, 0, 1> : &k_conv3x3_wino4<false, 0, F4_QNIT, 0, 1>);
     static int spec_on = -1;    // DLPM_WINO_SPEC=1: the channel-specialised instantiations (same bits; measured NEUTRAL, 1.0764-1.0823 vs 1.0786-1.0850 ms
                                 // on the H32 128 -> 128 layer in three alternating runs, profiles/r04/conv_layers_specialised_h32_c128.txt: off)
     if (spec_on < 0) { const char *e = getenv("DLPM_WINO_SPEC"); spec_on = e ? atoi(e) : 0; }
-    if (spec_on && !c.ups && c.Hout == 32 && c.Wout == 32 && c.C0 == 128 && c.C1 == 0 && c.Cout == 128 && c.coefA && c.coefB && c.bias &&
+    if (spec_on && !wino4_vsplit() && !c.ups && c.Hout == 32 && c.Wout == 32 && c.C0 == 128 && c.C1 == 0 && c.Cout == 128 && c.coefA && c.coefB && c.bias &&
         c.act_silu && bh == 4 && bw == 4 && nimg == 1 && !c.res1 && (!c.res0 || c.R0 == 128))
         fn = c.res0 ? &k_conv3x3_wino4<false, 0, 2, 2> : &k_conv3x3_wino4<false, 0, 2, 1>;
 
@@ -737,7 +839,8 @@ int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
         int r = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), 160 * 1024);
         if (r != DLPM_OK) return r;
     }
-    const size_t loop_b = (size_t)(2 * F4_VBUF + 2 * F4_RAWBUF + 2 * F4_CFS) * sizeof(float);
+    size_t loop_b = (size_t)(2 * F4_VBUF + 2 * F4_RAWBUF + 2 * F4_CFS) * sizeof(float);
+    if (wino4_vsplit() && loop_b < (size_t)8 * 4 * 16 * 64 * sizeof(float)) loop_b = (size_t)8 * 4 * 16 * 64 * sizeof(float);   // the epilogue's exchange buffer
     const int64_t tiles = (int64_t)c.B * (c.Hout / 4) * (c.Wout / 4);
     const int64_t mblocks = nimg == 1 ? tiles / F4_TILES : ceil_div(c.B, nimg);
     fn<<<(unsigned)(mblocks * (c.Cout / F4_NQ)), F4_NT, loop_b, st>>>(c, bh, bw, nimg);
@@ -750,7 +853,7 @@ int64_t wino4_weight_floats(int Cout, int Cin) { return (int64_t)Cout * Cin * 36
 int relayout_weight_wino4(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st) {
     const int64_t n = (int64_t)Cout * Cin * 36;
     DLPM_HIP(hipMemsetAsync(dst_dev + n, 0, (size_t)F4_PAD * 256 * sizeof(float), st));
-    k_relayout_weight_wino4<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
+    k_relayout_weight_wino4<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin, wino4_vsplit() ? 1 : 0);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }
