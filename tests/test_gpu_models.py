@@ -43,10 +43,11 @@ def test_unet_forward_matches_reference(name):
 
 
 @pytest.mark.parametrize('env,bound', [({'DLPM_WINO_F4': '0'}, 1e-5), ({'DLPM_WINO_F4': '0', 'DLPM_NO_WINO': '1'}, 1e-5),
-                                       ({}, 5e-5)], ids=['winograd_f2x2_only', 'implicit_gemm_only', 'default_f4x4'])
+                                       ({}, 2e-5)], ids=['winograd_f2x2_only', 'implicit_gemm_only', 'default_f4x4'])
 def test_unet_every_convolution_generation_against_reference(env, bound):
     """The kernel choice is read once per process, so each generation runs in a child process (tools/err_report.py):
-    CIFAR UNet vs the reference's own output.  Observed: F(4x4) 1.6e-5, F(2x2) 3e-6, implicit GEMM 4.4e-6."""
+    CIFAR UNet vs the reference's own output.  Observed: F(4x4) 5.1e-6 (round 4's interpolation points; 1.35e-5 with the textbook
+    ones, when the bound here was 5e-5), F(2x2) 3e-6, implicit GEMM 4.4e-6."""
     import os
     import re
     import subprocess
