@@ -339,7 +339,8 @@ def test_tiny_unet_trajectory_T1000_oracle_vs_reference():
     assert np.abs(x.numpy() - f['final']).max() < 1e-4 * max(1.0, np.abs(f['final']).max())
 
 
-BOUNDED = ['f5_traj_unet_wide_clip', 'f5_traj_unet_wide_startx_clip', 'f5_traj_unet_wide_startx_clip_damped', 'f5_traj_unet_wide_clip_T1000']
+BOUNDED = ['f5_traj_unet_wide_clip', 'f5_traj_unet_wide_startx_clip', 'f5_traj_unet_wide_startx_clip_damped', 'f5_traj_unet_wide_clip_T1000',
+           'f5_traj_unet_cifar_clip_T1000']   # the last: BASELINE configs[2]'s own net, image size, T and alpha at B = 2 (the oracle takes ~2 min)
 
 
 @pytest.mark.parametrize('name', BOUNDED)
@@ -357,19 +358,44 @@ def test_bounded_wide_unet_trajectories_oracle_vs_reference(name):
     fin = f['final']
     inside = float((np.abs(fin) < 1).mean())
     assert inside >= 0.5 and abs(inside - float(f['inside'])) < 1e-6
-    net, _ = build_unet('wide')
+    net, _ = build_unet(str(f['arch']))
     with torch.no_grad():
         getattr(net.out, '2').weight.mul_(float(f['head_scale']))
         getattr(net.out, '2').bias.mul_(float(f['head_scale']))
     assert state_digest(net) == bytes(f['digest']).hex()
     sd = {k: v.detach() for k, v in net.state_dict().items()}
     T, alpha, ca, ce = f['meta']
-    with torch.no_grad():
-        x, hist = sampler.sample(lambda x, t: nets.unet_forward(sd, x, t, 4), [int(v) for v in f['shape']], int(T),
-                                 float(alpha), sampler.Streams(0, 0), clamp_a=float(ca), clamp_eps=float(ce),
-                                 clip_denoised=True, mean_type=str(f['mean_type']), get_sample_history=True)
     want = f['history_sub']
-    got = hist[::int(f['every'])].numpy()
+    model = lambda x, t: nets.unet_forward(sd, x, t, 4)
+    if str(f['arch']) == 'cifar':
+        # the headline net at T = 1000 is ~2 min of CPU for the whole run: the oracle re-runs the LAST 100 steps, from the
+        # reference's own recorded state 900, with both reference streams advanced to that point (same draws, same order)
+        T, every, shape = int(T), int(f['every']), [int(v) for v in f['shape']]
+        streams = sampler.Streams(0, 0)
+        g, bg, s_, bs = P.schedule(T, float(alpha))
+        A = torch.stack([streams.skewed_levy(float(alpha), shape[0], float(ca)) for _ in range(T)])
+        Sig = P.sigma_table(A, g, s_)
+        streams.skewed_levy(float(alpha), shape[0], None)
+        streams.randn(shape)                                           # x_T's draws
+        k0 = 900
+        for _ in range(k0):
+            streams.randn(shape)                                       # the z of the steps already taken
+        x = T_(want[k0 // every])
+        states = {}
+        with torch.no_grad():
+            for k in range(k0, T - 1):                                 # step k takes state k to state k + 1 at i = T - 1 - k
+                i = T - 1 - k
+                eps = model(x, torch.full((shape[0],), i, dtype=torch.int64).float() * (1.0 / T))
+                eps = P.model_eps(x, eps, i, 'EPSILON', True, None, g, bg, bs, Sig=Sig, A=A)
+                x, _, _ = P.dlpm_step(x, eps, i, Sig, g, bs, streams.randn(shape))
+                states[k + 1] = x
+        got, want = x.numpy()[None], fin[None]
+    else:
+        with torch.no_grad():
+            x, hist = sampler.sample(model, [int(v) for v in f['shape']], int(T),
+                                     float(alpha), sampler.Streams(0, 0), clamp_a=float(ca), clamp_eps=float(ce),
+                                     clip_denoised=True, mean_type=str(f['mean_type']), get_sample_history=True)
+        got = hist[::int(f['every'])].numpy()
     err_state = float(np.abs(got - want).max())
     post = lambda v: P.generation_postprocess(torch.from_numpy(np.asarray(v)), True).numpy()
     err = float(np.abs(post(x.numpy()) - post(fin)).max())

@@ -472,13 +472,20 @@ def f5_bounded_unet_trajectories():
     # fp32 ops, already differs from the reference by 8.3e-5 in the final state there (2e-6 at step 180).  A trained x_0-predictor
     # is a denoiser (contractive near the data); `startx_clip_damped` is the same net with its head convolution scaled by 1/4
     # (exact in fp32: gain < 1), the START_X run on which the 1e-4 contract is meaningful.
-    cases = [('f5_traj_unet_wide_clip', 50, 4, 5, 'EPSILON', 1.0),
-             ('f5_traj_unet_wide_clip_T1000', 1000, 2, 100, 'EPSILON', 1.0),
-             ('f5_traj_unet_wide_startx_clip', 200, 2, 20, 'START_X', 1.0),
-             ('f5_traj_unet_wide_startx_clip_damped', 200, 2, 20, 'START_X', 0.25)]
-    for name, T, B, every, mean_type, head_scale in cases:
+    # ... and the HEADLINE configuration itself: the cifar10.yml UNet (mc = 128, mult (1, 2, 2, 2), attention at 16 / 8 / 4; weights =
+    # f6_unet_cifar's) at 32x32, T = 1000, alpha = 1.7, the config's clamps, B = 2: BASELINE.json configs[2] at a batch the CPU reference
+    # finishes in minutes.
+    cases = [('f5_traj_unet_wide_clip', 50, 4, 5, 'EPSILON', 1.0, 'wide'),
+             ('f5_traj_unet_wide_clip_T1000', 1000, 2, 100, 'EPSILON', 1.0, 'wide'),
+             ('f5_traj_unet_wide_startx_clip', 200, 2, 20, 'START_X', 1.0, 'wide'),
+             ('f5_traj_unet_wide_startx_clip_damped', 200, 2, 20, 'START_X', 0.25, 'wide'),
+             ('f5_traj_unet_cifar_clip_T1000', 1000, 2, 100, 'EPSILON', 1.0, 'cifar')]
+    only = os.environ.get('F5B_ONLY')
+    for name, T, B, every, mean_type, head_scale, arch in cases:
+        if only and only != name:
+            continue
         torch.manual_seed(1234)
-        net = make_unet(3, 128, [1, 2], [2], 4, 2).eval()
+        net = (make_unet(3, 128, [1, 2], [2], 4, 2) if arch == 'wide' else make_unet(3, 128, [1, 2, 2, 2], [4, 8, 16], 4, 2)).eval()
         rerandomize(net, 4321)
         if head_scale != 1.0:
             with torch.no_grad():
@@ -486,7 +493,7 @@ def f5_bounded_unet_trajectories():
                 net.out[2].bias.mul_(head_scale)
         np.random.seed(0)
         torch.manual_seed(0)
-        alpha, shape = 1.7, [B, 3, 16, 16]
+        alpha, shape = 1.7, [B, 3, 16, 16] if arch == 'wide' else [B, 3, 32, 32]
         meth = GenerativeLevyProcess(alpha=alpha, device='cpu', reverse_steps=T, rescale_timesteps=True)
         meth.model_mean_type = mean_type
         x, hist = meth.sample({'default': net}, shape, T, clamp_a=10, clamp_eps=50, clip_denoised=True, get_sample_history=True)
@@ -496,6 +503,7 @@ def f5_bounded_unet_trajectories():
         assert inside >= 0.5, name
         save(name, final=x, history_sub=hist[::every], every=np.array(every), meta=np.array([T, alpha, 10, 50]),
              mean_type=np.array(mean_type), shape=np.array(shape), inside=np.array(inside), head_scale=np.array(head_scale),
+             arch=np.array(arch),
              digest=np.frombuffer(bytes.fromhex(weight_digest(net)), dtype=np.uint8))
 
 
