@@ -1,4 +1,6 @@
-# validation of a build: full GPU suite (verbose), the driver's bench line, the MNIST workload, rocprof stats + PMC traffic
+#!/bin/bash
+# tools/validate_build.sh <tag>: on the GPU box, from the repo root -- the full GPU suite (verbose), the driver's bench line, the MNIST workload,
+# rocprofv3 kernel stats + the PMC traffic record of THIS build (profiles/pmc_traffic.json), and the bench line again with `traffic` filled in.
 tag=${1:-r4m}
 mkdir -p gpurun_out/$tag
 python -m pytest tests -m gpu -q -s > gpurun_out/$tag/gpu_tests_verbose.log 2>&1
