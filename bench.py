@@ -589,7 +589,7 @@ def main():
         assert dist_info['gather_verified'], 'the gathered batch does not hold the shards the ranks produced'
         ids = [ri['device_uuid'] or ri['pci_bus_id'] for ri in ranks_info]
         dist_info['distinct_devices'] = len(set(ids)) if all(i is not None for i in ids) else None
-        if backend == 'nccl' and os.environ.get('DLPM_BENCH_SINGLE_DEVICE') != '1':
+        if backend == 'nccl' and os.environ.get('DLPM_BENCH_SINGLE_DEVICE') != '1' and dist_info['distinct_devices'] is not None:
             assert dist_info['distinct_devices'] == world, 'RCCL ranks share a device: %s' % ids
     else:
         ranks_info, dist_info = [me], dict(backend=None, world_size=1, collective=None, allgather_bytes=0,
