@@ -10,7 +10,7 @@
 // Why a different kernel family: at these sizes a launch of the tiled kernels is ONE workgroup's serial life -- prologue,
 // 8 K-chunks with their barriers, epilogue: 23 of a launch's 26 us (profiles/r03/mnist_where_the_step_goes/) -- and a ResBlock
 // is two of them plus two GroupNorm launches plus (output blocks) a 1x1 launch.  An 8x8 x 64-channel image is 16 KB; with its
-// halo, both activated copies and the concat input it is 115 KB: the whole block fits one CU's LDS, so ONE workgroup per image
+// halo, both activated copies, the concat input and the hand-over buffer it is 131 KB: the whole block fits one CU's LDS, so ONE workgroup per image
 // walks the block with no HBM round trip, no launch gap and no grid-wide dependency (GroupNorm is per image).  A sample's
 // result depends on nothing but the sample: bits are independent of the batch.
 //
@@ -33,18 +33,19 @@ constexpr int RS_NT = 512;     // threads per workgroup
 constexpr int RS_CO = 64;      // output channels of a block
 constexpr int RS_LDO = RS_CO + 4;
 
-// One pass of the implicit GEMM over `nf` weight fragments starting at global fragment index f_first (this wave's share):
-// acc[mt] += A[pixels of tile mt][k] B[k][this wave's 16 channels].  halo: abuf is a halo tile and fragment (tap, j) reads the
-// pixel shifted by the tap; otherwise (1x1) fragment j reads the pixel itself.  R = weight fragments in flight (divides nf).
+// The first R weight fragments of a wave's stream (wp already points at its first fragment + lane), requested as early as the
+// caller can: the L2 round trip is then behind the phase that precedes the pass.
 template <int R>
 __device__ __forceinline__ void ring_fill(float4 (&ring)[R], const float4 *__restrict__ wp, int nf) {
 #pragma unroll
     for (int r = 0; r < R; r++) ring[r] = wp[(int64_t)min(r, nf - 1) * 64];
 }
 
-// (the ring arrives FILLED -- ring_fill, issued as early as the caller can, so the L2 round trip of the first fragments is behind
-//  the phase that precedes the pass)
-// RELOAD = false: the ring holds ALL nf = R fragments and is left intact (the caller runs several passes over the same weights)
+// One pass of the implicit GEMM over `nf` weight fragments starting at global fragment index f_first (this wave's share):
+// acc[mt] += A[pixels of tile mt][k] B[k][this wave's 16 channels].  halo: abuf is a halo tile and fragment (tap, j) reads the
+// pixel shifted by the tap; otherwise (1x1) fragment j reads the pixel itself.  R = weight fragments in flight (divides nf); the ring
+// arrives FILLED (ring_fill).  RELOAD = false: the ring holds ALL nf = R fragments and is left intact (the caller runs several
+// passes over the same weights).
 template <int MT, int R, bool RELOAD = true>
 __device__ __forceinline__ void mfma_pass(floatx4 (&acc)[MT], float4 (&ring)[R], const float *abuf, const int (&abase)[MT], int LD, int WP,
                                           bool halo, const float4 *__restrict__ wp, int f_first, int nf, int jc_shift) {

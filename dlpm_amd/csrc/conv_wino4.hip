@@ -65,7 +65,8 @@ constexpr int F4_PAD = 8;         // float4 fragments of zero padding behind the
 #define F4_PRIO 1     // s_setprio around the MFMA groups (0: off)
 #endif
 #ifndef F4_S0
-#define F4_S0 5    // position pair behind which the staging stores start
+#define F4_S0 6    // position pair behind which the staging stores start (round 4, QN = 2: 6 is 0.8-1.2 % faster than 4, 5, 7..10 -- four alternating
+                   // repetitions, profiles/r04/conv_layers_sidework_placement_qn2.txt; same bits)
 #endif
 #ifndef F4_EPI_T
 #define F4_EPI_T 0  // 1: accumulators transposed (lane = tile, 4 consecutive channels): 16-byte epilogue accesses, 32 instead of 128 memory

@@ -49,14 +49,14 @@ struct HeadFusedArgs {
 };
 
 // NCH = C / 32 K chunks, a compile-time constant: with a run-time bound the chunk loop's loads sit inside (uniform) branches and hipcc
-// drains them at every join (s_waitcnt vmcnt(0)) -- the prefetch of the next chunk stopped being one (0.170 ms, first version)
+// drains them at every join (s_waitcnt vmcnt(0)).
 template <int COUT, int NCH>
 __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
     constexpr int NV = 9 * COUT;                       // live tap channels (27), also the LDS pitch of P (odd: bank spread)
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W = p.W, H = p.H, TH = p.TH;
-    constexpr int C = 32 * NCH, nchunk = NCH;
+    constexpr int C = 32 * NCH;
     const int bands = H / TH, b = blockIdx.x / bands, y0 = (blockIdx.x - b * bands) * TH;
     const int R = TH + 2;                              // row slots of P: image rows y0 - 1 .. y0 + TH
     float *P = sm;                                     // [R][W][NV]
@@ -91,7 +91,8 @@ __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
     };
     // Input chunks travel ONE TILE ahead: buffer c holds chunk c of the tile being worked on and is reloaded with chunk c of the
     // wave's next tile as soon as it has been consumed (16 KB per wave, ~32 MB per chip in flight: what 5 TB/s x the loaded HBM
-    // latency needs; one chunk ahead -- 8 MB in flight -- measured 3.4 TB/s, 0.170 ms)
+    // latency needs).  Latency is not what bounds the kernel, as it turned out -- one chunk ahead measured the same 0.17 ms:
+    // MFMA 40 % + VALU 36 % of its cycles at 1.96 GHz (profiles/r04/head_fused/)
     float4 xb[NCH][4];
     if (wave < ntile) {
         const float *src = tile_src(wave);
