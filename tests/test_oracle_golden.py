@@ -340,7 +340,8 @@ def test_tiny_unet_trajectory_T1000_oracle_vs_reference():
 
 
 BOUNDED = ['f5_traj_unet_wide_clip', 'f5_traj_unet_wide_startx_clip', 'f5_traj_unet_wide_startx_clip_damped', 'f5_traj_unet_wide_clip_T1000',
-           'f5_traj_unet_cifar_clip_T1000']   # the last: BASELINE configs[2]'s own net, image size, T and alpha at B = 2 (the oracle takes ~2 min)
+           'f5_traj_unet_cifar_clip_T1000', 'f5_traj_unet_mnist_clip_T1000', 'f5_traj_unet_celeba64_clip_T1000']
+# the last three: BASELINE configs[2], [1] and [4]'s own nets, image sizes, T = 1000 and alpha (B = 2, 2, 1)
 
 
 @pytest.mark.parametrize('name', BOUNDED)
@@ -367,8 +368,8 @@ def test_bounded_wide_unet_trajectories_oracle_vs_reference(name):
     T, alpha, ca, ce = f['meta']
     want = f['history_sub']
     model = lambda x, t: nets.unet_forward(sd, x, t, 4)
-    if str(f['arch']) == 'cifar':
-        # the headline net at T = 1000 is ~2 min of CPU for the whole run: the oracle re-runs the LAST 100 steps, from the
+    if str(f['arch']) != 'wide':
+        # the configs' own nets at T = 1000 are minutes of CPU for the whole run: the oracle re-runs the LAST 100 steps, from the
         # reference's own recorded state 900, with both reference streams advanced to that point (same draws, same order)
         T, every, shape = int(T), int(f['every']), [int(v) for v in f['shape']]
         streams = sampler.Streams(0, 0)

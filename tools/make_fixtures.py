@@ -475,17 +475,25 @@ def f5_bounded_unet_trajectories():
     # ... and the HEADLINE configuration itself: the cifar10.yml UNet (mc = 128, mult (1, 2, 2, 2), attention at 16 / 8 / 4; weights =
     # f6_unet_cifar's) at 32x32, T = 1000, alpha = 1.7, the config's clamps, B = 2: BASELINE.json configs[2] at a batch the CPU reference
     # finishes in minutes.
-    cases = [('f5_traj_unet_wide_clip', 50, 4, 5, 'EPSILON', 1.0, 'wide'),
-             ('f5_traj_unet_wide_clip_T1000', 1000, 2, 100, 'EPSILON', 1.0, 'wide'),
-             ('f5_traj_unet_wide_startx_clip', 200, 2, 20, 'START_X', 1.0, 'wide'),
-             ('f5_traj_unet_wide_startx_clip_damped', 200, 2, 20, 'START_X', 0.25, 'wide'),
-             ('f5_traj_unet_cifar_clip_T1000', 1000, 2, 100, 'EPSILON', 1.0, 'cifar')]
+    # name, T, B, kept every, mean type, head scale, architecture, channels, image size, alpha, clamp_a, clamp_eps
+    cases = [('f5_traj_unet_wide_clip', 50, 4, 5, 'EPSILON', 1.0, 'wide', 3, 16, 1.7, 10, 50),
+             ('f5_traj_unet_wide_clip_T1000', 1000, 2, 100, 'EPSILON', 1.0, 'wide', 3, 16, 1.7, 10, 50),
+             ('f5_traj_unet_wide_startx_clip', 200, 2, 20, 'START_X', 1.0, 'wide', 3, 16, 1.7, 10, 50),
+             ('f5_traj_unet_wide_startx_clip_damped', 200, 2, 20, 'START_X', 0.25, 'wide', 3, 16, 1.7, 10, 50),
+             ('f5_traj_unet_cifar_clip_T1000', 1000, 2, 100, 'EPSILON', 1.0, 'cifar', 3, 32, 1.7, 10, 50),
+             # BASELINE configs[1]: the mnist.yml UNet (mc = 32, mult (1, 2, 2, 2), attention at 16x16 and 8x8) at 32x32, T = 1000,
+             # alpha = 1.7, the config's clamps -- on the GPU its 8x8 / 4x4 levels are the fused small-image blocks
+             ('f5_traj_unet_mnist_clip_T1000', 1000, 2, 100, 'EPSILON', 1.0, 'mnist', 1, 32, 1.7, 20, 200),
+             # BASELINE configs[4]'s per-GPU net: the CIFAR architecture at 64x64 (dlpm_amd/configs/celeba64.yml), alpha = 1.8, B = 1
+             ('f5_traj_unet_celeba64_clip_T1000', 1000, 1, 100, 'EPSILON', 1.0, 'cifar', 3, 64, 1.8, 10, 50)]
     only = os.environ.get('F5B_ONLY')
-    for name, T, B, every, mean_type, head_scale, arch in cases:
-        if only and only != name:
+    archs = {'wide': (128, [1, 2], [2], 2), 'cifar': (128, [1, 2, 2, 2], [4, 8, 16], 2), 'mnist': (32, [1, 2, 2, 2], [2, 4], 2)}
+    for name, T, B, every, mean_type, head_scale, arch, chans, size, alpha, ca, ce in cases:
+        if only and only not in name:
             continue
         torch.manual_seed(1234)
-        net = (make_unet(3, 128, [1, 2], [2], 4, 2) if arch == 'wide' else make_unet(3, 128, [1, 2, 2, 2], [4, 8, 16], 4, 2)).eval()
+        mc, mult, attn, res = archs[arch]
+        net = make_unet(chans, mc, mult, attn, 4, res).eval()
         rerandomize(net, 4321)
         if head_scale != 1.0:
             with torch.no_grad():
@@ -493,15 +501,15 @@ def f5_bounded_unet_trajectories():
                 net.out[2].bias.mul_(head_scale)
         np.random.seed(0)
         torch.manual_seed(0)
-        alpha, shape = 1.7, [B, 3, 16, 16] if arch == 'wide' else [B, 3, 32, 32]
+        shape = [B, chans, size, size]
         meth = GenerativeLevyProcess(alpha=alpha, device='cpu', reverse_steps=T, rescale_timesteps=True)
         meth.model_mean_type = mean_type
-        x, hist = meth.sample({'default': net}, shape, T, clamp_a=10, clamp_eps=50, clip_denoised=True, get_sample_history=True)
+        x, hist = meth.sample({'default': net}, shape, T, clamp_a=ca, clamp_eps=ce, clip_denoised=True, get_sample_history=True)
         inside = float((x.abs() < 1).float().mean())
         print('%s: |x| max %.4g, %.1f %% of the final pixels inside (-1, 1), max |state| over the run %.4g'
               % (name, float(x.abs().max()), 100 * inside, float(hist.abs().max())))
         assert inside >= 0.5, name
-        save(name, final=x, history_sub=hist[::every], every=np.array(every), meta=np.array([T, alpha, 10, 50]),
+        save(name, final=x, history_sub=hist[::every], every=np.array(every), meta=np.array([T, alpha, ca, ce]),
              mean_type=np.array(mean_type), shape=np.array(shape), inside=np.array(inside), head_scale=np.array(head_scale),
              arch=np.array(arch),
              digest=np.frombuffer(bytes.fromhex(weight_digest(net)), dtype=np.uint8))
