@@ -275,3 +275,32 @@ def test_unet_gemm_policy_both_pipes_against_reference(name):
     assert not torch.equal(outs['f32'], outs['bf16x3'])
     assert err['f32'] < 1e-5 and err['bf16x3'] < 1e-5
     assert err['bf16x3'] < 2 * err['f32'] + 1e-6
+
+
+def test_integration_md_ctypes_stub_runs_as_written():
+    """INTEGRATION.md section 2 shows the ctypes binding a maintainer of the reference would add (handles, struct layouts, the
+    three calls that replace p_sample_loop).  The block is executed VERBATIM here -- a stale struct layout in the document (the
+    round-3 text lacked SamplerConfig.mean_type) would read garbage or fail -- with the reference-shaped state_dict of the CIFAR net
+    and a two-sample state as the names it leaves to the host (`reference_state_dict`, `x`, `t`)."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+    doc = open(os.path.join(root, 'INTEGRATION.md')).read()
+    sec = doc[doc.index('## 2. The C ABI'):]
+    code = re.search(r'```python\n(.*?)```', sec, re.S).group(1)
+    net, _ = build_unet('cifar')
+    x = torch.randn(2, 3, 32, 32, device=DEV)
+    env = dict(reference_state_dict=net.state_dict(), x=x, t=torch.full((2,), 0.5, device=DEV))
+    cwd = os.getcwd()
+    os.chdir(root)                      # the stub loads 'dlpm_amd/lib/libdlpm_amd.so' relative to the repository root
+    try:
+        exec(compile(code, 'INTEGRATION.md', 'exec'), env)
+    finally:
+        os.chdir(cwd)
+    torch.cuda.synchronize()
+    eps, out = env['eps'], env['out']
+    want = net(x, torch.full((2,), 0.5, device=DEV))
+    assert torch.equal(eps, want)                                   # the stub's dlpm_unet_forward == the Python wrapper's
+    assert out.shape == (2, 3, 32, 32) and bool(torch.isfinite(out).all())
+    env['L'].dlpm_sampler_destroy(env['smp'])
+    env['L'].dlpm_unet_destroy(env['net'])
