@@ -18,6 +18,13 @@
 // [pixel][channel] into the MFMA's A layout (lane = pixel, k slot = channel): the k index of an MFMA is free as long as A and B
 // agree, so slot kh of MFMA (q, e) is channel 32 c + 8 q + 4 kh + e and one ds_read_b128 feeds four MFMAs.  W' sits in registers
 // for the whole kernel in that fragment order (64 VGPRs at 128 channels).
+//
+// BF = true (the default pipe; DLPM_HEAD_F32=1 or the fp32 GEMM policy take the form above): the same GEMM on the bf16 matrix pipe with
+// conv_split.hip's exact three-plane split -- act(h) is cut into three bf16 planes in registers right after the SiLU (and + subtract twice,
+// v_perm packs), W' is cut once at finalize, six v_mfma_f32_32x32x16_bf16 per 16 channels replace eight fp32 MFMAs per 16 channels at a
+// quarter of the cycles each (the fp32 form was SIMD-issue-bound: fp32 MFMAs 40 % + VALU 36 % of its cycles, and the fp32 MFMA shares
+// the vector lanes; the bf16 one runs beside the VALU).  The transpose patch holds [plane][pixel][32 channels] bf16 with the 16-byte
+// units of a pixel row XOR-swizzled by (pixel >> 1) & 3 (no padding: P + the patches fill the 160 KB).
 #include "conv.h"
 #include "philox.h"
 
@@ -25,10 +32,35 @@ namespace dlpm {
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int HF_NT = 512;        // 8 waves
 constexpr int HF_SLD = 36;        // floats per pixel row of a wave's transpose patch (32 channels + 4: conflict-free b128 reads)
 constexpr int HF_MAXCH = 4;       // K chunks of 32 channels the register-resident weights cover (Cin <= 128)
+constexpr int HF_STG_F32 = 32 * HF_SLD;   // dwords of a wave's transpose patch, fp32 form
+constexpr int HF_STG_BF = 3 * 32 * 16;    // ... bf16 form: [plane][pixel][32 bf16]
+constexpr float HF_LOG2E = 1.44269504088896340736f;
+
+// fp32 pair -> the packed bf16 pairs of its three planes (conv_split.hip's split, exact: 8 + 8 + 8 significand bits)
+__device__ __forceinline__ void hf_split2(float lo, float hi, uint32_t &p0, uint32_t &p1, uint32_t &p2) {
+    const uint32_t ul = __float_as_uint(lo), uh = __float_as_uint(hi);
+    p0 = __builtin_amdgcn_perm(uh, ul, 0x07060302u);
+    f32x2 r = f32x2{lo, hi} - f32x2{__uint_as_float(ul & 0xffff0000u), __uint_as_float(uh & 0xffff0000u)};
+    const uint32_t vl = __float_as_uint(r.x), vh = __float_as_uint(r.y);
+    p1 = __builtin_amdgcn_perm(vh, vl, 0x07060302u);
+    f32x2 q = r - f32x2{__uint_as_float(vl & 0xffff0000u), __uint_as_float(vh & 0xffff0000u)};
+    p2 = __builtin_amdgcn_perm(__float_as_uint(q.y), __float_as_uint(q.x), 0x07060302u);
+}
+
+// silu(x a + b) on a pair: silu_f's arithmetic (v * rcp(1 + exp2(-v log2e))), written on 2-vectors so that the multiplies and adds
+// become v_pk_*_f32
+__device__ __forceinline__ f32x2 hf_act2(f32x2 x, f32x2 a, f32x2 b) {
+    const f32x2 v = __builtin_elementwise_fma(x, a, b);
+    const f32x2 t = -v * HF_LOG2E;
+    const f32x2 d = 1.0f + f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    return v * f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
 
 #define HF_LDS_EXCHANGE()                                             \
     do {                                                              \
@@ -37,51 +69,68 @@ constexpr int HF_MAXCH = 4;       // K chunks of 32 channels the register-reside
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local"); \
     } while (0)
 
+// rows of P a workgroup keeps: its TH output rows + the halo rows that lie inside the picture
+__host__ __device__ __forceinline__ int hf_rows_kept(int H, int TH) { return H == TH ? TH : (H == 2 * TH ? TH + 1 : TH + 2); }
+
 struct HeadFusedArgs {
     const float *h;               // [B][H][W][C] NHWC
     const float *coefA, *coefB;   // [B][C] GroupNorm affine (SiLU follows)
-    const float *wf;              // W' in fragment order [C/32][4][64][4]
+    const float *wf;              // W' in fragment order: fp32 [C/32][4][64][4], behind it the bf16 planes [C/32][2][3][64][8]
     const float *bias;            // [Cout]
     float *out;                   // eps (plain forward): NCHW [B][Cout][H][W] or NHWC
     int out_nchw;
     int B, H, W, C, TH;
     HeadUpdate u;
+#ifdef DLPM_PHASE_TIMING
+    unsigned long long *phase;    // developer builds: 0 prologue, 1 tile loop, 2 barrier + gather/update, 3 workgroups, 12/13 clock, 16+w barrier wait
+#endif
 };
 
 // NCH = C / 32 K chunks, a compile-time constant: with a run-time bound the chunk loop's loads sit inside (uniform) branches and hipcc
 // drains them at every join (s_waitcnt vmcnt(0)).
-template <int COUT, int NCH>
+template <int COUT, int NCH, bool BF>
 __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
     constexpr int NV = 9 * COUT;                       // live tap channels (27), also the LDS pitch of P (odd: bank spread)
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W = p.W, H = p.H, TH = p.TH;
     constexpr int C = 32 * NCH;
+#ifdef DLPM_PHASE_TIMING
+    const long long _c0 = clock64(), _r0 = wall_clock64();
+    long long _c1 = _c0, _c2 = _c0, _c3 = _c0;
+#endif
     const int bands = H / TH, b = blockIdx.x / bands, y0 = (blockIdx.x - b * bands) * TH;
-    const int R = TH + 2;                              // row slots of P: image rows y0 - 1 .. y0 + TH
-    float *P = sm;                                     // [R][W][NV]
-    float *stg = sm + ((R * W * NV + 3) & ~3) + wave * (32 * HF_SLD);
+    // row slots of P: image rows y0 - 1 .. y0 + TH, of which only those inside the picture are kept (s_lo .. s_hi - 1)
+    const int s_lo = y0 == 0 ? 1 : 0, s_hi = (y0 + TH == H) ? TH + 1 : TH + 2;
+    // P as NV planes [row s - s_lo][W] of pitch PL = rows W + 4 floats: a lane's four consecutive pixels are one 16-byte LDS access on
+    // both sides (MFMA registers 4 j .. 4 j + 3 in; a gather item's pixel quad out), the + 4 spreads the 27 lanes of a store over the banks
+    const int PL = hf_rows_kept(H, TH) * W + 4;
+    float *P = sm;
+    float *stg = sm + NV * PL + wave * (BF ? HF_STG_BF : HF_STG_F32);
     const int tpr = W >> 5;                            // 32-pixel tiles per row
     const int64_t HW = (int64_t)H * W;
 
     // ---- W' fragments and this image's GroupNorm coefficients: registers for the whole kernel
-    float4 bw[NCH][4], cA[NCH], cB[NCH];
+    float4 bw[BF ? 1 : NCH][4];
+    bf16x8 bwb[BF ? NCH : 1][2][3];
+    float4 cA[NCH], cB[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
+        if constexpr (BF) {
+            const bf16x8 *wb = reinterpret_cast<const bf16x8 *>(p.wf + (int64_t)C * 32);
 #pragma unroll
-        for (int q = 0; q < 4; q++) bw[c][q] = reinterpret_cast<const float4 *>(p.wf)[(c * 4 + q) * 64 + lane];
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) bwb[c][j][pl] = wb[((c * 2 + j) * 3 + pl) * 64 + lane];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) bw[c][q] = reinterpret_cast<const float4 *>(p.wf)[(c * 4 + q) * 64 + lane];
+        }
         cA[c] = *reinterpret_cast<const float4 *>(p.coefA + (int64_t)b * C + 32 * c + 4 * (lane & 7));
         cB[c] = *reinterpret_cast<const float4 *>(p.coefB + (int64_t)b * C + 32 * c + 4 * (lane & 7));
     }
-    // rows of the slot image that lie outside the picture are zero (the taps that would read them are simply absent)
-    for (int s = 0; s < R; s++) {
-        const int iy = y0 - 1 + s;
-        if (iy < 0 || iy >= H)
-            for (int i = tid; i < W * NV; i += HF_NT) P[s * W * NV + i] = 0.f;
-    }
 
     // ---- phase A: the band's rows as 32-pixel tiles, round-robin over the waves
-    const int s_lo = y0 == 0 ? 1 : 0, s_hi = (y0 + TH == H) ? R - 1 : R;      // slots with a real image row
     const int ntile = (s_hi - s_lo) * tpr;
     const int lp = lane >> 3, lc = lane & 7;           // load role: pixel 8 i + lp, channels 4 lc .. 4 lc + 3 of the chunk
     const int lm = lane & 31, kh = lane >> 5;          // MFMA role: pixel lm, k slot kh
@@ -89,41 +138,78 @@ __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
         const int s = s_lo + t / tpr, x0 = (t - (t / tpr) * tpr) * 32;
         return p.h + (((int64_t)b * H + (y0 - 1 + s)) * W + x0) * C + 4 * lc;
     };
+    // bf16 form, dword offsets into the wave's patch: a pixel row is 16 dwords = four 16-byte units (8 channels each), unit u of pixel
+    // px sits at slot u ^ ((px >> 1) & 3) -- the 8 lanes of a b128 read phase (8 consecutive pixels, same u) then cover all 32 banks
+    const int wr_off = lp * 16 + 4 * ((lc >> 1) ^ ((lp >> 1) & 3)) + 2 * (lc & 1);      // + plane 512 + i 128
+    const int rd_sw = (lm >> 1) & 3;                                                      // unit 2 j + kh -> slot ^ rd_sw
     // Input chunks travel ONE TILE ahead: buffer c holds chunk c of the tile being worked on and is reloaded with chunk c of the
     // wave's next tile as soon as it has been consumed (16 KB per wave, ~32 MB per chip in flight: what 5 TB/s x the loaded HBM
-    // latency needs).  Latency is not what bounds the kernel, as it turned out -- one chunk ahead measured the same 0.17 ms:
-    // MFMA 40 % + VALU 36 % of its cycles at 1.96 GHz (profiles/r04/head_fused/)
+    // latency needs).
     float4 xb[NCH][4];
     if (wave < ntile) {
         const float *src = tile_src(wave);
 #pragma unroll
-        for (int c = 0; c < NCH; c++)
+        for (int c = 0; c < NCH; c++) {
 #pragma unroll
             for (int i = 0; i < 4; i++) xb[c][i] = *reinterpret_cast<const float4 *>(src + 32 * c + (int64_t)(8 * i + lp) * C);
+            // chunk order, as the loop reloads them: the loop's vmcnt waits are the merge of both entry paths, and hipcc sorts
+            // these 16 loads by address otherwise (vmcnt(5) at the loop top = waiting for loads issued one chunk ago)
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
-    for (int t = wave; t < ntile; t += 8) {
+    // (the loop sits behind the same condition as those loads, as a do-while: were its header reachable without them, the static
+    // vmcnt at its top would be the one that path needs for the coefficient loads above -- vmcnt(5), on every iteration)
+#ifdef DLPM_PHASE_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the prologue's loads have landed: phase 0 ends here)
+    _c1 = clock64();
+#endif
+    if (wave < ntile) for (int t = wave;;) {
         floatx16 acc;
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.f;
         const float *nsrc = tile_src(t + 8 < ntile ? t + 8 : t);        // (the last tile reloads itself: unconditional loads)
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
-            {
+            const f32x2 a01 = {cA[c].x, cA[c].y}, a23 = {cA[c].z, cA[c].w}, b01 = {cB[c].x, cB[c].y}, b23 = {cB[c].z, cB[c].w};
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const float4 xr = xb[c][i];
-                    float4 v;
-                    v.x = silu_f(fmaf(xr.x, cA[c].x, cB[c].x));
-                    v.y = silu_f(fmaf(xr.y, cA[c].y, cB[c].y));
-                    v.z = silu_f(fmaf(xr.z, cA[c].z, cB[c].z));
-                    v.w = silu_f(fmaf(xr.w, cA[c].w, cB[c].w));
-                    *reinterpret_cast<float4 *>(stg + (8 * i + lp) * HF_SLD + 4 * lc) = v;
+            for (int i = 0; i < 4; i++) {
+                const float4 xr = xb[c][i];
+                const f32x2 v01 = hf_act2(f32x2{xr.x, xr.y}, a01, b01), v23 = hf_act2(f32x2{xr.z, xr.w}, a23, b23);
+                if constexpr (BF) {
+                    uint32_t q0[2], q1[2], q2[2];
+                    hf_split2(v01.x, v01.y, q0[0], q1[0], q2[0]);
+                    hf_split2(v23.x, v23.y, q0[1], q1[1], q2[1]);
+                    uint32_t *dst = reinterpret_cast<uint32_t *>(stg) + wr_off + i * 128;
+                    *reinterpret_cast<uint2 *>(dst) = make_uint2(q0[0], q0[1]);
+                    *reinterpret_cast<uint2 *>(dst + 512) = make_uint2(q1[0], q1[1]);
+                    *reinterpret_cast<uint2 *>(dst + 1024) = make_uint2(q2[0], q2[1]);
+                } else {
+                    *reinterpret_cast<float4 *>(stg + (8 * i + lp) * HF_SLD + 4 * lc) = make_float4(v01.x, v01.y, v23.x, v23.y);
                 }
+            }
 #pragma unroll
-                for (int i = 0; i < 4; i++) xb[c][i] = *reinterpret_cast<const float4 *>(nsrc + 32 * c + (int64_t)(8 * i + lp) * C);
-                // wave-private exchange: LDS operations of one wave execute in order; the LDS-only fences keep the compiler from
-                // moving them (a plain wavefront fence also drains the GLOBAL loads in flight: the prefetch)
-                HF_LDS_EXCHANGE();
+            for (int i = 0; i < 4; i++) xb[c][i] = *reinterpret_cast<const float4 *>(nsrc + 32 * c + (int64_t)(8 * i + lp) * C);
+            // wave-private exchange: LDS operations of one wave execute in order; the LDS-only fences keep the compiler from
+            // moving them (a plain wavefront fence also drains the GLOBAL loads in flight: the prefetch)
+            HF_LDS_EXCHANGE();
+            if constexpr (BF) {
+                bf16x8 A[2][3];
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int pl = 0; pl < 3; pl++)
+                        A[j][pl] = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const uint32_t *>(stg) + pl * 512 + lm * 16 +
+                                                                     4 * ((2 * j + kh) ^ rd_sw));
+#pragma unroll
+                for (int j = 0; j < 2; j++) {      // small terms first (conv_split.hip's order)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][2], bwb[c][j][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][1], bwb[c][j][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], bwb[c][j][2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][1], bwb[c][j][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], bwb[c][j][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], bwb[c][j][0], acc, 0, 0, 0);
+                }
+            } else {
                 float4 a[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) a[q] = *reinterpret_cast<const float4 *>(stg + lm * HF_SLD + 8 * q + 4 * kh);
@@ -134,40 +220,87 @@ __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bw[c][q].z, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bw[c][q].w, acc, 0, 0, 0);
                 }
-                HF_LDS_EXCHANGE();
             }
+            HF_LDS_EXCHANGE();
+            // nothing of the next chunk moves up here: hipcc otherwise hoists the GroupNorm FMAs of ALL later chunks between this
+            // chunk's MFMAs and waits for loads issued one chunk ago (vmcnt(4)) -- the one-tile read-ahead above would be void
+            __builtin_amdgcn_sched_barrier(0);
         }
         // D layout of the 32x32 MFMA: register i holds row 8 (i / 4) + 4 kh + (i % 4) (pixel), column lm (tap channel)
         if (lm < NV) {
-            const int s = s_lo + t / tpr, x0 = (t - (t / tpr) * tpr) * 32;
-            float *dst = P + ((int64_t)s * W + x0) * NV + lm;
+            const int sr = t / tpr, x0 = (t - sr * tpr) * 32;
+            float *dst = P + lm * PL + sr * W + x0 + 4 * kh;
 #pragma unroll
-            for (int i = 0; i < 16; i++) dst[(8 * (i >> 2) + 4 * kh + (i & 3)) * NV] = acc[i];
+            for (int j = 0; j < 4; j++) *reinterpret_cast<float4 *>(dst + 8 * j) = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
         }
+        t += 8;
+        if (t >= ntile) break;
     }
-    __syncthreads();
-
-    // ---- phase B: 9-point gather from LDS + the reverse update (k_head_gather's arithmetic, bit for bit)
+    // ---- phase B: 9-point gather from LDS + the reverse update (k_head_gather's arithmetic, tap by tap in its order; taps outside
+    // the picture add a literal zero where k_head_gather adds the zero its padded P holds).  An item = (channel, row, 4 pixels); at
+    // most two per thread (head_fused_ok).  The state quads are requested BEFORE the barrier: the waves that finish their tiles first
+    // wait there anyway.
     const int nq = W >> 2, per_co = TH * nq, nitem = COUT * per_co;
     const int64_t D = (int64_t)COUT * HW;
-    for (int it = tid; it < nitem; it += HF_NT) {
-        const int co = it / per_co, rq = it - co * per_co, r = rq / nq, q = rq - r * nq;
+    const HeadUpdate &u = p.u;
+    int64_t e0k[2];
+    int cok[2], rk[2], qk[2];
+    float4 xk[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int it = tid + k * HF_NT;
+        cok[k] = it / per_co;
+        const int rq = it - cok[k] * per_co;
+        rk[k] = rq / nq;
+        qk[k] = rq - rk[k] * nq;
+        e0k[k] = (int64_t)cok[k] * HW + (int64_t)(y0 + rk[k]) * W + 4 * qk[k];
+        if (u.x && it < nitem) xk[k] = *reinterpret_cast<const float4 *>(u.x + (int64_t)b * D + e0k[k]);
+    }
+#ifdef DLPM_PHASE_TIMING
+    _c2 = clock64();
+#endif
+    __syncthreads();
+#ifdef DLPM_PHASE_TIMING
+    _c3 = clock64();
+#endif
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int it = tid + k * HF_NT;
+        if (it >= nitem) break;
+        const int co = cok[k], r = rk[k], q = qk[k];
         const float bv = p.bias ? p.bias[co] : 0.f;
         float acc[4] = {bv, bv, bv, bv};
+        float4 Q[3][3];
 #pragma unroll
-        for (int ky = 0; ky < 3; ky++)
+        for (int ky = 0; ky < 3; ky++) {
+            const int s = r + ky;                                              // slot of image row y0 + r + ky - 1
+            const int sc = min(max(s, s_lo), s_hi - 1) - s_lo;
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) Q[ky][kx] = *reinterpret_cast<const float4 *>(P + ((ky * 3 + kx) * COUT + co) * PL + sc * W + 4 * q);
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+            const int s = r + ky;
+            const bool inb = s >= s_lo && s < s_hi;
 #pragma unroll
             for (int kx = 0; kx < 3; kx++) {
-                const float *srow = P + ((int64_t)(r + ky) * W) * NV + (ky * 3 + kx) * COUT + co;
-#pragma unroll
-                for (int px = 0; px < 4; px++) {
-                    const int ix = 4 * q + px + kx - 1;
-                    if (ix >= 0 && ix < W) acc[px] += srow[ix * NV];
+                float4 v = Q[ky][kx];
+                if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kx == 0) {         // pixels 4 q - 1 .. 4 q + 2: the left neighbour's last value comes over the lanes (items of a row are adjacent lanes)
+                    float l = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.w), 0x111, 0xf, 0xf, true));   // row_shr:1
+                    if (q == 0) l = 0.f;
+                    acc[0] += l; acc[1] += v.x; acc[2] += v.y; acc[3] += v.z;
+                } else if (kx == 1) {
+                    acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+                } else {               // pixels 4 q + 1 .. 4 q + 4
+                    float rr = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.x), 0x101, 0xf, 0xf, true));  // row_shl:1
+                    if (q == nq - 1) rr = 0.f;
+                    acc[0] += v.y; acc[1] += v.z; acc[2] += v.w; acc[3] += rr;
                 }
             }
+        }
         const int64_t pix = (int64_t)(y0 + r) * W + 4 * q;
-        const int64_t e0 = (int64_t)co * HW + pix;
-        const HeadUpdate &u = p.u;
+        const int64_t e0 = e0k[k];
         if (u.x) {
             const int tt = *u.t;
             const float g = u.g[tt], rg = 1.0f / g;
@@ -176,7 +309,7 @@ __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
             const uint64_t gidx = (uint64_t)((u.key ? (int64_t)u.key[1] : u.sample_offset) + b);
             float *hr = u.hist_pp ? *u.hist_pp : nullptr;
             if (hr) hr += ((int64_t)(u.T - tt) * u.B + b) * D;
-            const float4 x = *reinterpret_cast<const float4 *>(u.x + (int64_t)b * D + e0);
+            const float4 x = xk[k];
             float4 z;
             if (u.z) z = *reinterpret_cast<const float4 *>(u.z + (int64_t)b * D + e0);
             else z = (cn != 0.0f) ? philox_normal4(seed, gidx, (uint32_t)(e0 >> 2), kPurposeStepZ, (uint32_t)tt) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -195,6 +328,21 @@ __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
             for (int px = 0; px < 4; px++) p.out[((int64_t)b * HW + pix + px) * COUT + co] = acc[px];
         }
     }
+#ifdef DLPM_PHASE_TIMING
+    if (p.phase && lane == 0) {
+        atomicAdd(p.phase + 16 + wave, (unsigned long long)(_c3 - _c2));
+        if (wave == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const long long _c4 = clock64();
+            atomicAdd(p.phase + 0, (unsigned long long)(_c1 - _c0));
+            atomicAdd(p.phase + 1, (unsigned long long)(_c2 - _c1));
+            atomicAdd(p.phase + 2, (unsigned long long)(_c4 - _c2));
+            atomicAdd(p.phase + 3, 1ull);
+            atomicAdd(p.phase + 12, (unsigned long long)(_c4 - _c0));
+            atomicAdd(p.phase + 13, (unsigned long long)(wall_clock64() - _r0));
+        }
+    }
+#endif
 }
 
 // OIHW (3x3, Cout <= 3) -> W' fragments [C/32][4 q][lane][e]: lane (n = lane % 32, kh = lane / 32) holds W'[ci = 32 c + 8 q + 4 kh + e][n],
@@ -208,9 +356,36 @@ __global__ void k_relayout_weight_head_fused(const float *oihw, float *dst, int 
     dst[i] = n < 9 * Cout ? oihw[((int64_t)co * Cin + ci) * 9 + tap] : 0.f;
 }
 
+// ... -> the bf16 planes [C/32][2 j][3 planes][lane][8]: lane (n, g = lane / 32) holds W'[ci = 32 c + 16 j + 8 g + e][n], e < 8
+__global__ void k_relayout_weight_head_fused_bf(const float *oihw, uint4 *dst, int Cout, int Cin) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;        // one thread per (c, j, lane)
+    if (i >= (Cin / 32) * 2 * 64) return;
+    const int lane = i & 63, j = (i >> 6) & 1, c = i >> 7;
+    const int n = lane & 31, g = lane >> 5, ci0 = 32 * c + 16 * j + 8 * g;
+    const int tap = n / Cout, co = n - tap * Cout;
+    float w[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) w[e] = n < 9 * Cout ? oihw[((int64_t)co * Cin + ci0 + e) * 9 + tap] : 0.f;
+    uint32_t P[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) hf_split2(w[2 * e], w[2 * e + 1], P[0][e], P[1][e], P[2][e]);
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) dst[((c * 2 + j) * 3 + pl) * 64 + lane] = make_uint4(P[pl][0], P[pl][1], P[pl][2], P[pl][3]);
+}
+
+bool head_fused_bf(const ConvLaunch &c) {     // which matrix pipe: bf16 x 3 unless the fp32 GEMM policy (or DLPM_HEAD_F32=1) asks otherwise
+    static int f32 = -1;
+    if (f32 < 0) { const char *e = getenv("DLPM_HEAD_F32"); f32 = (e && e[0] == '1') ? 1 : 0; }
+    return !f32 && c.gemm != DLPM_GEMM_F32;
+}
+
+size_t head_fused_lds_floats(const ConvLaunch &c, int th) {
+    return (size_t)9 * c.Cout * (hf_rows_kept(c.Hout, th) * c.Wout + 4) + 8 * (head_fused_bf(c) ? HF_STG_BF : HF_STG_F32);
+}
+
 int head_fused_rows(const ConvLaunch &c) {   // output rows per workgroup: the whole image when its P image fits beside the transpose patches
     int th = c.Hout;
-    while (th > 1 && ((size_t)(th + 2) * c.Wout * 9 * c.Cout + 8 * 32 * HF_SLD + 8) * sizeof(float) > 160 * 1024) th >>= 1;
+    while (th > 1 && head_fused_lds_floats(c, th) * sizeof(float) > 160 * 1024) th >>= 1;
     return th;
 }
 
@@ -223,13 +398,16 @@ bool head_fused_ok(const ConvLaunch &c) {
     if (c.Cout < 1 || c.Cout > 3 || c.C0 % 32 != 0 || c.C0 > 32 * HF_MAXCH || c.Hin != c.Hout || c.Win != c.Wout) return false;
     if ((c.Wout & 31) || c.Wout > 64 || c.Hout < 4) return false;
     const int th = head_fused_rows(c);
-    return th >= 4 && c.Hout % th == 0;
+    return th >= 4 && c.Hout % th == 0 && c.Cout * th * (c.Wout >> 2) <= 2 * HF_NT;   // (two gather items per thread)
 }
 
-int64_t head_fused_weight_floats(int Cin) { return (int64_t)Cin * 32; }
+int64_t head_fused_weight_floats(int Cin) { return (int64_t)Cin * 32 + (int64_t)Cin * 48; }   // fp32 fragments + three bf16 planes
 
 int relayout_weight_head_fused(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st) {
     k_relayout_weight_head_fused<<<(unsigned)ceil_div(Cin * 32, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
+    DLPM_LAUNCH_CHECK();
+    k_relayout_weight_head_fused_bf<<<(unsigned)ceil_div((Cin / 32) * 128, 128), 128, 0, st>>>(
+        oihw_dev, reinterpret_cast<uint4 *>(dst_dev + (int64_t)Cin * 32), Cout, Cin);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }
@@ -239,17 +417,26 @@ int launch_conv_head_fused(const ConvLaunch &c, const HeadUpdate *hu, hipStream_
     a.h = c.src0; a.coefA = c.coefA; a.coefB = c.coefB; a.wf = c.w_hfused; a.bias = c.bias; a.out = c.out; a.out_nchw = c.out_nchw;
     a.B = c.B; a.H = c.Hout; a.W = c.Wout; a.C = c.C0; a.TH = head_fused_rows(c);
     if (hu) a.u = *hu;
+#ifdef DLPM_PHASE_TIMING
+    a.phase = phase_buffer();
+#endif
     const int64_t M = (int64_t)c.B * c.Hout * c.Wout;
     // algorithmic bytes: the head's input once + the state read and written (or eps written)
     const double bytes = 4.0 * ((double)M * c.C0 + (double)M * c.Cout * (hu ? 2 + (hu->z ? 1 : 0) + (hu->eps_out ? 1 : 0) : 1));
     ProfScope ps(hu ? "head_fused+update" : "head_fused", 2.0 * M * c.Cout * 9.0 * c.C0, bytes, st);
-    const size_t lds = ((size_t)(((a.TH + 2) * a.W * 9 * c.Cout + 3) & ~3) + 8 * 32 * HF_SLD) * sizeof(float);
+    const size_t lds = head_fused_lds_floats(c, a.TH) * sizeof(float);
+    const bool bf = head_fused_bf(c);
     const unsigned grid = (unsigned)(c.B * (c.Hout / a.TH));
+#define DLPM_HF1(CO, NCH, BFV)                                                                            \
+    do {                                                                                                  \
+        int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_head_fused<CO, NCH, BFV>), 160 * 1024); \
+        if (r != DLPM_OK) return r;                                                                       \
+        k_head_fused<CO, NCH, BFV><<<grid, HF_NT, lds, st>>>(a);                                          \
+    } while (0)
 #define DLPM_HF(CO, NCH)                                                                                  \
     do {                                                                                                  \
-        int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_head_fused<CO, NCH>), 160 * 1024);   \
-        if (r != DLPM_OK) return r;                                                                       \
-        k_head_fused<CO, NCH><<<grid, HF_NT, lds, st>>>(a);                                               \
+        if (bf) DLPM_HF1(CO, NCH, true);                                                                  \
+        else DLPM_HF1(CO, NCH, false);                                                                    \
     } while (0)
 #define DLPM_HFC(CO)                                                                                      \
     do {                                                                                                  \
@@ -265,6 +452,7 @@ int launch_conv_head_fused(const ConvLaunch &c, const HeadUpdate *hu, hipStream_
     else DLPM_HFC(3);
 #undef DLPM_HFC
 #undef DLPM_HF
+#undef DLPM_HF1
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }

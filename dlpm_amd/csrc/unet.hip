@@ -1133,6 +1133,7 @@ extern "C" int dlpm_conv2d_f32(const dlpm_conv_args *a, float *scratch_dev, dlpm
     if ((a->force_direct & 64) && a->ksize == 3 && a->Cout <= 3 && a->C0 % 32 == 0 && a->C1 == 0) {
         // bit 64: the one-pass head kernel (head_fused.hip; in the UNet it also carries the sampler's update): W' fragments in scratch
         L.w_hfused = scratch_dev;
+        L.gemm = (a->force_direct & 128) ? DLPM_GEMM_F32 : DLPM_GEMM_AUTO;   // bit 128: its fp32-MFMA form instead of the bf16 x 3 one
         if (a->scratch_floats >= head_fused_weight_floats(a->C0) && head_fused_ok(L)) {
             TRY(relayout_weight_head_fused(a->weight, scratch_dev, a->Cout, a->C0, st));
             return launch_conv_head_fused(L, nullptr, st);

@@ -414,7 +414,9 @@ typedef struct dlpm_conv_args {
                                    Winograd F(4x4,3x3) kernel where the shape qualifies (needs scratch for it);
                                    bit 4: 1x1, or 3x3 as an implicit GEMM, through the bf16-split kernel where the shape
                                    qualifies (scratch: + 1.5x weight); bit 5: the head (Cout <= 3) as a 1x1 GEMM onto its tap
-                                   channels + gather; bit 6: the head as the one-pass kernel (tap channels stay in LDS) */
+                                   channels + gather; bit 6: the head as the one-pass kernel (tap channels stay in LDS; scratch >= 80 Cin
+                                   floats), on the bf16 matrix pipe with the exact three-plane split; bit 7: with bit 6, on the
+                                   fp32 MFMA */
     int64_t scratch_floats;     /* size of scratch_dev in floats; room for a second, fragment-ordered copy of a
                                    3x3 weight (+1 KB per 32 output channels) enables the weight-streaming kernel */
 } dlpm_conv_args;

@@ -351,11 +351,15 @@ def test_head_conv_as_gemm_plus_gather(B, C, H, Cout, nchw):
     e_new, e_old = (got - want).abs().max().item(), (old - want).abs().max().item()
     print('head %dx%d C%d -> %d: GEMM + gather err %.2e, VALU kernel err %.2e, tol %.2e' % (H, H, C, Cout, e_new, e_old, conv_tol(w, C)))
     if H % 32 == 0 and C <= 128:
-        # round 4: the ONE-PASS head kernel (force_direct bit 64; head_fused.hip): the tap channels never leave the CU
+        # round 4: the ONE-PASS head kernel (force_direct bit 64; head_fused.hip): the tap channels never leave the CU.  Its default
+        # form runs the GEMM on the bf16 pipe (exact three-plane split, six products); bit 128 keeps it on the fp32 MFMA
+        extra = max(extra, 80 * C + 4096)
         one = run_conv(h, w, b, coef=coef, silu=True, out_nchw=nchw, force_direct=64, scratch_extra=extra)
-        e_one = (one - want).abs().max().item()
-        print('    one-pass head kernel err %.2e' % e_one)
-        assert e_one < conv_tol(w, C)
+        one32 = run_conv(h, w, b, coef=coef, silu=True, out_nchw=nchw, force_direct=64 | 128, scratch_extra=extra)
+        e_one, e_one32 = (one - want).abs().max().item(), (one32 - want).abs().max().item()
+        print('    one-pass head kernel err %.2e (bf16 x 3), %.2e (fp32 MFMA)' % (e_one, e_one32))
+        assert e_one < conv_tol(w, C) and e_one32 < conv_tol(w, C)
+        assert e_one <= 1.5 * e_one32 + 1e-7              # the split is exact to 2^-24 per product: no worse than the fp32 form
     assert e_new < conv_tol(w, C) and e_old < conv_tol(w, C)
     got2 = run_conv(h, w, None, out_nchw=nchw, force_direct=32, scratch_extra=extra)       # no activation, no bias
     assert (got2 - ref_conv(h, w, None)).abs().max().item() < conv_tol(w, C)

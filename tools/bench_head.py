@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """The head convolution at the CIFAR step's shape ([1024, 32, 32, 128] -> 3 channels, fused GroupNorm affine + SiLU) through its three
-forms (developer tool): the one-pass kernel (head_fused.hip, force_direct bit 64), the GEMM + gather pair (bit 32), the VALU kernel.
+forms (developer tool): the one-pass kernel (head_fused.hip, force_direct bit 64: bf16 x 3; bits 64 | 128: fp32 MFMA), the GEMM + gather
+pair (bit 32), the VALU kernel.
 
-    python tools/bench_head.py [--reps N] [--only fused|pair|valu] [--B 1024] [--H 32] [--C 128]
+    python tools/bench_head.py [--reps N] [--only fused|fused32|pair|valu] [--B 1024] [--H 32] [--C 128]
 
 ms per launch from the library's own HIP events (dlpm_prof_enable); the per-call weight relayout is a separate class."""
 import argparse
@@ -30,7 +31,7 @@ cA, cB = torch.rand(B, Cc, device=DEV) + 0.5, torch.randn(B, Cc, device=DEV) * 0
 out = torch.empty(B, Cout, H, H, device=DEV)
 scratch = torch.empty(64 * Cc + B * H * H * 32 + 9 * Cc * 8 + 4096, device=DEV)
 st = _lib.stream_ptr()
-for name, bits in (('fused', 64), ('pair', 32), ('valu', 0)):
+for name, bits in (('fused', 64), ('fused32', 64 | 128), ('pair', 32), ('valu', 0)):
     if args.only and args.only != name:
         continue
     a = _lib.ConvArgs()
@@ -43,6 +44,13 @@ for name, bits in (('fused', 64), ('pair', 32), ('valu', 0)):
     _lib.check(L.dlpm_prof_enable(1))
     for _ in range(args.reps):
         _lib.check(L.dlpm_conv2d_f32(C.byref(a), scratch.data_ptr(), st))
+    if hasattr(L, 'dlpm_debug_phases') and name.startswith('fused'):     # DLPM_PHASE_TIMING build: where a workgroup's life goes
+        ph = (C.c_ulonglong * 32)()
+        L.dlpm_debug_phases.argtypes = [C.POINTER(C.c_ulonglong * 32)]
+        _lib.check(L.dlpm_debug_phases(C.byref(ph)))
+        n = max(ph[3], 1)
+        print('%-6s cycles per workgroup (wave 0): prologue %.0f  tile loop %.0f  barrier + gather %.0f;  barrier wait by wave: %s;  clock %.0f MHz'
+              % (name, ph[0] / n, ph[1] / n, ph[2] / n, ' '.join('%.0f' % (ph[16 + w] / n) for w in range(8)), 100.0 * ph[12] / max(ph[13], 1)))
     buf = C.create_string_buffer(1 << 16)
     _lib.check(L.dlpm_prof_report(buf, len(buf)))
     _lib.check(L.dlpm_prof_enable(0))
