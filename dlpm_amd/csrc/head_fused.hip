@@ -26,6 +26,7 @@
 // the vector lanes; the bf16 one runs beside the VALU).  The transpose patch holds [plane][pixel][32 channels] bf16 with the 16-byte
 // units of a pixel row XOR-swizzled by (pixel >> 1) & 3 (no padding: P + the patches fill the 160 KB).
 #include "conv.h"
+#include <type_traits>
 #include "philox.h"
 
 namespace dlpm {
@@ -72,6 +73,15 @@ __device__ __forceinline__ f32x2 hf_act2(f32x2 x, f32x2 a, f32x2 b) {
 // rows of P a workgroup keeps: its TH output rows + the halo rows that lie inside the picture
 __host__ __device__ __forceinline__ int hf_rows_kept(int H, int TH) { return H == TH ? TH : (H == 2 * TH ? TH + 1 : TH + 2); }
 
+// workgroup barrier that orders LDS only: __syncthreads() is a workgroup-scope fence over ALL address spaces, i.e. s_waitcnt vmcnt(0) --
+// every wave would sit out the write acknowledgements of its update stores and the landing of its prefetch at each barrier
+#define HF_LDS_BARRIER()                                              \
+    do {                                                              \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); \
+        __builtin_amdgcn_s_barrier();                                 \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); \
+    } while (0)
+
 struct HeadFusedArgs {
     const float *h;               // [B][H][W][C] NHWC
     const float *coefA, *coefB;   // [B][C] GroupNorm affine (SiLU follows)
@@ -86,34 +96,115 @@ struct HeadFusedArgs {
 #endif
 };
 
+// One tile of a wave (expanded twice in the kernel: the tiles of a band that have a successor in it, and the band's last one).
+// step(c, NEXT): chunk c's A fragments out of the patch, then its MFMAs next to the staging of the wave's next chunk (NEXT: 1 = chunk
+// c + 1 of this tile, 2 = chunk 0 of the next tile, 0 = none: the band's last step).  Wave-private exchanges: LDS operations of one wave
+// execute in order; the LDS-only fences keep the compiler from moving them (a plain wavefront fence also drains the GLOBAL loads in
+// flight: the prefetch).  The sched_barrier at the end of a step: nothing of a later step moves up -- hipcc otherwise hoists the
+// GroupNorm FMAs of ALL later chunks between this chunk's MFMAs and waits for loads issued one chunk ago.  ns = the tile after t
+// (chunks 1.. are reloaded from it), ns2 = the one after that (chunk 0).  D layout of the 32x32 MFMA: register i holds row
+// 8 (i / 4) + 4 kh + (i % 4) (pixel), column lm (tap channel).  (A macro, not a lambda: called twice, a lambda is not inlined before
+// SROA and every register array of the kernel lands in scratch.)
+#define HF_TILE(LASTV)                                                                                  \
+    do {                                                                                                \
+        constexpr bool last = LASTV;                                                                    \
+            floatx16 acc; \
+_Pragma("unroll") \
+            for (int r = 0; r < 16; r++) acc[r] = 0.f; \
+            const float *ns = !last ? tile_src(wg, t + 8) : (more ? tile_src(wgn, wave) : p.wf + 4 * lc); \
+            const float *ns2 = t + 16 < ntile ? tile_src(wg, t + 16) \
+                                              : (more ? tile_src(wgn, !last ? wave : wave + 8) : p.wf + 4 * lc); \
+            auto step = [&](auto cc, auto nn) __attribute__((always_inline)) { \
+                constexpr int c = decltype(cc)::value, NEXT = decltype(nn)::value; \
+                if constexpr (BF) { \
+                    bf16x8 A[2][3]; \
+_Pragma("unroll") \
+                    for (int j = 0; j < 2; j++) \
+_Pragma("unroll") \
+                        for (int pl = 0; pl < 3; pl++) \
+                            A[j][pl] = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const uint32_t *>(stg) + pl * 512 + lm * 16 + \
+                                                                         4 * ((2 * j + kh) ^ rd_sw)); \
+                    HF_LDS_EXCHANGE(); \
+                    if constexpr (NEXT == 1) { stage(c + 1); load_chunk(ns, c + 1); } \
+                    if constexpr (NEXT == 2) { stage(0); load_chunk(ns2, 0); } \
+_Pragma("unroll") \
+                    for (int j = 0; j < 2; j++) { \
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][2], bwb[c][j][0], acc, 0, 0, 0); \
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][1], bwb[c][j][1], acc, 0, 0, 0); \
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], bwb[c][j][2], acc, 0, 0, 0); \
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][1], bwb[c][j][0], acc, 0, 0, 0); \
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], bwb[c][j][1], acc, 0, 0, 0); \
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], bwb[c][j][0], acc, 0, 0, 0); \
+                    } \
+                } else { \
+                    float4 a[4]; \
+_Pragma("unroll") \
+                    for (int q = 0; q < 4; q++) a[q] = *reinterpret_cast<const float4 *>(stg + lm * HF_SLD + 8 * q + 4 * kh); \
+                    HF_LDS_EXCHANGE(); \
+                    if constexpr (NEXT == 1) { stage(c + 1); load_chunk(ns, c + 1); } \
+                    if constexpr (NEXT == 2) { stage(0); load_chunk(ns2, 0); } \
+_Pragma("unroll") \
+                    for (int q = 0; q < 4; q++) { \
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bw[c][q].x, acc, 0, 0, 0); \
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bw[c][q].y, acc, 0, 0, 0); \
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bw[c][q].z, acc, 0, 0, 0); \
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bw[c][q].w, acc, 0, 0, 0); \
+                    } \
+                } \
+                HF_LDS_EXCHANGE(); \
+                __builtin_amdgcn_sched_barrier(0); \
+            }; \
+            auto store_tile = [&]() __attribute__((always_inline)) { \
+                if (lm < NV) { \
+                    const int sr = t / tpr, x0 = (t - sr * tpr) * 32; \
+                    float *dst = P + lm * PL + sr * W + x0 + 4 * kh; \
+_Pragma("unroll") \
+                    for (int j = 0; j < 4; j++) \
+                        *reinterpret_cast<float4 *>(dst + 8 * j) = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]); \
+                } \
+            }; \
+            if constexpr (NCH > 1) step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); \
+            if constexpr (NCH > 2) step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}); \
+            if constexpr (NCH > 3) step(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}); \
+            step(std::integral_constant<int, NCH - 1>{}, std::integral_constant<int, last ? 0 : 2>{}); \
+            store_tile(); \
+    } while (0)
+
 // NCH = C / 32 K chunks, a compile-time constant: with a run-time bound the chunk loop's loads sit inside (uniform) branches and hipcc
 // drains them at every join (s_waitcnt vmcnt(0)).
+//
+// PERSISTENT: the grid is one workgroup per CU and a workgroup walks the bands wg = blockIdx.x, + gridDim.x, ...: W' is fetched once
+// (all 256 CUs pulling the same 24 KB four times over was 10 k of a band's 75 k cycles), and the next band's coefficients and first
+// tile are requested before the barrier, so HBM keeps streaming while the gather runs.
+// PIPELINED: step (t, c) of a wave = read chunk c's A fragments from the patch, then MFMAs(c) next to stage(c + 1) -- SiLU + split of the
+// NEXT chunk into the patch -- in one scheduling region: the bf16 MFMA runs beside the VALU, and a wave alone on its SIMD (the
+// older wave of a SIMD finishes its tiles first) keeps both busy.
 template <int COUT, int NCH, bool BF>
 __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
-    constexpr int NV = 9 * COUT;                       // live tap channels (27), also the LDS pitch of P (odd: bank spread)
+    constexpr int NV = 9 * COUT;                       // live tap channels (27)
+    constexpr int C = 32 * NCH;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W = p.W, H = p.H, TH = p.TH;
-    constexpr int C = 32 * NCH;
-#ifdef DLPM_PHASE_TIMING
-    const long long _c0 = clock64(), _r0 = wall_clock64();
-    long long _c1 = _c0, _c2 = _c0, _c3 = _c0;
-#endif
-    const int bands = H / TH, b = blockIdx.x / bands, y0 = (blockIdx.x - b * bands) * TH;
-    // row slots of P: image rows y0 - 1 .. y0 + TH, of which only those inside the picture are kept (s_lo .. s_hi - 1)
-    const int s_lo = y0 == 0 ? 1 : 0, s_hi = (y0 + TH == H) ? TH + 1 : TH + 2;
+    const int bands = H / TH, nwg = p.B * bands, G = gridDim.x;
     // P as NV planes [row s - s_lo][W] of pitch PL = rows W + 4 floats: a lane's four consecutive pixels are one 16-byte LDS access on
     // both sides (MFMA registers 4 j .. 4 j + 3 in; a gather item's pixel quad out), the + 4 spreads the 27 lanes of a store over the banks
     const int PL = hf_rows_kept(H, TH) * W + 4;
     float *P = sm;
     float *stg = sm + NV * PL + wave * (BF ? HF_STG_BF : HF_STG_F32);
+    float *cf = sm + NV * PL + 8 * (BF ? HF_STG_BF : HF_STG_F32);   // [2][C] GroupNorm affine of the band's image (registers are short)
     const int tpr = W >> 5;                            // 32-pixel tiles per row
     const int64_t HW = (int64_t)H * W;
+    const int lp = lane >> 3, lc = lane & 7;           // load role: pixel 8 i + lp, channels 4 lc .. 4 lc + 3 of the chunk
+    const int lm = lane & 31, kh = lane >> 5;          // MFMA role: pixel lm, k slot kh
+    // bf16 form, dword offsets into the wave's patch: a pixel row is 16 dwords = four 16-byte units (8 channels each), unit u of pixel
+    // px sits at slot u ^ ((px >> 1) & 3) -- the 8 lanes of a b128 read phase (8 consecutive pixels, same u) then cover all 32 banks
+    const int wr_off = lp * 16 + 4 * ((lc >> 1) ^ ((lp >> 1) & 3)) + 2 * (lc & 1);      // + plane 512 + i 128
+    const int rd_sw = (lm >> 1) & 3;                                                      // unit 2 j + kh -> slot ^ rd_sw
 
-    // ---- W' fragments and this image's GroupNorm coefficients: registers for the whole kernel
+    // ---- W' fragments: registers for the whole kernel
     float4 bw[BF ? 1 : NCH][4];
     bf16x8 bwb[BF ? NCH : 1][2][3];
-    float4 cA[NCH], cB[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
         if constexpr (BF) {
@@ -126,223 +217,215 @@ __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
 #pragma unroll
             for (int q = 0; q < 4; q++) bw[c][q] = reinterpret_cast<const float4 *>(p.wf)[(c * 4 + q) * 64 + lane];
         }
-        cA[c] = *reinterpret_cast<const float4 *>(p.coefA + (int64_t)b * C + 32 * c + 4 * (lane & 7));
-        cB[c] = *reinterpret_cast<const float4 *>(p.coefB + (int64_t)b * C + 32 * c + 4 * (lane & 7));
     }
 
-    // ---- phase A: the band's rows as 32-pixel tiles, round-robin over the waves
-    const int ntile = (s_hi - s_lo) * tpr;
-    const int lp = lane >> 3, lc = lane & 7;           // load role: pixel 8 i + lp, channels 4 lc .. 4 lc + 3 of the chunk
-    const int lm = lane & 31, kh = lane >> 5;          // MFMA role: pixel lm, k slot kh
-    auto tile_src = [&](int t) {
-        const int s = s_lo + t / tpr, x0 = (t - (t / tpr) * tpr) * 32;
+    // band geometry: image b, first output row y0; row slots of P are image rows y0 - 1 .. y0 + TH, of which only those inside the
+    // picture are kept (s_lo .. s_hi - 1)
+    auto band_y0 = [&](int wg) __attribute__((always_inline)) { return (wg - (wg / bands) * bands) * TH; };
+    auto tile_src = [&](int wg, int t) __attribute__((always_inline)) {               // tile t of band wg: 32 pixels of one row, this lane's channel quad of chunk 0
+        const int b = wg / bands, y0 = band_y0(wg), s = (y0 == 0 ? 1 : 0) + t / tpr, x0 = (t - (t / tpr) * tpr) * 32;
         return p.h + (((int64_t)b * H + (y0 - 1 + s)) * W + x0) * C + 4 * lc;
     };
-    // bf16 form, dword offsets into the wave's patch: a pixel row is 16 dwords = four 16-byte units (8 channels each), unit u of pixel
-    // px sits at slot u ^ ((px >> 1) & 3) -- the 8 lanes of a b128 read phase (8 consecutive pixels, same u) then cover all 32 banks
-    const int wr_off = lp * 16 + 4 * ((lc >> 1) ^ ((lp >> 1) & 3)) + 2 * (lc & 1);      // + plane 512 + i 128
-    const int rd_sw = (lm >> 1) & 3;                                                      // unit 2 j + kh -> slot ^ rd_sw
     // Input chunks travel ONE TILE ahead: buffer c holds chunk c of the tile being worked on and is reloaded with chunk c of the
-    // wave's next tile as soon as it has been consumed (16 KB per wave, ~32 MB per chip in flight: what 5 TB/s x the loaded HBM
-    // latency needs).
+    // wave's next tile as soon as it has been staged (16 KB per wave in flight).
     float4 xb[NCH][4];
-    if (wave < ntile) {
-        const float *src = tile_src(wave);
+    auto load_chunk = [&](const float *src, int c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int c = 0; c < NCH; c++) {
+        for (int i = 0; i < 4; i++) xb[c][i] = *reinterpret_cast<const float4 *>(src + 32 * c + (int64_t)(8 * i + lp) * C);
+    };
+    // the image's coefficients: threads 0 .. C / 2 - 1 fetch one float4 each (A then B) ...
+    auto fetch_coefs = [&](int wg) __attribute__((always_inline)) {
+        const int b = wg / bands;
+        const float *src = tid < C / 4 ? p.coefA + (int64_t)b * C + 4 * tid : p.coefB + (int64_t)b * C + 4 * (tid - C / 4);
+        return tid < C / 2 ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    // ... and drop it into LDS once nobody reads the previous image's any more (after the band's first barrier)
+    auto put_coefs = [&](float4 v) __attribute__((always_inline)) {
+        if (tid < C / 2) *reinterpret_cast<float4 *>(cf + 4 * tid) = v;
+    };
+    // stage(c): GroupNorm affine + SiLU (+ the three-plane split) of buffer c into the wave's patch
+    auto stage = [&](int c) __attribute__((always_inline)) {
+        const float4 cA = *reinterpret_cast<const float4 *>(cf + 32 * c + 4 * lc), cB = *reinterpret_cast<const float4 *>(cf + C + 32 * c + 4 * lc);
+        const f32x2 a01 = {cA.x, cA.y}, a23 = {cA.z, cA.w}, b01 = {cB.x, cB.y}, b23 = {cB.z, cB.w};
 #pragma unroll
-            for (int i = 0; i < 4; i++) xb[c][i] = *reinterpret_cast<const float4 *>(src + 32 * c + (int64_t)(8 * i + lp) * C);
-            // chunk order, as the loop reloads them: the loop's vmcnt waits are the merge of both entry paths, and hipcc sorts
-            // these 16 loads by address otherwise (vmcnt(5) at the loop top = waiting for loads issued one chunk ago)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    // (the loop sits behind the same condition as those loads, as a do-while: were its header reachable without them, the static
-    // vmcnt at its top would be the one that path needs for the coefficient loads above -- vmcnt(5), on every iteration)
-#ifdef DLPM_PHASE_TIMING
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the prologue's loads have landed: phase 0 ends here)
-    _c1 = clock64();
-#endif
-    if (wave < ntile) for (int t = wave;;) {
-        floatx16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = 0.f;
-        const float *nsrc = tile_src(t + 8 < ntile ? t + 8 : t);        // (the last tile reloads itself: unconditional loads)
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            const f32x2 a01 = {cA[c].x, cA[c].y}, a23 = {cA[c].z, cA[c].w}, b01 = {cB[c].x, cB[c].y}, b23 = {cB[c].z, cB[c].w};
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const float4 xr = xb[c][i];
-                const f32x2 v01 = hf_act2(f32x2{xr.x, xr.y}, a01, b01), v23 = hf_act2(f32x2{xr.z, xr.w}, a23, b23);
-                if constexpr (BF) {
-                    uint32_t q0[2], q1[2], q2[2];
-                    hf_split2(v01.x, v01.y, q0[0], q1[0], q2[0]);
-                    hf_split2(v23.x, v23.y, q0[1], q1[1], q2[1]);
-                    uint32_t *dst = reinterpret_cast<uint32_t *>(stg) + wr_off + i * 128;
-                    *reinterpret_cast<uint2 *>(dst) = make_uint2(q0[0], q0[1]);
-                    *reinterpret_cast<uint2 *>(dst + 512) = make_uint2(q1[0], q1[1]);
-                    *reinterpret_cast<uint2 *>(dst + 1024) = make_uint2(q2[0], q2[1]);
-                } else {
-                    *reinterpret_cast<float4 *>(stg + (8 * i + lp) * HF_SLD + 4 * lc) = make_float4(v01.x, v01.y, v23.x, v23.y);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) xb[c][i] = *reinterpret_cast<const float4 *>(nsrc + 32 * c + (int64_t)(8 * i + lp) * C);
-            // wave-private exchange: LDS operations of one wave execute in order; the LDS-only fences keep the compiler from
-            // moving them (a plain wavefront fence also drains the GLOBAL loads in flight: the prefetch)
-            HF_LDS_EXCHANGE();
+        for (int i = 0; i < 4; i++) {
+            const float4 xr = xb[c][i];
+            const f32x2 v01 = hf_act2(f32x2{xr.x, xr.y}, a01, b01), v23 = hf_act2(f32x2{xr.z, xr.w}, a23, b23);
             if constexpr (BF) {
-                bf16x8 A[2][3];
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-#pragma unroll
-                    for (int pl = 0; pl < 3; pl++)
-                        A[j][pl] = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const uint32_t *>(stg) + pl * 512 + lm * 16 +
-                                                                     4 * ((2 * j + kh) ^ rd_sw));
-#pragma unroll
-                for (int j = 0; j < 2; j++) {      // small terms first (conv_split.hip's order)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][2], bwb[c][j][0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][1], bwb[c][j][1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], bwb[c][j][2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][1], bwb[c][j][0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], bwb[c][j][1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], bwb[c][j][0], acc, 0, 0, 0);
-                }
+                uint32_t q0[2], q1[2], q2[2];
+                hf_split2(v01.x, v01.y, q0[0], q1[0], q2[0]);
+                hf_split2(v23.x, v23.y, q0[1], q1[1], q2[1]);
+                uint32_t *dst = reinterpret_cast<uint32_t *>(stg) + wr_off + i * 128;
+                *reinterpret_cast<uint2 *>(dst) = make_uint2(q0[0], q0[1]);
+                *reinterpret_cast<uint2 *>(dst + 512) = make_uint2(q1[0], q1[1]);
+                *reinterpret_cast<uint2 *>(dst + 1024) = make_uint2(q2[0], q2[1]);
             } else {
-                float4 a[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) a[q] = *reinterpret_cast<const float4 *>(stg + lm * HF_SLD + 8 * q + 4 * kh);
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bw[c][q].x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bw[c][q].y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bw[c][q].z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bw[c][q].w, acc, 0, 0, 0);
-                }
+                *reinterpret_cast<float4 *>(stg + (8 * i + lp) * HF_SLD + 4 * lc) = make_float4(v01.x, v01.y, v23.x, v23.y);
             }
-            HF_LDS_EXCHANGE();
-            // nothing of the next chunk moves up here: hipcc otherwise hoists the GroupNorm FMAs of ALL later chunks between this
-            // chunk's MFMAs and waits for loads issued one chunk ago (vmcnt(4)) -- the one-tile read-ahead above would be void
-            __builtin_amdgcn_sched_barrier(0);
         }
-        // D layout of the 32x32 MFMA: register i holds row 8 (i / 4) + 4 kh + (i % 4) (pixel), column lm (tap channel)
-        if (lm < NV) {
-            const int sr = t / tpr, x0 = (t - sr * tpr) * 32;
-            float *dst = P + lm * PL + sr * W + x0 + 4 * kh;
-#pragma unroll
-            for (int j = 0; j < 4; j++) *reinterpret_cast<float4 *>(dst + 8 * j) = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
-        }
-        t += 8;
-        if (t >= ntile) break;
-    }
-    // ---- phase B: 9-point gather from LDS + the reverse update (k_head_gather's arithmetic, tap by tap in its order; taps outside
-    // the picture add a literal zero where k_head_gather adds the zero its padded P holds).  An item = (channel, row, 4 pixels); at
-    // most two per thread (head_fused_ok).  The state quads are requested BEFORE the barrier: the waves that finish their tiles first
-    // wait there anyway.
+    };
+
+    const HeadUpdate &u = p.u;
     const int nq = W >> 2, per_co = TH * nq, nitem = COUT * per_co;
     const int64_t D = (int64_t)COUT * HW;
-    const HeadUpdate &u = p.u;
-    int64_t e0k[2];
-    int cok[2], rk[2], qk[2];
-    float4 xk[2];
+    int wg = blockIdx.x;
+    put_coefs(fetch_coefs(wg));
+    {
+        const float *src = tile_src(wg, wave);
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int it = tid + k * HF_NT;
-        cok[k] = it / per_co;
-        const int rq = it - cok[k] * per_co;
-        rk[k] = rq / nq;
-        qk[k] = rq - rk[k] * nq;
-        e0k[k] = (int64_t)cok[k] * HW + (int64_t)(y0 + rk[k]) * W + 4 * qk[k];
-        if (u.x && it < nitem) xk[k] = *reinterpret_cast<const float4 *>(u.x + (int64_t)b * D + e0k[k]);
+        for (int c = 0; c < NCH; c++) {
+            load_chunk(src, c);
+            // chunk order, as the loop reloads them (hipcc sorts these 16 loads by address otherwise, and the loop's static vmcnt
+            // waits are the merge of all entry paths)
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
+    HF_LDS_BARRIER();
+    for (;;) {
 #ifdef DLPM_PHASE_TIMING
-    _c2 = clock64();
+        const long long _c0 = clock64(), _r0 = wall_clock64();
 #endif
-    __syncthreads();
-#ifdef DLPM_PHASE_TIMING
-    _c3 = clock64();
-#endif
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int it = tid + k * HF_NT;
-        if (it >= nitem) break;
-        const int co = cok[k], r = rk[k], q = qk[k];
-        const float bv = p.bias ? p.bias[co] : 0.f;
-        float acc[4] = {bv, bv, bv, bv};
-        float4 Q[3][3];
-#pragma unroll
-        for (int ky = 0; ky < 3; ky++) {
-            const int s = r + ky;                                              // slot of image row y0 + r + ky - 1
-            const int sc = min(max(s, s_lo), s_hi - 1) - s_lo;
-#pragma unroll
-            for (int kx = 0; kx < 3; kx++) Q[ky][kx] = *reinterpret_cast<const float4 *>(P + ((ky * 3 + kx) * COUT + co) * PL + sc * W + 4 * q);
+        const int b = wg / bands, y0 = band_y0(wg);
+        const int s_lo = y0 == 0 ? 1 : 0, s_hi = (y0 + TH == H) ? TH + 1 : TH + 2;
+        const int ntile = (s_hi - s_lo) * tpr;         // >= 8 (head_fused_ok): every wave has a tile
+        const int wgn = wg + G;
+        const bool more = wgn < nwg;
+
+        // ---- phase A: the band's rows as 32-pixel tiles, round-robin over the waves
+        stage(0);
+        {   // (the tile after this one: in this band, else the first of the next band, else a harmless L2-resident address --
+            //  the loads stay unconditional, so that every path into the loop has the same loads in flight)
+            const float *n0 = wave + 8 < ntile ? tile_src(wg, wave + 8) : (more ? tile_src(wgn, wave) : p.wf + 4 * lc);
+            load_chunk(n0, 0);
+        }
+        HF_LDS_EXCHANGE();
+        __builtin_amdgcn_sched_barrier(0);
+        // The band's last tile is its own copy of the code, behind the loop: as a branch inside one copy ("stage chunk 0 of the next
+        // tile unless this is the last"), hipcc's waitcnt pass sees a path around those loads into the loop's back edge and counts every
+        // wait of the loop for it (vmcnt(11) instead of (15): the read-ahead one chunk shorter)
+        int t = wave;
+        for (; t + 8 < ntile; t += 8) HF_TILE(false);
+        HF_TILE(true);
+
+        // ---- phase B: 9-point gather from LDS + the reverse update (k_head_gather's arithmetic, tap by tap in its order; taps outside
+        // the picture add a literal zero where k_head_gather adds the zero its padded P holds).  An item = (channel, row, 4 pixels); at
+        // most two per thread (head_fused_ok).  The state quads and the next band's coefficients are requested BEFORE the barrier: the
+        // waves that finish their tiles first wait there anyway.
+        int64_t e0k[2];
+        int cok[2], rk[2], qk[2];
+        float4 xk[2];
+        float bvk[2];
+        // (recomputed per band behind an opaque copy of the thread index: hoisted out of the band loop as invariants, the item
+        //  coordinates live across the tile loop, i.e. in scratch, and every reload is an s_waitcnt vmcnt(0))
+        int tb = tid;
+        asm volatile("" : "+v"(tb));
+        // the update's per-image scalars, requested here: three dependent loads (t -> g, c_eps, c_noise) otherwise sit behind the barrier
+        int tt = 0;
+        float g = 1.f, rg = 1.f, ce = 0.f, cn = 0.f;
+        uint64_t seed = 0, gidx = 0;
+        float *hr = nullptr;
+        if (u.x) {
+            tt = *u.t;
+            g = u.g[tt];
+            rg = 1.0f / g;
+            ce = u.c_eps[(int64_t)tt * u.B + b];
+            cn = u.c_noise[(int64_t)tt * u.B + b];
+            seed = u.key ? u.key[0] : u.seed;
+            gidx = (uint64_t)((u.key ? (int64_t)u.key[1] : u.sample_offset) + b);
+            hr = u.hist_pp ? *u.hist_pp : nullptr;
+            if (hr) hr += ((int64_t)(u.T - tt) * u.B + b) * D;
         }
 #pragma unroll
-        for (int ky = 0; ky < 3; ky++) {
-            const int s = r + ky;
-            const bool inb = s >= s_lo && s < s_hi;
+        for (int k = 0; k < 2; k++) {
+            const int it = tb + k * HF_NT;
+            cok[k] = it / per_co;
+            const int rq = it - cok[k] * per_co;
+            rk[k] = rq / nq;
+            qk[k] = rq - rk[k] * nq;
+            e0k[k] = (int64_t)cok[k] * HW + (int64_t)(y0 + rk[k]) * W + 4 * qk[k];
+            if (u.x && it < nitem) xk[k] = *reinterpret_cast<const float4 *>(u.x + (int64_t)b * D + e0k[k]);
+            bvk[k] = (p.bias && it < nitem) ? p.bias[cok[k]] : 0.f;
+        }
+        const float4 ncf = fetch_coefs(more ? wgn : wg);
+#ifdef DLPM_PHASE_TIMING
+        const long long _c2 = clock64();
+#endif
+        HF_LDS_BARRIER();
+#ifdef DLPM_PHASE_TIMING
+        const long long _c3 = clock64();
+#endif
+        put_coefs(ncf);
 #pragma unroll
-            for (int kx = 0; kx < 3; kx++) {
-                float4 v = Q[ky][kx];
-                if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kx == 0) {         // pixels 4 q - 1 .. 4 q + 2: the left neighbour's last value comes over the lanes (items of a row are adjacent lanes)
-                    float l = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.w), 0x111, 0xf, 0xf, true));   // row_shr:1
-                    if (q == 0) l = 0.f;
-                    acc[0] += l; acc[1] += v.x; acc[2] += v.y; acc[3] += v.z;
-                } else if (kx == 1) {
-                    acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
-                } else {               // pixels 4 q + 1 .. 4 q + 4
-                    float rr = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.x), 0x101, 0xf, 0xf, true));  // row_shl:1
-                    if (q == nq - 1) rr = 0.f;
-                    acc[0] += v.y; acc[1] += v.z; acc[2] += v.w; acc[3] += rr;
+        for (int k = 0; k < 2; k++) {
+            const int it = tb + k * HF_NT;
+            if (it >= nitem) break;
+            const int co = cok[k], r = rk[k], q = qk[k];
+            const float bv = bvk[k];
+            float acc[4] = {bv, bv, bv, bv};
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++) {
+                const int s = r + ky;                                              // slot of image row y0 + r + ky - 1
+                const int sc = min(max(s, s_lo), s_hi - 1) - s_lo;
+                const bool inb = s >= s_lo && s < s_hi;
+                float4 Q[3];                                                       // (row by row: registers are short here)
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) Q[kx] = *reinterpret_cast<const float4 *>(P + ((ky * 3 + kx) * COUT + co) * PL + sc * W + 4 * q);
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    float4 v = Q[kx];
+                    if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (kx == 0) {         // pixels 4 q - 1 .. 4 q + 2: the left neighbour's last value comes over the lanes (items of a row are adjacent lanes)
+                        float l = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.w), 0x111, 0xf, 0xf, true));   // row_shr:1
+                        if (q == 0) l = 0.f;
+                        acc[0] += l; acc[1] += v.x; acc[2] += v.y; acc[3] += v.z;
+                    } else if (kx == 1) {
+                        acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+                    } else {               // pixels 4 q + 1 .. 4 q + 4
+                        float rr = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.x), 0x101, 0xf, 0xf, true));  // row_shl:1
+                        if (q == nq - 1) rr = 0.f;
+                        acc[0] += v.y; acc[1] += v.z; acc[2] += v.w; acc[3] += rr;
+                    }
                 }
             }
-        }
-        const int64_t pix = (int64_t)(y0 + r) * W + 4 * q;
-        const int64_t e0 = e0k[k];
-        if (u.x) {
-            const int tt = *u.t;
-            const float g = u.g[tt], rg = 1.0f / g;
-            const float ce = u.c_eps[(int64_t)tt * u.B + b], cn = u.c_noise[(int64_t)tt * u.B + b];
-            const uint64_t seed = u.key ? u.key[0] : u.seed;
-            const uint64_t gidx = (uint64_t)((u.key ? (int64_t)u.key[1] : u.sample_offset) + b);
-            float *hr = u.hist_pp ? *u.hist_pp : nullptr;
-            if (hr) hr += ((int64_t)(u.T - tt) * u.B + b) * D;
-            const float4 x = xk[k];
-            float4 z;
-            if (u.z) z = *reinterpret_cast<const float4 *>(u.z + (int64_t)b * D + e0);
-            else z = (cn != 0.0f) ? philox_normal4(seed, gidx, (uint32_t)(e0 >> 2), kPurposeStepZ, (uint32_t)tt) : make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 o;
-            o.x = fmaf(cn, z.x, div_by(x.x - ce * acc[0], g, rg));
-            o.y = fmaf(cn, z.y, div_by(x.y - ce * acc[1], g, rg));
-            o.z = fmaf(cn, z.z, div_by(x.z - ce * acc[2], g, rg));
-            o.w = fmaf(cn, z.w, div_by(x.w - ce * acc[3], g, rg));
-            *reinterpret_cast<float4 *>(u.x + (int64_t)b * D + e0) = o;
-            if (hr) *reinterpret_cast<float4 *>(hr + e0) = o;
-            if (u.eps_out) *reinterpret_cast<float4 *>(u.eps_out + (int64_t)b * D + e0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        } else if (p.out_nchw) {
-            *reinterpret_cast<float4 *>(p.out + (int64_t)b * D + e0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        } else {
+            const int64_t pix = (int64_t)(y0 + r) * W + 4 * q;
+            const int64_t e0 = e0k[k];
+            if (u.x) {
+                const float4 x = xk[k];
+                float4 z;
+                if (u.z) z = *reinterpret_cast<const float4 *>(u.z + (int64_t)b * D + e0);
+                else z = (cn != 0.0f) ? philox_normal4(seed, gidx, (uint32_t)(e0 >> 2), kPurposeStepZ, (uint32_t)tt) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 o;
+                o.x = fmaf(cn, z.x, div_by(x.x - ce * acc[0], g, rg));
+                o.y = fmaf(cn, z.y, div_by(x.y - ce * acc[1], g, rg));
+                o.z = fmaf(cn, z.z, div_by(x.z - ce * acc[2], g, rg));
+                o.w = fmaf(cn, z.w, div_by(x.w - ce * acc[3], g, rg));
+                *reinterpret_cast<float4 *>(u.x + (int64_t)b * D + e0) = o;
+                if (hr) *reinterpret_cast<float4 *>(hr + e0) = o;
+                if (u.eps_out) *reinterpret_cast<float4 *>(u.eps_out + (int64_t)b * D + e0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            } else if (p.out_nchw) {
+                *reinterpret_cast<float4 *>(p.out + (int64_t)b * D + e0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            } else {
 #pragma unroll
-            for (int px = 0; px < 4; px++) p.out[((int64_t)b * HW + pix + px) * COUT + co] = acc[px];
+                for (int px = 0; px < 4; px++) p.out[((int64_t)b * HW + pix + px) * COUT + co] = acc[px];
+            }
         }
-    }
 #ifdef DLPM_PHASE_TIMING
-    if (p.phase && lane == 0) {
-        atomicAdd(p.phase + 16 + wave, (unsigned long long)(_c3 - _c2));
-        if (wave == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const long long _c4 = clock64();
-            atomicAdd(p.phase + 0, (unsigned long long)(_c1 - _c0));
-            atomicAdd(p.phase + 1, (unsigned long long)(_c2 - _c1));
-            atomicAdd(p.phase + 2, (unsigned long long)(_c4 - _c2));
-            atomicAdd(p.phase + 3, 1ull);
-            atomicAdd(p.phase + 12, (unsigned long long)(_c4 - _c0));
-            atomicAdd(p.phase + 13, (unsigned long long)(wall_clock64() - _r0));
+        if (p.phase && lane == 0) {
+            atomicAdd(p.phase + 16 + wave, (unsigned long long)(_c3 - _c2));
+            if (wave == 0) {
+                const long long _c4 = clock64();
+                atomicAdd(p.phase + 1, (unsigned long long)(_c2 - _c0));
+                atomicAdd(p.phase + 2, (unsigned long long)(_c4 - _c2));
+                atomicAdd(p.phase + 3, 1ull);
+                atomicAdd(p.phase + 12, (unsigned long long)(_c4 - _c0));
+                atomicAdd(p.phase + 13, (unsigned long long)(wall_clock64() - _r0));
+            }
         }
-    }
 #endif
+        if (!more) break;
+        HF_LDS_BARRIER();                               // the gather has read P: the next band's tiles may land
+        wg = wgn;
+    }
 }
 
 // OIHW (3x3, Cout <= 3) -> W' fragments [C/32][4 q][lane][e]: lane (n = lane % 32, kh = lane / 32) holds W'[ci = 32 c + 8 q + 4 kh + e][n],
@@ -380,7 +463,7 @@ bool head_fused_bf(const ConvLaunch &c) {     // which matrix pipe: bf16 x 3 unl
 }
 
 size_t head_fused_lds_floats(const ConvLaunch &c, int th) {
-    return (size_t)9 * c.Cout * (hf_rows_kept(c.Hout, th) * c.Wout + 4) + 8 * (head_fused_bf(c) ? HF_STG_BF : HF_STG_F32);
+    return (size_t)9 * c.Cout * (hf_rows_kept(c.Hout, th) * c.Wout + 4) + 8 * (head_fused_bf(c) ? HF_STG_BF : HF_STG_F32) + 2 * c.C0;
 }
 
 int head_fused_rows(const ConvLaunch &c) {   // output rows per workgroup: the whole image when its P image fits beside the transpose patches
@@ -398,7 +481,9 @@ bool head_fused_ok(const ConvLaunch &c) {
     if (c.Cout < 1 || c.Cout > 3 || c.C0 % 32 != 0 || c.C0 > 32 * HF_MAXCH || c.Hin != c.Hout || c.Win != c.Wout) return false;
     if ((c.Wout & 31) || c.Wout > 64 || c.Hout < 4) return false;
     const int th = head_fused_rows(c);
-    return th >= 4 && c.Hout % th == 0 && c.Cout * th * (c.Wout >> 2) <= 2 * HF_NT;   // (two gather items per thread)
+    const int min_rows = c.Hout == th ? th : th + 1;                                   // rows of P an edge band keeps
+    return th >= 4 && c.Hout % th == 0 && c.Cout * th * (c.Wout >> 2) <= 2 * HF_NT &&   // (two gather items per thread)
+           min_rows * (c.Wout >> 5) >= 8;                                              // (every wave has a tile)
 }
 
 int64_t head_fused_weight_floats(int Cin) { return (int64_t)Cin * 32 + (int64_t)Cin * 48; }   // fp32 fragments + three bf16 planes
@@ -426,7 +511,14 @@ int launch_conv_head_fused(const ConvLaunch &c, const HeadUpdate *hu, hipStream_
     ProfScope ps(hu ? "head_fused+update" : "head_fused", 2.0 * M * c.Cout * 9.0 * c.C0, bytes, st);
     const size_t lds = head_fused_lds_floats(c, a.TH) * sizeof(float);
     const bool bf = head_fused_bf(c);
-    const unsigned grid = (unsigned)(c.B * (c.Hout / a.TH));
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        DLPM_HIP(hipGetDevice(&dev));
+        DLPM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int nwg = c.B * (c.Hout / a.TH);
+    const unsigned grid = (unsigned)(nwg < ncu ? nwg : ncu);     // persistent: one workgroup per CU walks the bands
 #define DLPM_HF1(CO, NCH, BFV)                                                                            \
     do {                                                                                                  \
         int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_head_fused<CO, NCH, BFV>), 160 * 1024); \
@@ -453,6 +545,8 @@ int launch_conv_head_fused(const ConvLaunch &c, const HeadUpdate *hu, hipStream_
 #undef DLPM_HFC
 #undef DLPM_HF
 #undef DLPM_HF1
+#undef HF_TILE
+#undef HF_LDS_BARRIER
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }
