@@ -42,6 +42,9 @@ constexpr int HF_MAXCH = 4;       // K chunks of 32 channels the register-reside
 constexpr int HF_STG_F32 = 32 * HF_SLD;   // dwords of a wave's transpose patch, fp32 form
 constexpr int HF_STG_BF = 3 * 32 * 16;    // ... bf16 form: [plane][pixel][32 bf16]
 constexpr float HF_LOG2E = 1.44269504088896340736f;
+#ifndef HF_ABLATE          // timing-only developer builds (wrong results): 1 no MFMAs, 2 no SiLU / split arithmetic, 4 no gather, 8 no reloads
+#define HF_ABLATE 0
+#endif
 
 // fp32 pair -> the packed bf16 pairs of its three planes (conv_split.hip's split, exact: 8 + 8 + 8 significand bits)
 __device__ __forceinline__ void hf_split2(float lo, float hi, uint32_t &p0, uint32_t &p1, uint32_t &p2) {
@@ -63,15 +66,33 @@ __device__ __forceinline__ f32x2 hf_act2(f32x2 x, f32x2 a, f32x2 b) {
     return v * f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
 }
 
+// the gather's item of a thread: (channel co, row y, pixel quad q) of the rows g_lo .. ; co >= Cout = none
+struct HfItem { int co, y, q; };
+__device__ __forceinline__ HfItem hf_item(int tid, int g_lo, int rows, int nq) {
+    int tb = tid;
+    asm volatile("" : "+v"(tb));     // (opaque: hoisted out of the image walk as invariants, the coordinates would live in scratch)
+    const int per_co = rows * nq, co = tb / per_co, rq = tb - co * per_co, r = rq / nq;
+    return HfItem{co, g_lo + r, rq - r * nq};
+}
+
+// A 16-byte global store the compiler does not see as one.  hipcc's waitcnt pass treats a store and the loads in flight as unordered
+// (one counter on gfx9, no vscnt): the first wait for a LOAD after a store becomes s_waitcnt vmcnt(0) -- the head of every phase would
+// sit out the write acknowledgements of the update and the landing of two tiles of read-ahead.  Hidden, the store still counts in the
+// hardware's vmcnt, which only makes the loop's counted waits stricter: loads retire in order among themselves, so "at most N
+// operations outstanding" still implies that a load with N younger loads behind it has landed, whatever the stores do.  (s_nop: the
+// data registers of a store wider than 8 bytes may not be overwritten in the next cycle, and the hazard recognizer does not read asm.)
+typedef float hf_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void hf_store4(float *ptr, float4 v) {
+    const hf_f32x4 d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(ptr), "v"(d) : "memory");
+}
+
 #define HF_LDS_EXCHANGE()                                             \
     do {                                                              \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); \
         __builtin_amdgcn_wave_barrier();                              \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local"); \
     } while (0)
-
-// rows of P a workgroup keeps: its TH output rows + the halo rows that lie inside the picture
-__host__ __device__ __forceinline__ int hf_rows_kept(int H, int TH) { return H == TH ? TH : (H == 2 * TH ? TH + 1 : TH + 2); }
 
 // workgroup barrier that orders LDS only: __syncthreads() is a workgroup-scope fence over ALL address spaces, i.e. s_waitcnt vmcnt(0) --
 // every wave would sit out the write acknowledgements of its update stores and the landing of its prefetch at each barrier
@@ -89,111 +110,45 @@ struct HeadFusedArgs {
     const float *bias;            // [Cout]
     float *out;                   // eps (plain forward): NCHW [B][Cout][H][W] or NHWC
     int out_nchw;
-    int B, H, W, C, TH;
+    int B, H, W, C;
     HeadUpdate u;
 #ifdef DLPM_PHASE_TIMING
-    unsigned long long *phase;    // developer builds: 0 prologue, 1 tile loop, 2 barrier + gather/update, 3 workgroups, 12/13 clock, 16+w barrier wait
+    unsigned long long *phase;    // developer builds: 1 tile steps, 2 barrier + gather/update, 3 phases, 12/13 clock, 16+w barrier wait
 #endif
 };
 
-// One tile of a wave (expanded twice in the kernel: the tiles of a band that have a successor in it, and the band's last one).
-// step(c, NEXT): chunk c's A fragments out of the patch, then its MFMAs next to the staging of the wave's next chunk (NEXT: 1 = chunk
-// c + 1 of this tile, 2 = chunk 0 of the next tile, 0 = none: the band's last step).  Wave-private exchanges: LDS operations of one wave
-// execute in order; the LDS-only fences keep the compiler from moving them (a plain wavefront fence also drains the GLOBAL loads in
-// flight: the prefetch).  The sched_barrier at the end of a step: nothing of a later step moves up -- hipcc otherwise hoists the
-// GroupNorm FMAs of ALL later chunks between this chunk's MFMAs and waits for loads issued one chunk ago.  ns = the tile after t
-// (chunks 1.. are reloaded from it), ns2 = the one after that (chunk 0).  D layout of the 32x32 MFMA: register i holds row
-// 8 (i / 4) + 4 kh + (i % 4) (pixel), column lm (tap channel).  (A macro, not a lambda: called twice, a lambda is not inlined before
-// SROA and every register array of the kernel lands in scratch.)
-#define HF_TILE(LASTV)                                                                                  \
-    do {                                                                                                \
-        constexpr bool last = LASTV;                                                                    \
-            floatx16 acc; \
-_Pragma("unroll") \
-            for (int r = 0; r < 16; r++) acc[r] = 0.f; \
-            const float *ns = !last ? tile_src(wg, t + 8) : (more ? tile_src(wgn, wave) : p.wf + 4 * lc); \
-            const float *ns2 = t + 16 < ntile ? tile_src(wg, t + 16) \
-                                              : (more ? tile_src(wgn, !last ? wave : wave + 8) : p.wf + 4 * lc); \
-            auto step = [&](auto cc, auto nn) __attribute__((always_inline)) { \
-                constexpr int c = decltype(cc)::value, NEXT = decltype(nn)::value; \
-                if constexpr (BF) { \
-                    bf16x8 A[2][3]; \
-_Pragma("unroll") \
-                    for (int j = 0; j < 2; j++) \
-_Pragma("unroll") \
-                        for (int pl = 0; pl < 3; pl++) \
-                            A[j][pl] = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const uint32_t *>(stg) + pl * 512 + lm * 16 + \
-                                                                         4 * ((2 * j + kh) ^ rd_sw)); \
-                    HF_LDS_EXCHANGE(); \
-                    if constexpr (NEXT == 1) { stage(c + 1); load_chunk(ns, c + 1); } \
-                    if constexpr (NEXT == 2) { stage(0); load_chunk(ns2, 0); } \
-_Pragma("unroll") \
-                    for (int j = 0; j < 2; j++) { \
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][2], bwb[c][j][0], acc, 0, 0, 0); \
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][1], bwb[c][j][1], acc, 0, 0, 0); \
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], bwb[c][j][2], acc, 0, 0, 0); \
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][1], bwb[c][j][0], acc, 0, 0, 0); \
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], bwb[c][j][1], acc, 0, 0, 0); \
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], bwb[c][j][0], acc, 0, 0, 0); \
-                    } \
-                } else { \
-                    float4 a[4]; \
-_Pragma("unroll") \
-                    for (int q = 0; q < 4; q++) a[q] = *reinterpret_cast<const float4 *>(stg + lm * HF_SLD + 8 * q + 4 * kh); \
-                    HF_LDS_EXCHANGE(); \
-                    if constexpr (NEXT == 1) { stage(c + 1); load_chunk(ns, c + 1); } \
-                    if constexpr (NEXT == 2) { stage(0); load_chunk(ns2, 0); } \
-_Pragma("unroll") \
-                    for (int q = 0; q < 4; q++) { \
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bw[c][q].x, acc, 0, 0, 0); \
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bw[c][q].y, acc, 0, 0, 0); \
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bw[c][q].z, acc, 0, 0, 0); \
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bw[c][q].w, acc, 0, 0, 0); \
-                    } \
-                } \
-                HF_LDS_EXCHANGE(); \
-                __builtin_amdgcn_sched_barrier(0); \
-            }; \
-            auto store_tile = [&]() __attribute__((always_inline)) { \
-                if (lm < NV) { \
-                    const int sr = t / tpr, x0 = (t - sr * tpr) * 32; \
-                    float *dst = P + lm * PL + sr * W + x0 + 4 * kh; \
-_Pragma("unroll") \
-                    for (int j = 0; j < 4; j++) \
-                        *reinterpret_cast<float4 *>(dst + 8 * j) = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]); \
-                } \
-            }; \
-            if constexpr (NCH > 1) step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); \
-            if constexpr (NCH > 2) step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}); \
-            if constexpr (NCH > 3) step(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}); \
-            step(std::integral_constant<int, NCH - 1>{}, std::integral_constant<int, last ? 0 : 2>{}); \
-            store_tile(); \
-    } while (0)
-
-// NCH = C / 32 K chunks, a compile-time constant: with a run-time bound the chunk loop's loads sit inside (uniform) branches and hipcc
-// drains them at every join (s_waitcnt vmcnt(0)).
-//
-// PERSISTENT: the grid is one workgroup per CU and a workgroup walks the bands wg = blockIdx.x, + gridDim.x, ...: W' is fetched once
-// (all 256 CUs pulling the same 24 KB four times over was 10 k of a band's 75 k cycles), and the next band's coefficients and first
-// tile are requested before the barrier, so HBM keeps streaming while the gather runs.
-// PIPELINED: step (t, c) of a wave = read chunk c's A fragments from the patch, then MFMAs(c) next to stage(c + 1) -- SiLU + split of the
-// NEXT chunk into the patch -- in one scheduling region: the bf16 MFMA runs beside the VALU, and a wave alone on its SIMD (the
-// older wave of a SIMD finishes its tiles first) keeps both busy.
+// THE KERNEL'S SHAPE (round 4, third form).  One persistent workgroup per CU walks images b = blockIdx.x, + gridDim.x, ...; an image
+// is cut into PHASES of 16 tiles (32 pixels of one row x all channels each; NR = 16 / (W / 32) rows), two tiles per wave:
+//   tile steps:  the phase's rows of  P[n = tap Cout + co][row][x] = sum_ci act(h)[row][x][ci] W'[ci][n]  into an LDS RING of NR + 2 rows
+//   barrier, gather: the 9-point sums + the reverse update for the rows whose three P rows are complete -- rows ph NR - 1 .. (ph + 1) NR - 2
+//                    (the image's first and last phase take the border row as well); the ring keeps the two rows the next phase needs
+//   barrier
+// so no row of P is computed twice (the earlier band form recomputed 2 of 10 rows for 64 x 64 images) and P is 62 KB instead of 111.
+// What that frees goes to the operands: W' sits in LDS (24 KB, b128 reads in fragment order, same for every wave) instead of 96 VGPRs,
+// and the registers hold TWO tiles of input in flight per wave (32 KB; 256 KB per CU): buffer s = the wave's s-th tile of a phase,
+// reloaded chunk by chunk with the same tile of the NEXT phase as soon as a chunk has been staged -- seven steps ahead.  (With one tile
+// ahead, PMC showed the SIMDs idle 42 % of the cycles: both waves of a SIMD waiting for HBM.)
+// A wave's instruction stream is one pipeline of STEPS that runs across tiles, phases and images: step (s, c) reads chunk c's A
+// fragments from its patch, then issues chunk c's MFMAs next to the staging -- GroupNorm affine, SiLU, three-plane split, patch
+// stores -- of the NEXT chunk of its sequence (the bf16 MFMA runs beside the VALU).  All loads are unconditional (past the last image
+// they read the L2-resident weight buffer), so every wait of the loop is an exact vmcnt.
 template <int COUT, int NCH, bool BF>
 __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
     constexpr int NV = 9 * COUT;                       // live tap channels (27)
     constexpr int C = 32 * NCH;
+    constexpr int STG = BF ? HF_STG_BF : HF_STG_F32;
+    constexpr int WFL = BF ? C * 48 : C * 32;          // floats of W' this form reads
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int W = p.W, H = p.H, TH = p.TH;
-    const int bands = H / TH, nwg = p.B * bands, G = gridDim.x;
-    // P as NV planes [row s - s_lo][W] of pitch PL = rows W + 4 floats: a lane's four consecutive pixels are one 16-byte LDS access on
-    // both sides (MFMA registers 4 j .. 4 j + 3 in; a gather item's pixel quad out), the + 4 spreads the 27 lanes of a store over the banks
-    const int PL = hf_rows_kept(H, TH) * W + 4;
+    const int W = p.W, H = p.H, G = gridDim.x;
+    const int tpr = W >> 5, NR = 16 / tpr, RR = NR + 2, NPH = H / NR;      // tiles per row, rows per phase, ring rows, phases per image
+    // P as NV planes [ring row][W] of pitch PL = RR W + 4 floats: a lane's four consecutive pixels are one 16-byte LDS access on both
+    // sides (MFMA registers 4 j .. 4 j + 3 in; a gather item's pixel quad out), the + 4 spreads the 27 lanes of a store over the banks
+    const int PL = RR * W + 4;
     float *P = sm;
-    float *stg = sm + NV * PL + wave * (BF ? HF_STG_BF : HF_STG_F32);
-    float *cf = sm + NV * PL + 8 * (BF ? HF_STG_BF : HF_STG_F32);   // [2][C] GroupNorm affine of the band's image (registers are short)
-    const int tpr = W >> 5;                            // 32-pixel tiles per row
+    float *stg = sm + NV * PL + wave * STG;
+    const float *wl = sm + NV * PL + 8 * STG;          // W' (this form's fragments)
+    float *cf = sm + NV * PL + 8 * STG + WFL;          // [2 slots][2][C] GroupNorm affine: slot = parity of the image's position in this workgroup's walk
     const int64_t HW = (int64_t)H * W;
     const int lp = lane >> 3, lc = lane & 7;           // load role: pixel 8 i + lp, channels 4 lc .. 4 lc + 3 of the chunk
     const int lm = lane & 31, kh = lane >> 5;          // MFMA role: pixel lm, k slot kh
@@ -202,59 +157,50 @@ __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
     const int wr_off = lp * 16 + 4 * ((lc >> 1) ^ ((lp >> 1) & 3)) + 2 * (lc & 1);      // + plane 512 + i 128
     const int rd_sw = (lm >> 1) & 3;                                                      // unit 2 j + kh -> slot ^ rd_sw
 
-    // ---- W' fragments: registers for the whole kernel
-    float4 bw[BF ? 1 : NCH][4];
-    bf16x8 bwb[BF ? NCH : 1][2][3];
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-        if constexpr (BF) {
-            const bf16x8 *wb = reinterpret_cast<const bf16x8 *>(p.wf + (int64_t)C * 32);
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int pl = 0; pl < 3; pl++) bwb[c][j][pl] = wb[((c * 2 + j) * 3 + pl) * 64 + lane];
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; q++) bw[c][q] = reinterpret_cast<const float4 *>(p.wf)[(c * 4 + q) * 64 + lane];
-        }
+    {   // W' -> LDS, once
+        const float4 *src = reinterpret_cast<const float4 *>(p.wf + (BF ? (int64_t)C * 32 : 0));
+        float4 *dst = reinterpret_cast<float4 *>(sm + NV * PL + 8 * STG);
+        for (int i = tid; i < WFL / 4; i += HF_NT) dst[i] = src[i];
     }
-
-    // band geometry: image b, first output row y0; row slots of P are image rows y0 - 1 .. y0 + TH, of which only those inside the
-    // picture are kept (s_lo .. s_hi - 1)
-    auto band_y0 = [&](int wg) __attribute__((always_inline)) { return (wg - (wg / bands) * bands) * TH; };
-    auto tile_src = [&](int wg, int t) __attribute__((always_inline)) {               // tile t of band wg: 32 pixels of one row, this lane's channel quad of chunk 0
-        const int b = wg / bands, y0 = band_y0(wg), s = (y0 == 0 ? 1 : 0) + t / tpr, x0 = (t - (t / tpr) * tpr) * 32;
-        return p.h + (((int64_t)b * H + (y0 - 1 + s)) * W + x0) * C + 4 * lc;
-    };
-    // Input chunks travel ONE TILE ahead: buffer c holds chunk c of the tile being worked on and is reloaded with chunk c of the
-    // wave's next tile as soon as it has been staged (16 KB per wave in flight).
-    float4 xb[NCH][4];
-    auto load_chunk = [&](const float *src, int c) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) xb[c][i] = *reinterpret_cast<const float4 *>(src + 32 * c + (int64_t)(8 * i + lp) * C);
-    };
-    // the image's coefficients: threads 0 .. C / 2 - 1 fetch one float4 each (A then B) ...
-    auto fetch_coefs = [&](int wg) __attribute__((always_inline)) {
-        const int b = wg / bands;
+    // the coefficients of an image: threads 0 .. C / 2 - 1 fetch one float4 each (A then B) ...
+    auto fetch_coefs = [&](int b) __attribute__((always_inline)) {
         const float *src = tid < C / 4 ? p.coefA + (int64_t)b * C + 4 * tid : p.coefB + (int64_t)b * C + 4 * (tid - C / 4);
         return tid < C / 2 ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    // ... and drop it into LDS once nobody reads the previous image's any more (after the band's first barrier)
-    auto put_coefs = [&](float4 v) __attribute__((always_inline)) {
-        if (tid < C / 2) *reinterpret_cast<float4 *>(cf + 4 * tid) = v;
+    // ... and drop it into a slot nobody reads any more
+    auto put_coefs = [&](float4 v, int slot) __attribute__((always_inline)) {
+        if (tid < C / 2) *reinterpret_cast<float4 *>(cf + slot * 2 * C + 4 * tid) = v;
     };
-    // stage(c): GroupNorm affine + SiLU (+ the three-plane split) of buffer c into the wave's patch
-    auto stage = [&](int c) __attribute__((always_inline)) {
-        const float4 cA = *reinterpret_cast<const float4 *>(cf + 32 * c + 4 * lc), cB = *reinterpret_cast<const float4 *>(cf + C + 32 * c + 4 * lc);
+    // tile s (0 / 1) of phase ph of image b for this wave; past the last image a harmless L2-resident address (the loads stay unconditional)
+    auto tile_src = [&](int b, int ph, int s) __attribute__((always_inline)) {
+        const int id = wave + 8 * s, y = ph * NR + id / tpr, x0 = (id - (id / tpr) * tpr) * 32;
+        return b < p.B ? p.h + (((int64_t)b * H + y) * W + x0) * C + 4 * lc : p.wf + 4 * lc;
+    };
+    float4 xb[2][NCH][4];
+    auto load_chunk = [&](const float *src, int s, int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (!(HF_ABLATE & 8)) xb[s][c][i] = *reinterpret_cast<const float4 *>(src + 32 * c + (int64_t)(8 * i + lp) * C);
+    };
+    // stage(s, c, slot): GroupNorm affine + SiLU (+ the three-plane split) of buffer (s, c) into the wave's patch
+    auto stage = [&](int s, int c, const float *cfs) __attribute__((always_inline)) {
+        const float4 cA = *reinterpret_cast<const float4 *>(cfs + 32 * c + 4 * lc), cB = *reinterpret_cast<const float4 *>(cfs + C + 32 * c + 4 * lc);
         const f32x2 a01 = {cA.x, cA.y}, a23 = {cA.z, cA.w}, b01 = {cB.x, cB.y}, b23 = {cB.z, cB.w};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const float4 xr = xb[c][i];
-            const f32x2 v01 = hf_act2(f32x2{xr.x, xr.y}, a01, b01), v23 = hf_act2(f32x2{xr.z, xr.w}, a23, b23);
+            const float4 xr = xb[s][c][i];
+            f32x2 v01, v23;
+            if (HF_ABLATE & 2) { v01 = f32x2{xr.x, xr.y} + a01; v23 = f32x2{xr.z, xr.w} + b23; }
+            else { v01 = hf_act2(f32x2{xr.x, xr.y}, a01, b01); v23 = hf_act2(f32x2{xr.z, xr.w}, a23, b23); }
             if constexpr (BF) {
                 uint32_t q0[2], q1[2], q2[2];
-                hf_split2(v01.x, v01.y, q0[0], q1[0], q2[0]);
-                hf_split2(v23.x, v23.y, q0[1], q1[1], q2[1]);
+                if (HF_ABLATE & 2) {
+                    q0[0] = q1[0] = q2[0] = __float_as_uint(v01.x) ^ __float_as_uint(v01.y);
+                    q0[1] = q1[1] = q2[1] = __float_as_uint(v23.x) ^ __float_as_uint(v23.y);
+                } else {
+                    hf_split2(v01.x, v01.y, q0[0], q1[0], q2[0]);
+                    hf_split2(v23.x, v23.y, q0[1], q1[1], q2[1]);
+                }
                 uint32_t *dst = reinterpret_cast<uint32_t *>(stg) + wr_off + i * 128;
                 *reinterpret_cast<uint2 *>(dst) = make_uint2(q0[0], q0[1]);
                 *reinterpret_cast<uint2 *>(dst + 512) = make_uint2(q1[0], q1[1]);
@@ -266,87 +212,143 @@ __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
     };
 
     const HeadUpdate &u = p.u;
-    const int nq = W >> 2, per_co = TH * nq, nitem = COUT * per_co;
+    const int nq = W >> 2;
     const int64_t D = (int64_t)COUT * HW;
-    int wg = blockIdx.x;
-    put_coefs(fetch_coefs(wg));
-    {
-        const float *src = tile_src(wg, wave);
+    // the update's launch constants (t -> g is a DEPENDENT pair of loads: once, here)
+    int tt = 0;
+    float g = 1.f, rg = 1.f;
+    uint64_t seed = 0;
+    int64_t soff = 0;
+    float *hist = nullptr;
+    if (u.x) {
+        tt = *u.t;
+        g = u.g[tt];
+        rg = 1.0f / g;
+        seed = u.key ? u.key[0] : u.seed;
+        soff = u.key ? (int64_t)u.key[1] : u.sample_offset;
+        hist = u.hist_pp ? *u.hist_pp : nullptr;
+    }
+    // ---- the walk: position (image b, phase ph); n = the image's index in this workgroup's sequence (its coefficient slot is n & 1)
+    int b = blockIdx.x, ph = 0, n = 0;
+    put_coefs(fetch_coefs(b), 0);
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const float *src = tile_src(b, 0, s);
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
-            load_chunk(src, c);
-            // chunk order, as the loop reloads them (hipcc sorts these 16 loads by address otherwise, and the loop's static vmcnt
-            // waits are the merge of all entry paths)
-            __builtin_amdgcn_sched_barrier(0);
+            load_chunk(src, s, c);
+            __builtin_amdgcn_sched_barrier(0);         // (issue order = consumption order: the loop's vmcnt waits count on it)
         }
     }
     HF_LDS_BARRIER();
+    stage(0, 0, cf);
+    load_chunk(tile_src(NPH > 1 ? b : b + G, NPH > 1 ? 1 : 0, 0), 0, 0);
+    HF_LDS_EXCHANGE();
+    __builtin_amdgcn_sched_barrier(0);
     for (;;) {
 #ifdef DLPM_PHASE_TIMING
         const long long _c0 = clock64(), _r0 = wall_clock64();
 #endif
-        const int b = wg / bands, y0 = band_y0(wg);
-        const int s_lo = y0 == 0 ? 1 : 0, s_hi = (y0 + TH == H) ? TH + 1 : TH + 2;
-        const int ntile = (s_hi - s_lo) * tpr;         // >= 8 (head_fused_ok): every wave has a tile
-        const int wgn = wg + G;
-        const bool more = wgn < nwg;
+        // the next two positions of the walk
+        const bool lastph = ph + 1 == NPH;
+        const int b1 = lastph ? b + G : b, ph1 = lastph ? 0 : ph + 1, n1 = lastph ? n + 1 : n;
+        const bool lastph1 = ph1 + 1 == NPH;
+        const int b2 = lastph1 ? b1 + G : b1, ph2 = lastph1 ? 0 : ph1 + 1;
+        const float *cf0 = cf + (n & 1) * 2 * C, *cf1 = cf + (n1 & 1) * 2 * C;
+        const float *nx0 = tile_src(b1, ph1, 0), *nx1 = tile_src(b1, ph1, 1), *nxx = tile_src(b2, ph2, 0);
 
-        // ---- phase A: the band's rows as 32-pixel tiles, round-robin over the waves
-        stage(0);
-        {   // (the tile after this one: in this band, else the first of the next band, else a harmless L2-resident address --
-            //  the loads stay unconditional, so that every path into the loop has the same loads in flight)
-            const float *n0 = wave + 8 < ntile ? tile_src(wg, wave + 8) : (more ? tile_src(wgn, wave) : p.wf + 4 * lc);
-            load_chunk(n0, 0);
-        }
-        HF_LDS_EXCHANGE();
-        __builtin_amdgcn_sched_barrier(0);
-        // The band's last tile is its own copy of the code, behind the loop: as a branch inside one copy ("stage chunk 0 of the next
-        // tile unless this is the last"), hipcc's waitcnt pass sees a path around those loads into the loop's back edge and counts every
-        // wait of the loop for it (vmcnt(11) instead of (15): the read-ahead one chunk shorter)
-        int t = wave;
-        for (; t + 8 < ntile; t += 8) HF_TILE(false);
-        HF_TILE(true);
+        // the gather covers the rows whose P rows will be complete, g_lo .. g_hi - 1; an item = (channel, row, 4 pixels), one per thread
+        const int g_lo = ph == 0 ? 0 : ph * NR - 1, g_hi = lastph ? H : (ph + 1) * NR - 1;
+        // the next image's coefficients travel during its predecessor's first phase (its first chunk is staged in the LAST step of the
+        // predecessor's last phase; NPH >= 2)
+        const bool carry = ph == 0 && b + G < p.B;
+        float4 xq = make_float4(0.f, 0.f, 0.f, 0.f), ncf = make_float4(0.f, 0.f, 0.f, 0.f);
+        float bv = 0.f, ce = 0.f, cn = 0.f;
 
-        // ---- phase B: 9-point gather from LDS + the reverse update (k_head_gather's arithmetic, tap by tap in its order; taps outside
-        // the picture add a literal zero where k_head_gather adds the zero its padded P holds).  An item = (channel, row, 4 pixels); at
-        // most two per thread (head_fused_ok).  The state quads and the next band's coefficients are requested BEFORE the barrier: the
-        // waves that finish their tiles first wait there anyway.
-        int64_t e0k[2];
-        int cok[2], rk[2], qk[2];
-        float4 xk[2];
-        float bvk[2];
-        // (recomputed per band behind an opaque copy of the thread index: hoisted out of the band loop as invariants, the item
-        //  coordinates live across the tile loop, i.e. in scratch, and every reload is an s_waitcnt vmcnt(0))
-        int tb = tid;
-        asm volatile("" : "+v"(tb));
-        // the update's per-image scalars, requested here: three dependent loads (t -> g, c_eps, c_noise) otherwise sit behind the barrier
-        int tt = 0;
-        float g = 1.f, rg = 1.f, ce = 0.f, cn = 0.f;
-        uint64_t seed = 0, gidx = 0;
-        float *hr = nullptr;
-        if (u.x) {
-            tt = *u.t;
-            g = u.g[tt];
-            rg = 1.0f / g;
-            ce = u.c_eps[(int64_t)tt * u.B + b];
-            cn = u.c_noise[(int64_t)tt * u.B + b];
-            seed = u.key ? u.key[0] : u.seed;
-            gidx = (uint64_t)((u.key ? (int64_t)u.key[1] : u.sample_offset) + b);
-            hr = u.hist_pp ? *u.hist_pp : nullptr;
-            if (hr) hr += ((int64_t)(u.T - tt) * u.B + b) * D;
-        }
+        // ---- tile steps.  step(s, c): chunk c's A fragments out of the patch, then its MFMAs next to the staging of the NEXT chunk of the
+        // wave's sequence -- (s, c + 1), or (1, 0), or chunk 0 of the next position's first tile -- whose buffer is reloaded from the
+        // same tile one position on.  Wave-private exchanges: LDS operations of one wave execute in order; the LDS-only fences keep
+        // the compiler from moving them (a plain wavefront fence also drains the GLOBAL loads in flight).  The sched_barrier: nothing
+        // of a later step moves up (hipcc otherwise hoists the affine FMAs of ALL later chunks and waits for their loads here).
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int it = tb + k * HF_NT;
-            cok[k] = it / per_co;
-            const int rq = it - cok[k] * per_co;
-            rk[k] = rq / nq;
-            qk[k] = rq - rk[k] * nq;
-            e0k[k] = (int64_t)cok[k] * HW + (int64_t)(y0 + rk[k]) * W + 4 * qk[k];
-            if (u.x && it < nitem) xk[k] = *reinterpret_cast<const float4 *>(u.x + (int64_t)b * D + e0k[k]);
-            bvk[k] = (p.bias && it < nitem) ? p.bias[cok[k]] : 0.f;
+        for (int s = 0; s < 2; s++) {
+            floatx16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                if constexpr (BF) {
+                    bf16x8 A[2][3];
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+#pragma unroll
+                        for (int pl = 0; pl < 3; pl++)
+                            A[j][pl] = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const uint32_t *>(stg) + pl * 512 + lm * 16 +
+                                                                         4 * ((2 * j + kh) ^ rd_sw));
+                    HF_LDS_EXCHANGE();
+                    if (c + 1 < NCH) { stage(s, c + 1, cf0); load_chunk(s == 0 ? nx0 : nx1, s, c + 1); }
+                    else if (s == 0) { stage(1, 0, cf0); load_chunk(nx1, 1, 0); }
+                    else { stage(0, 0, cf1); load_chunk(nxx, 0, 0); }
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {      // small terms first (conv_split.hip's order); W' fragments straight from LDS
+                        if (HF_ABLATE & 1) { asm volatile("" :: "v"(A[j][0]), "v"(A[j][1]), "v"(A[j][2])); continue; }
+                        bf16x8 Bf[3];
+#pragma unroll
+                        for (int pl = 0; pl < 3; pl++) Bf[pl] = reinterpret_cast<const bf16x8 *>(wl)[((c * 2 + j) * 3 + pl) * 64 + lane];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][2], Bf[0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][1], Bf[1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], Bf[2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][1], Bf[0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], Bf[1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], Bf[0], acc, 0, 0, 0);
+                    }
+                } else {
+                    float4 a[4], bq[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        a[q] = *reinterpret_cast<const float4 *>(stg + lm * HF_SLD + 8 * q + 4 * kh);
+                        bq[q] = reinterpret_cast<const float4 *>(wl)[(c * 4 + q) * 64 + lane];
+                    }
+                    HF_LDS_EXCHANGE();
+                    if (c + 1 < NCH) { stage(s, c + 1, cf0); load_chunk(s == 0 ? nx0 : nx1, s, c + 1); }
+                    else if (s == 0) { stage(1, 0, cf0); load_chunk(nx1, 1, 0); }
+                    else { stage(0, 0, cf1); load_chunk(nxx, 0, 0); }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bq[q].x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bq[q].y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bq[q].z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bq[q].w, acc, 0, 0, 0);
+                    }
+                }
+                HF_LDS_EXCHANGE();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // D layout of the 32x32 MFMA: register i holds row 8 (i / 4) + 4 kh + (i % 4) (pixel), column lm (tap channel)
+            if (lm < NV) {
+                const int id = wave + 8 * s, y = ph * NR + id / tpr, x0 = (id - (id / tpr) * tpr) * 32;
+                float *dst = P + lm * PL + (y % RR) * W + x0 + 4 * kh;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    *reinterpret_cast<float4 *>(dst + 8 * j) = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+            }
+            if (s == 0) {
+                // What the gather reads from global memory is requested HALFWAY through the phase: vmcnt retires in order, so a wait
+                // for anything requested after the last tile's reloads would wait for all of them (an HBM latency per phase), whereas
+                // behind these sit only the second tile's 16.  Unconditional (dummy addresses), so the loop's waits stay exact counts.
+                const HfItem it = hf_item(tid, g_lo, g_hi - g_lo, nq);
+                const bool item = it.co < COUT;
+                const float *px = (u.x && item) ? u.x + (int64_t)b * D + (int64_t)it.co * HW + (int64_t)it.y * W + 4 * it.q : p.wf + 4 * lane;
+                xq = *reinterpret_cast<const float4 *>(px);
+                bv = *((p.bias && item) ? p.bias + it.co : p.wf);
+                ce = *(u.x ? u.c_eps + (int64_t)tt * u.B + b : p.wf);
+                cn = *(u.x ? u.c_noise + (int64_t)tt * u.B + b : p.wf);
+                if (carry) ncf = fetch_coefs(b + G);
+            }
         }
-        const float4 ncf = fetch_coefs(more ? wgn : wg);
+
+        // ---- gather + update.  k_head_gather's arithmetic, tap by tap in its order; taps outside the picture add a literal zero where
+        // k_head_gather adds the zero its padded P holds.
 #ifdef DLPM_PHASE_TIMING
         const long long _c2 = clock64();
 #endif
@@ -354,22 +356,24 @@ __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
 #ifdef DLPM_PHASE_TIMING
         const long long _c3 = clock64();
 #endif
-        put_coefs(ncf);
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int it = tb + k * HF_NT;
-            if (it >= nitem) break;
-            const int co = cok[k], r = rk[k], q = qk[k];
-            const float bv = bvk[k];
+        asm volatile("" :: "v"(xq.x), "v"(xq.y), "v"(xq.z), "v"(xq.w), "v"(bv), "v"(ce), "v"(cn));   // (every path consumes what it requested)
+        if (carry) put_coefs(ncf, (n + 1) & 1);
+        const uint64_t gidx = (uint64_t)(soff + b);
+        float *hr = hist ? hist + ((int64_t)(u.T - tt) * u.B + b) * D : nullptr;
+        const HfItem it = hf_item(tid, g_lo, g_hi - g_lo, nq);
+        const int co = it.co, y = it.y, q = it.q;
+        const bool item = co < COUT && !(HF_ABLATE & 4);
+        const int64_t e0 = (int64_t)co * HW + (int64_t)y * W + 4 * q;
+        if (item) {
             float acc[4] = {bv, bv, bv, bv};
 #pragma unroll
             for (int ky = 0; ky < 3; ky++) {
-                const int s = r + ky;                                              // slot of image row y0 + r + ky - 1
-                const int sc = min(max(s, s_lo), s_hi - 1) - s_lo;
-                const bool inb = s >= s_lo && s < s_hi;
-                float4 Q[3];                                                       // (row by row: registers are short here)
+                const int yy = y + ky - 1;
+                const bool inb = yy >= 0 && yy < H;
+                const int yc = min(max(yy, 0), H - 1);
+                float4 Q[3];
 #pragma unroll
-                for (int kx = 0; kx < 3; kx++) Q[kx] = *reinterpret_cast<const float4 *>(P + ((ky * 3 + kx) * COUT + co) * PL + sc * W + 4 * q);
+                for (int kx = 0; kx < 3; kx++) Q[kx] = *reinterpret_cast<const float4 *>(P + ((ky * 3 + kx) * COUT + co) * PL + (yc % RR) * W + 4 * q);
 #pragma unroll
                 for (int kx = 0; kx < 3; kx++) {
                     float4 v = Q[kx];
@@ -387,24 +391,22 @@ __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
                     }
                 }
             }
-            const int64_t pix = (int64_t)(y0 + r) * W + 4 * q;
-            const int64_t e0 = e0k[k];
             if (u.x) {
-                const float4 x = xk[k];
                 float4 z;
                 if (u.z) z = *reinterpret_cast<const float4 *>(u.z + (int64_t)b * D + e0);
                 else z = (cn != 0.0f) ? philox_normal4(seed, gidx, (uint32_t)(e0 >> 2), kPurposeStepZ, (uint32_t)tt) : make_float4(0.f, 0.f, 0.f, 0.f);
                 float4 o;
-                o.x = fmaf(cn, z.x, div_by(x.x - ce * acc[0], g, rg));
-                o.y = fmaf(cn, z.y, div_by(x.y - ce * acc[1], g, rg));
-                o.z = fmaf(cn, z.z, div_by(x.z - ce * acc[2], g, rg));
-                o.w = fmaf(cn, z.w, div_by(x.w - ce * acc[3], g, rg));
-                *reinterpret_cast<float4 *>(u.x + (int64_t)b * D + e0) = o;
-                if (hr) *reinterpret_cast<float4 *>(hr + e0) = o;
-                if (u.eps_out) *reinterpret_cast<float4 *>(u.eps_out + (int64_t)b * D + e0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                o.x = fmaf(cn, z.x, div_by(xq.x - ce * acc[0], g, rg));
+                o.y = fmaf(cn, z.y, div_by(xq.y - ce * acc[1], g, rg));
+                o.z = fmaf(cn, z.z, div_by(xq.z - ce * acc[2], g, rg));
+                o.w = fmaf(cn, z.w, div_by(xq.w - ce * acc[3], g, rg));
+                hf_store4(u.x + (int64_t)b * D + e0, o);
+                if (hr) hf_store4(hr + e0, o);
+                if (u.eps_out) hf_store4(u.eps_out + (int64_t)b * D + e0, make_float4(acc[0], acc[1], acc[2], acc[3]));
             } else if (p.out_nchw) {
-                *reinterpret_cast<float4 *>(p.out + (int64_t)b * D + e0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                hf_store4(p.out + (int64_t)b * D + e0, make_float4(acc[0], acc[1], acc[2], acc[3]));
             } else {
+                const int64_t pix = (int64_t)y * W + 4 * q;
 #pragma unroll
                 for (int px = 0; px < 4; px++) p.out[((int64_t)b * HW + pix + px) * COUT + co] = acc[px];
             }
@@ -422,9 +424,9 @@ __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
             }
         }
 #endif
-        if (!more) break;
-        HF_LDS_BARRIER();                               // the gather has read P: the next band's tiles may land
-        wg = wgn;
+        if (b1 >= p.B) break;
+        HF_LDS_BARRIER();                              // the gather has read the ring: the next phase's tiles may land
+        b = b1; ph = ph1; n = n1;
     }
 }
 
@@ -462,14 +464,11 @@ bool head_fused_bf(const ConvLaunch &c) {     // which matrix pipe: bf16 x 3 unl
     return !f32 && c.gemm != DLPM_GEMM_F32;
 }
 
-size_t head_fused_lds_floats(const ConvLaunch &c, int th) {
-    return (size_t)9 * c.Cout * (hf_rows_kept(c.Hout, th) * c.Wout + 4) + 8 * (head_fused_bf(c) ? HF_STG_BF : HF_STG_F32) + 2 * c.C0;
-}
-
-int head_fused_rows(const ConvLaunch &c) {   // output rows per workgroup: the whole image when its P image fits beside the transpose patches
-    int th = c.Hout;
-    while (th > 1 && head_fused_lds_floats(c, th) * sizeof(float) > 160 * 1024) th >>= 1;
-    return th;
+// LDS: the ring of P rows + the eight transpose patches + W' + two coefficient slots
+size_t head_fused_lds_floats(const ConvLaunch &c) {
+    const int nr = 16 / (c.Wout >> 5);
+    const bool bf = head_fused_bf(c);
+    return (size_t)9 * c.Cout * ((nr + 2) * c.Wout + 4) + 8 * (bf ? HF_STG_BF : HF_STG_F32) + (size_t)c.C0 * (bf ? 48 : 32) + 4 * c.C0;
 }
 
 }  // namespace
@@ -479,11 +478,9 @@ bool head_fused_ok(const ConvLaunch &c) {
     if (off < 0) { const char *e = getenv("DLPM_NO_HEAD_FUSED"); off = (e && e[0] == '1') ? 1 : 0; }
     if (off || !c.w_hfused || c.ks != 3 || c.stride != 1 || c.ups || c.in_nchw || c.C1 != 0 || c.res0 || !c.coefA || !c.act_silu) return false;
     if (c.Cout < 1 || c.Cout > 3 || c.C0 % 32 != 0 || c.C0 > 32 * HF_MAXCH || c.Hin != c.Hout || c.Win != c.Wout) return false;
-    if ((c.Wout & 31) || c.Wout > 64 || c.Hout < 4) return false;
-    const int th = head_fused_rows(c);
-    const int min_rows = c.Hout == th ? th : th + 1;                                   // rows of P an edge band keeps
-    return th >= 4 && c.Hout % th == 0 && c.Cout * th * (c.Wout >> 2) <= 2 * HF_NT &&   // (two gather items per thread)
-           min_rows * (c.Wout >> 5) >= 8;                                              // (every wave has a tile)
+    if (c.Wout != 32 && c.Wout != 64) return false;
+    const int nr = 16 / (c.Wout >> 5);                                                 // rows per phase (16 tiles)
+    return c.Hout % nr == 0 && c.Hout / nr >= 2 && head_fused_lds_floats(c) * sizeof(float) <= 160 * 1024;
 }
 
 int64_t head_fused_weight_floats(int Cin) { return (int64_t)Cin * 32 + (int64_t)Cin * 48; }   // fp32 fragments + three bf16 planes
@@ -500,7 +497,7 @@ int relayout_weight_head_fused(const float *oihw_dev, float *dst_dev, int Cout, 
 int launch_conv_head_fused(const ConvLaunch &c, const HeadUpdate *hu, hipStream_t st) {
     HeadFusedArgs a{};
     a.h = c.src0; a.coefA = c.coefA; a.coefB = c.coefB; a.wf = c.w_hfused; a.bias = c.bias; a.out = c.out; a.out_nchw = c.out_nchw;
-    a.B = c.B; a.H = c.Hout; a.W = c.Wout; a.C = c.C0; a.TH = head_fused_rows(c);
+    a.B = c.B; a.H = c.Hout; a.W = c.Wout; a.C = c.C0;
     if (hu) a.u = *hu;
 #ifdef DLPM_PHASE_TIMING
     a.phase = phase_buffer();
@@ -509,7 +506,7 @@ int launch_conv_head_fused(const ConvLaunch &c, const HeadUpdate *hu, hipStream_
     // algorithmic bytes: the head's input once + the state read and written (or eps written)
     const double bytes = 4.0 * ((double)M * c.C0 + (double)M * c.Cout * (hu ? 2 + (hu->z ? 1 : 0) + (hu->eps_out ? 1 : 0) : 1));
     ProfScope ps(hu ? "head_fused+update" : "head_fused", 2.0 * M * c.Cout * 9.0 * c.C0, bytes, st);
-    const size_t lds = head_fused_lds_floats(c, a.TH) * sizeof(float);
+    const size_t lds = head_fused_lds_floats(c) * sizeof(float);
     const bool bf = head_fused_bf(c);
     static int ncu = 0;
     if (!ncu) {
@@ -517,8 +514,7 @@ int launch_conv_head_fused(const ConvLaunch &c, const HeadUpdate *hu, hipStream_
         DLPM_HIP(hipGetDevice(&dev));
         DLPM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     }
-    const int nwg = c.B * (c.Hout / a.TH);
-    const unsigned grid = (unsigned)(nwg < ncu ? nwg : ncu);     // persistent: one workgroup per CU walks the bands
+    const unsigned grid = (unsigned)(c.B < ncu ? c.B : ncu);     // persistent: one workgroup per CU walks the images
 #define DLPM_HF1(CO, NCH, BFV)                                                                            \
     do {                                                                                                  \
         int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_head_fused<CO, NCH, BFV>), 160 * 1024); \
@@ -545,7 +541,6 @@ int launch_conv_head_fused(const ConvLaunch &c, const HeadUpdate *hu, hipStream_
 #undef DLPM_HFC
 #undef DLPM_HF
 #undef DLPM_HF1
-#undef HF_TILE
 #undef HF_LDS_BARRIER
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
