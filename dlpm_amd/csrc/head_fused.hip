@@ -36,7 +36,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int HF_NT = 512;        // 8 waves
+constexpr int HF_NT = 256;        // 4 waves, two workgroups per CU
+constexpr int HF_NW = HF_NT / 64;
 constexpr int HF_SLD = 36;        // floats per pixel row of a wave's transpose patch (32 channels + 4: conflict-free b128 reads)
 constexpr int HF_MAXCH = 4;       // K chunks of 32 channels the register-resident weights cover (Cin <= 128)
 constexpr int HF_STG_F32 = 32 * HF_SLD;   // dwords of a wave's transpose patch, fp32 form
@@ -133,22 +134,21 @@ struct HeadFusedArgs {
 // stores -- of the NEXT chunk of its sequence (the bf16 MFMA runs beside the VALU).  All loads are unconditional (past the last image
 // they read the L2-resident weight buffer), so every wait of the loop is an exact vmcnt.
 template <int COUT, int NCH, bool BF>
-__global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
+__global__ void __launch_bounds__(HF_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) k_head_fused(HeadFusedArgs p) {
     constexpr int NV = 9 * COUT;                       // live tap channels (27)
     constexpr int C = 32 * NCH;
     constexpr int STG = BF ? HF_STG_BF : HF_STG_F32;
-    constexpr int WFL = BF ? C * 48 : C * 32;          // floats of W' this form reads
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W = p.W, H = p.H, G = gridDim.x;
-    const int tpr = W >> 5, NR = 16 / tpr, RR = NR + 2, NPH = H / NR;      // tiles per row, rows per phase, ring rows, phases per image
+    const int tpr = W >> 5, NR = 8 / tpr, RR = NR + 2, NPH = H / NR;       // tiles per row, rows per phase, ring rows, phases per image
     // P as NV planes [ring row][W] of pitch PL = RR W + 4 floats: a lane's four consecutive pixels are one 16-byte LDS access on both
     // sides (MFMA registers 4 j .. 4 j + 3 in; a gather item's pixel quad out), the + 4 spreads the 27 lanes of a store over the banks
     const int PL = RR * W + 4;
     float *P = sm;
     float *stg = sm + NV * PL + wave * STG;
-    const float *wl = sm + NV * PL + 8 * STG;          // W' (this form's fragments)
-    float *cf = sm + NV * PL + 8 * STG + WFL;          // [2 slots][2][C] GroupNorm affine: slot = parity of the image's position in this workgroup's walk
+    float *cf = sm + NV * PL + HF_NW * STG;            // [2 slots][2][C] GroupNorm affine: slot = parity of the image's position in this workgroup's walk
+    const bf16x8 *wl2 = reinterpret_cast<const bf16x8 *>(cf + 4 * C);   // bf16 form: the LOWEST plane of W' [C/32][2][64 lanes] (registers are short by 20)
     const int64_t HW = (int64_t)H * W;
     const int lp = lane >> 3, lc = lane & 7;           // load role: pixel 8 i + lp, channels 4 lc .. 4 lc + 3 of the chunk
     const int lm = lane & 31, kh = lane >> 5;          // MFMA role: pixel lm, k slot kh
@@ -157,10 +157,23 @@ __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
     const int wr_off = lp * 16 + 4 * ((lc >> 1) ^ ((lp >> 1) & 3)) + 2 * (lc & 1);      // + plane 512 + i 128
     const int rd_sw = (lm >> 1) & 3;                                                      // unit 2 j + kh -> slot ^ rd_sw
 
-    {   // W' -> LDS, once
-        const float4 *src = reinterpret_cast<const float4 *>(p.wf + (BF ? (int64_t)C * 32 : 0));
-        float4 *dst = reinterpret_cast<float4 *>(sm + NV * PL + 8 * STG);
-        for (int i = tid; i < WFL / 4; i += HF_NT) dst[i] = src[i];
+    // ---- W' fragments: registers for the whole kernel
+    float4 bw[BF ? 1 : NCH][4];
+    bf16x8 bwb[BF ? NCH : 1][2][2];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        if constexpr (BF) {
+            const bf16x8 *wb = reinterpret_cast<const bf16x8 *>(p.wf + (int64_t)C * 32);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++) bwb[c][j][pl] = wb[((c * 2 + j) * 3 + pl) * 64 + lane];
+                if (wave == ((c * 2 + j) & (HF_NW - 1))) const_cast<bf16x8 *>(wl2)[(c * 2 + j) * 64 + lane] = wb[((c * 2 + j) * 3 + 2) * 64 + lane];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) bw[c][q] = reinterpret_cast<const float4 *>(p.wf)[(c * 4 + q) * 64 + lane];
+        }
     }
     // the coefficients of an image: threads 0 .. C / 2 - 1 fetch one float4 each (A then B) ...
     auto fetch_coefs = [&](int b) __attribute__((always_inline)) {
@@ -173,22 +186,22 @@ __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
     };
     // tile s (0 / 1) of phase ph of image b for this wave; past the last image a harmless L2-resident address (the loads stay unconditional)
     auto tile_src = [&](int b, int ph, int s) __attribute__((always_inline)) {
-        const int id = wave + 8 * s, y = ph * NR + id / tpr, x0 = (id - (id / tpr) * tpr) * 32;
+        const int id = wave + HF_NW * s, y = ph * NR + id / tpr, x0 = (id - (id / tpr) * tpr) * 32;
         return b < p.B ? p.h + (((int64_t)b * H + y) * W + x0) * C + 4 * lc : p.wf + 4 * lc;
     };
-    float4 xb[2][NCH][4];
-    auto load_chunk = [&](const float *src, int s, int c) __attribute__((always_inline)) {
+    float4 xb[NCH][4];
+    auto load_chunk = [&](const float *src, int c) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; i++)
-            if (!(HF_ABLATE & 8)) xb[s][c][i] = *reinterpret_cast<const float4 *>(src + 32 * c + (int64_t)(8 * i + lp) * C);
+            if (!(HF_ABLATE & 8)) xb[c][i] = *reinterpret_cast<const float4 *>(src + 32 * c + (int64_t)(8 * i + lp) * C);
     };
-    // stage(s, c, slot): GroupNorm affine + SiLU (+ the three-plane split) of buffer (s, c) into the wave's patch
-    auto stage = [&](int s, int c, const float *cfs) __attribute__((always_inline)) {
+    // stage(c, slot): GroupNorm affine + SiLU (+ the three-plane split) of buffer c into the wave's patch
+    auto stage = [&](int c, const float *cfs) __attribute__((always_inline)) {
         const float4 cA = *reinterpret_cast<const float4 *>(cfs + 32 * c + 4 * lc), cB = *reinterpret_cast<const float4 *>(cfs + C + 32 * c + 4 * lc);
         const f32x2 a01 = {cA.x, cA.y}, a23 = {cA.z, cA.w}, b01 = {cB.x, cB.y}, b23 = {cB.z, cB.w};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const float4 xr = xb[s][c][i];
+            const float4 xr = xb[c][i];
             f32x2 v01, v23;
             if (HF_ABLATE & 2) { v01 = f32x2{xr.x, xr.y} + a01; v23 = f32x2{xr.z, xr.w} + b23; }
             else { v01 = hf_act2(f32x2{xr.x, xr.y}, a01, b01); v23 = hf_act2(f32x2{xr.z, xr.w}, a23, b23); }
@@ -231,18 +244,17 @@ __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
     // ---- the walk: position (image b, phase ph); n = the image's index in this workgroup's sequence (its coefficient slot is n & 1)
     int b = blockIdx.x, ph = 0, n = 0;
     put_coefs(fetch_coefs(b), 0);
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-        const float *src = tile_src(b, 0, s);
+    {
+        const float *src = tile_src(b, 0, 0);
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
-            load_chunk(src, s, c);
+            load_chunk(src, c);
             __builtin_amdgcn_sched_barrier(0);         // (issue order = consumption order: the loop's vmcnt waits count on it)
         }
     }
     HF_LDS_BARRIER();
-    stage(0, 0, cf);
-    load_chunk(tile_src(NPH > 1 ? b : b + G, NPH > 1 ? 1 : 0, 0), 0, 0);
+    stage(0, cf);
+    load_chunk(tile_src(b, 0, 1), 0);
     HF_LDS_EXCHANGE();
     __builtin_amdgcn_sched_barrier(0);
     for (;;) {
@@ -252,10 +264,9 @@ __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
         // the next two positions of the walk
         const bool lastph = ph + 1 == NPH;
         const int b1 = lastph ? b + G : b, ph1 = lastph ? 0 : ph + 1, n1 = lastph ? n + 1 : n;
-        const bool lastph1 = ph1 + 1 == NPH;
-        const int b2 = lastph1 ? b1 + G : b1, ph2 = lastph1 ? 0 : ph1 + 1;
         const float *cf0 = cf + (n & 1) * 2 * C, *cf1 = cf + (n1 & 1) * 2 * C;
-        const float *nx0 = tile_src(b1, ph1, 0), *nx1 = tile_src(b1, ph1, 1), *nxx = tile_src(b2, ph2, 0);
+        // the wave's next three tiles after (ph, 0): t1 = (ph, 1), t2 / t3 = the two of the next position
+        const float *t1 = tile_src(b, ph, 1), *t2 = tile_src(b1, ph1, 0), *t3 = tile_src(b1, ph1, 1);
 
         // the gather covers the rows whose P rows will be complete, g_lo .. g_hi - 1; an item = (channel, row, 4 pixels), one per thread
         const int g_lo = ph == 0 ? 0 : ph * NR - 1, g_hi = lastph ? H : (ph + 1) * NR - 1;
@@ -277,6 +288,13 @@ __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
             for (int r = 0; r < 16; r++) acc[r] = 0.f;
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
+                // the next chunk of the wave's sequence: chunk c + 1 of this tile, else chunk 0 of the next tile (already in its buffer);
+                // the buffer is then reloaded from the tile after the one just staged
+                auto stage_next = [&]() __attribute__((always_inline)) {
+                    if (c + 1 < NCH) { stage(c + 1, cf0); load_chunk(s == 0 ? t1 : t2, c + 1); }
+                    else if (s == 0) { stage(0, cf0); load_chunk(t2, 0); }
+                    else { stage(0, cf1); load_chunk(t3, 0); }
+                };
                 if constexpr (BF) {
                     bf16x8 A[2][3];
 #pragma unroll
@@ -286,39 +304,30 @@ __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
                             A[j][pl] = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const uint32_t *>(stg) + pl * 512 + lm * 16 +
                                                                          4 * ((2 * j + kh) ^ rd_sw));
                     HF_LDS_EXCHANGE();
-                    if (c + 1 < NCH) { stage(s, c + 1, cf0); load_chunk(s == 0 ? nx0 : nx1, s, c + 1); }
-                    else if (s == 0) { stage(1, 0, cf0); load_chunk(nx1, 1, 0); }
-                    else { stage(0, 0, cf1); load_chunk(nxx, 0, 0); }
+                    stage_next();
 #pragma unroll
-                    for (int j = 0; j < 2; j++) {      // small terms first (conv_split.hip's order); W' fragments straight from LDS
+                    for (int j = 0; j < 2; j++) {      // small terms first (conv_split.hip's order)
                         if (HF_ABLATE & 1) { asm volatile("" :: "v"(A[j][0]), "v"(A[j][1]), "v"(A[j][2])); continue; }
-                        bf16x8 Bf[3];
-#pragma unroll
-                        for (int pl = 0; pl < 3; pl++) Bf[pl] = reinterpret_cast<const bf16x8 *>(wl)[((c * 2 + j) * 3 + pl) * 64 + lane];
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][2], Bf[0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][1], Bf[1], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], Bf[2], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][1], Bf[0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], Bf[1], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], Bf[0], acc, 0, 0, 0);
+                        const bf16x8 b2 = wl2[(c * 2 + j) * 64 + lane];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][2], bwb[c][j][0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][1], bwb[c][j][1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], b2, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][1], bwb[c][j][0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], bwb[c][j][1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], bwb[c][j][0], acc, 0, 0, 0);
                     }
                 } else {
-                    float4 a[4], bq[4];
+                    float4 a[4];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        a[q] = *reinterpret_cast<const float4 *>(stg + lm * HF_SLD + 8 * q + 4 * kh);
-                        bq[q] = reinterpret_cast<const float4 *>(wl)[(c * 4 + q) * 64 + lane];
-                    }
+                    for (int q = 0; q < 4; q++) a[q] = *reinterpret_cast<const float4 *>(stg + lm * HF_SLD + 8 * q + 4 * kh);
                     HF_LDS_EXCHANGE();
-                    if (c + 1 < NCH) { stage(s, c + 1, cf0); load_chunk(s == 0 ? nx0 : nx1, s, c + 1); }
-                    else if (s == 0) { stage(1, 0, cf0); load_chunk(nx1, 1, 0); }
-                    else { stage(0, 0, cf1); load_chunk(nxx, 0, 0); }
+                    stage_next();
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bq[q].x, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bq[q].y, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bq[q].z, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bq[q].w, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bw[c][q].x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bw[c][q].y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bw[c][q].z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bw[c][q].w, acc, 0, 0, 0);
                     }
                 }
                 HF_LDS_EXCHANGE();
@@ -326,7 +335,7 @@ __global__ void __launch_bounds__(HF_NT, 1) k_head_fused(HeadFusedArgs p) {
             }
             // D layout of the 32x32 MFMA: register i holds row 8 (i / 4) + 4 kh + (i % 4) (pixel), column lm (tap channel)
             if (lm < NV) {
-                const int id = wave + 8 * s, y = ph * NR + id / tpr, x0 = (id - (id / tpr) * tpr) * 32;
+                const int id = wave + HF_NW * s, y = ph * NR + id / tpr, x0 = (id - (id / tpr) * tpr) * 32;
                 float *dst = P + lm * PL + (y % RR) * W + x0 + 4 * kh;
 #pragma unroll
                 for (int j = 0; j < 4; j++)
@@ -464,11 +473,10 @@ bool head_fused_bf(const ConvLaunch &c) {     // which matrix pipe: bf16 x 3 unl
     return !f32 && c.gemm != DLPM_GEMM_F32;
 }
 
-// LDS: the ring of P rows + the eight transpose patches + W' + two coefficient slots
+// LDS: the ring of P rows + the four transpose patches + two coefficient slots
 size_t head_fused_lds_floats(const ConvLaunch &c) {
-    const int nr = 16 / (c.Wout >> 5);
-    const bool bf = head_fused_bf(c);
-    return (size_t)9 * c.Cout * ((nr + 2) * c.Wout + 4) + 8 * (bf ? HF_STG_BF : HF_STG_F32) + (size_t)c.C0 * (bf ? 48 : 32) + 4 * c.C0;
+    const int nr = 8 / (c.Wout >> 5);
+    return (size_t)9 * c.Cout * ((nr + 2) * c.Wout + 4) + HF_NW * (head_fused_bf(c) ? HF_STG_BF : HF_STG_F32) + 4 * c.C0 + (c.C0 / 32) * 2 * 64 * 4;
 }
 
 }  // namespace
@@ -479,8 +487,8 @@ bool head_fused_ok(const ConvLaunch &c) {
     if (off || !c.w_hfused || c.ks != 3 || c.stride != 1 || c.ups || c.in_nchw || c.C1 != 0 || c.res0 || !c.coefA || !c.act_silu) return false;
     if (c.Cout < 1 || c.Cout > 3 || c.C0 % 32 != 0 || c.C0 > 32 * HF_MAXCH || c.Hin != c.Hout || c.Win != c.Wout) return false;
     if (c.Wout != 32 && c.Wout != 64) return false;
-    const int nr = 16 / (c.Wout >> 5);                                                 // rows per phase (16 tiles)
-    return c.Hout % nr == 0 && c.Hout / nr >= 2 && head_fused_lds_floats(c) * sizeof(float) <= 160 * 1024;
+    const int nr = 8 / (c.Wout >> 5);                                                  // rows per phase (8 tiles)
+    return c.Hout % nr == 0 && c.Hout / nr >= 2 && head_fused_lds_floats(c) * sizeof(float) <= 80 * 1024;   // two workgroups per CU
 }
 
 int64_t head_fused_weight_floats(int Cin) { return (int64_t)Cin * 32 + (int64_t)Cin * 48; }   // fp32 fragments + three bf16 planes
@@ -514,7 +522,7 @@ int launch_conv_head_fused(const ConvLaunch &c, const HeadUpdate *hu, hipStream_
         DLPM_HIP(hipGetDevice(&dev));
         DLPM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     }
-    const unsigned grid = (unsigned)(c.B < ncu ? c.B : ncu);     // persistent: one workgroup per CU walks the images
+    const unsigned grid = (unsigned)(c.B < 2 * ncu ? c.B : 2 * ncu);     // persistent: two workgroups per CU walk the images
 #define DLPM_HF1(CO, NCH, BFV)                                                                            \
     do {                                                                                                  \
         int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_head_fused<CO, NCH, BFV>), 160 * 1024); \

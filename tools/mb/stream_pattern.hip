@@ -3,6 +3,7 @@
 //   pattern 0: the kernel's -- a load instruction = 8 pixels x 128 B (32 channels), 512-B stride; the 4 channel chunks of a tile are
 //              separate instructions
 //   pattern 1: a load instruction = 1 KB contiguous (2 whole pixels)
+//   pattern 3: a load instruction = 32 pixels x 32 B (lane = pixel + 32 k-half, 16 B each): the MFMA's own operand layout, no transposition
 //   pattern 2: as 0, but the chunk loads of a tile are issued chunk-interleaved with ALU delay between them (as the pipelined kernel does)
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/mb/stream_pattern tools/mb/stream_pattern.hip
 #include <hip/hip_runtime.h>
@@ -18,6 +19,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) k(const float *h, float *out, i
     auto src = [&](int wg, int t) { return h + ((int64_t)wg * tiles_per_wg + t) * 4096; };
     auto ld = [&](const float *p, int j) {
         if (PAT == 1) return *reinterpret_cast<const float4 *>(p + j * 256 + lane * 4);
+        if (PAT == 3) return *reinterpret_cast<const float4 *>(p + (lane & 31) * 128 + j * 8 + (lane >> 5) * 4);
         const int c = j >> 2, i = j & 3;
         return *reinterpret_cast<const float4 *>(p + 32 * c + (8 * i + lp) * 128 + 4 * lc);
     };
@@ -68,6 +70,8 @@ int main() {
     run<2, 8>("... + 16 dependent rcp between the chunks", h, out, nimg, 16);
     run<2, 8>("... + 64 dependent rcp between the chunks", h, out, nimg, 64);
     run<2, 8>("... + 128 dependent rcp between the chunks", h, out, nimg, 128);
+    run<3, 8>("32 pixels x 32 B per load instruction (MFMA operand layout), 8 waves", h, out, nimg, 0);
+    run<3, 4>("32 pixels x 32 B per load instruction (MFMA operand layout), 4 waves", h, out, nimg, 0);
     run<1, 16>("1 KB contiguous per load instruction, 16 waves", h, out, nimg, 0);
     run<0, 16>("8 pixels x 128 B per load instruction, 16 waves", h, out, nimg, 0);
     run<1, 4>("1 KB contiguous per load instruction, 4 waves", h, out, nimg, 0);
