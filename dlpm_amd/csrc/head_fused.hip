@@ -6,27 +6,31 @@
 // Round 3 split the head into a 1x1 GEMM onto its 9 Cout tap channels  P = act(h) W'  (every input line fetched once) and a 9-point
 // gather over P that carried the update: the pair wrote and re-read the 113 MB of P that the algorithm does not have (0.195 ms,
 // 0.37 of the HBM roof on the bytes the algorithm does have: the head's input once + 12 B per state element).  Here P never
-// leaves the CU: one workgroup owns a band of TH output rows of one image (the WHOLE 32x32 image for the CIFAR shape: no halo
-// rows to recompute), its 8 waves walk the band's rows as 32-pixel MFMA tiles
-//     P[pixel][n = tap Cout + co] = sum_ci act(h)[pixel][ci] W'[ci][n]        (v_mfma_f32_32x32x2_f32, 27 of 32 columns live)
-// and drop them into an LDS image [rows + 2][W][9 Cout]; after one barrier the gather  eps[p, co] = b + sum_tap P[p + off(tap)][tap, co]
-// runs from LDS and applies the update to the NCHW state in place with the Philox counters of k_update_rows.  HBM traffic = the
-// algorithmic bytes (+ the halo rows of a band when the image does not fit: 64x64).
+// leaves the CU.
 //
-// A wave's tile: 32 consecutive pixels of one row x 32 input channels per K chunk.  Global loads are line-coalesced (8 lanes x 16
-// bytes = the 32 channels of a pixel), GroupNorm affine + SiLU are applied in registers, and a wave-private 4.6-KB LDS patch turns
-// [pixel][channel] into the MFMA's A layout (lane = pixel, k slot = channel): the k index of an MFMA is free as long as A and B
-// agree, so slot kh of MFMA (q, e) is channel 32 c + 8 q + 4 kh + e and one ds_read_b128 feeds four MFMAs.  W' sits in registers
-// for the whole kernel in that fragment order (64 VGPRs at 128 channels).
-//
-// BF = true (the default pipe; DLPM_HEAD_F32=1 or the fp32 GEMM policy take the form above): the same GEMM on the bf16 matrix pipe with
-// conv_split.hip's exact three-plane split -- act(h) is cut into three bf16 planes in registers right after the SiLU (and + subtract twice,
-// v_perm packs), W' is cut once at finalize, six v_mfma_f32_32x32x16_bf16 per 16 channels replace eight fp32 MFMAs per 16 channels at a
-// quarter of the cycles each (the fp32 form was SIMD-issue-bound: fp32 MFMAs 40 % + VALU 36 % of its cycles, and the fp32 MFMA shares
-// the vector lanes; the bf16 one runs beside the VALU).  The transpose patch holds [plane][pixel][32 channels] bf16 with the 16-byte
-// units of a pixel row XOR-swizzled by (pixel >> 1) & 3 (no padding: P + the patches fill the 160 KB).
+// THE KERNEL'S SHAPE.  Persistent four-wave workgroups, two per CU (they drift apart: while one gathers, the other streams), each
+// walking images b = blockIdx.x, + gridDim.x, ...  An image is cut into PHASES of 8 tiles (a tile = 32 pixels of one row x all
+// channels; NR = 8 / (W / 32) rows), two tiles per wave:
+//   tile steps:  the phase's rows of  P[n = tap Cout + co][row][x] = sum_ci act(h)[row][x][ci] W'[ci][n]  into an LDS RING of NR + 2 rows
+//   barrier, gather: the 9-point sums + the reverse update for the rows whose three P rows are complete -- rows ph NR - 1 .. (ph + 1) NR - 2
+//                    (the image's first and last phase take the border row as well); the ring keeps the two rows the next phase needs
+//   barrier
+// so no row of P is computed twice and P is 35 KB.
+// NO TRANSPOSITION.  The k index of an MFMA is free as long as A and B agree, so the input is loaded in the MFMA's own operand layout:
+// lane = (pixel lm, k-half kh) reads the 16 bytes of channels 8 j + 4 kh .. + 3 of its pixel (load j; a load instruction = 32 pixels x
+// 32 contiguous bytes -- tools/mb/stream_pattern.hip: 5.5-5.9 TB/s, the same as whole lines), GroupNorm affine + SiLU run on the
+// registers, and loads 2 m, 2 m + 1 ARE the lane's eight k slots of K-step m (16 channels).  (The earlier forms loaded line-coalesced
+// and turned [pixel][channel] around through a wave-private LDS patch: 18 LDS operations and two dependent LDS round trips per 32
+// channels in front of every MFMA chain.)  W' -- in that slot order -- and the GroupNorm coefficients sit in LDS (b128 reads, the same
+// for every wave), which leaves the registers to the input: TWO tiles in flight per wave (32 KB; buffer s = the wave's s-th tile of
+// a phase, each load reissued for the same tile of the NEXT phase as soon as its K-step has been staged).
+// bf16 form (the default pipe; DLPM_HEAD_F32=1 or the fp32 GEMM policy take the fp32 MFMA): conv_split.hip's exact three-plane split --
+// act(h) is cut into three bf16 planes in registers right after the SiLU (and + subtract twice, v_perm packs), W' is cut once at
+// finalize, six v_mfma_f32_32x32x16_bf16 per K-step replace eight v_mfma_f32_32x32x2_f32 at a quarter of the cycles each, and the bf16
+// MFMA runs BESIDE the VALU (the fp32 one shares its lanes): K-step m's MFMAs are issued next to the staging of K-step m + 1.
+// All loads are unconditional (past the last image they read the L2-resident weight buffer) and the update's stores are hidden from
+// the compiler (hf_store4), so every wait of the loop is an exact vmcnt count.
 #include "conv.h"
-#include <type_traits>
 #include "philox.h"
 
 namespace dlpm {
@@ -35,13 +39,11 @@ namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t hf_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int HF_NT = 256;        // 4 waves, two workgroups per CU
 constexpr int HF_NW = HF_NT / 64;
-constexpr int HF_SLD = 36;        // floats per pixel row of a wave's transpose patch (32 channels + 4: conflict-free b128 reads)
-constexpr int HF_MAXCH = 4;       // K chunks of 32 channels the register-resident weights cover (Cin <= 128)
-constexpr int HF_STG_F32 = 32 * HF_SLD;   // dwords of a wave's transpose patch, fp32 form
-constexpr int HF_STG_BF = 3 * 32 * 16;    // ... bf16 form: [plane][pixel][32 bf16]
+constexpr int HF_MAXCH = 4;       // Cin <= 128 (registers: two tiles of input per wave)
 constexpr float HF_LOG2E = 1.44269504088896340736f;
 #ifndef HF_ABLATE          // timing-only developer builds (wrong results): 1 no MFMAs, 2 no SiLU / split arithmetic, 4 no gather, 8 no reloads
 #define HF_ABLATE 0
@@ -88,15 +90,8 @@ __device__ __forceinline__ void hf_store4(float *ptr, float4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(ptr), "v"(d) : "memory");
 }
 
-#define HF_LDS_EXCHANGE()                                             \
-    do {                                                              \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); \
-        __builtin_amdgcn_wave_barrier();                              \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local"); \
-    } while (0)
-
 // workgroup barrier that orders LDS only: __syncthreads() is a workgroup-scope fence over ALL address spaces, i.e. s_waitcnt vmcnt(0) --
-// every wave would sit out the write acknowledgements of its update stores and the landing of its prefetch at each barrier
+// every wave would sit out the write acknowledgements of its update stores and the landing of its read-ahead at each barrier
 #define HF_LDS_BARRIER()                                              \
     do {                                                              \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); \
@@ -107,7 +102,7 @@ __device__ __forceinline__ void hf_store4(float *ptr, float4 v) {
 struct HeadFusedArgs {
     const float *h;               // [B][H][W][C] NHWC
     const float *coefA, *coefB;   // [B][C] GroupNorm affine (SiLU follows)
-    const float *wf;              // W' in fragment order: fp32 [C/32][4][64][4], behind it the bf16 planes [C/32][2][3][64][8]
+    const float *wf;              // W' in slot order: fp32 [C/8][64][4], behind it the bf16 planes [C/16][3][64][8]
     const float *bias;            // [Cout]
     float *out;                   // eps (plain forward): NCHW [B][Cout][H][W] or NHWC
     int out_nchw;
@@ -118,26 +113,12 @@ struct HeadFusedArgs {
 #endif
 };
 
-// THE KERNEL'S SHAPE (round 4, third form).  One persistent workgroup per CU walks images b = blockIdx.x, + gridDim.x, ...; an image
-// is cut into PHASES of 16 tiles (32 pixels of one row x all channels each; NR = 16 / (W / 32) rows), two tiles per wave:
-//   tile steps:  the phase's rows of  P[n = tap Cout + co][row][x] = sum_ci act(h)[row][x][ci] W'[ci][n]  into an LDS RING of NR + 2 rows
-//   barrier, gather: the 9-point sums + the reverse update for the rows whose three P rows are complete -- rows ph NR - 1 .. (ph + 1) NR - 2
-//                    (the image's first and last phase take the border row as well); the ring keeps the two rows the next phase needs
-//   barrier
-// so no row of P is computed twice (the earlier band form recomputed 2 of 10 rows for 64 x 64 images) and P is 62 KB instead of 111.
-// What that frees goes to the operands: W' sits in LDS (24 KB, b128 reads in fragment order, same for every wave) instead of 96 VGPRs,
-// and the registers hold TWO tiles of input in flight per wave (32 KB; 256 KB per CU): buffer s = the wave's s-th tile of a phase,
-// reloaded chunk by chunk with the same tile of the NEXT phase as soon as a chunk has been staged -- seven steps ahead.  (With one tile
-// ahead, PMC showed the SIMDs idle 42 % of the cycles: both waves of a SIMD waiting for HBM.)
-// A wave's instruction stream is one pipeline of STEPS that runs across tiles, phases and images: step (s, c) reads chunk c's A
-// fragments from its patch, then issues chunk c's MFMAs next to the staging -- GroupNorm affine, SiLU, three-plane split, patch
-// stores -- of the NEXT chunk of its sequence (the bf16 MFMA runs beside the VALU).  All loads are unconditional (past the last image
-// they read the L2-resident weight buffer), so every wait of the loop is an exact vmcnt.
+// NCH = C / 32, a compile-time constant: everything below is straight-line code per phase
 template <int COUT, int NCH, bool BF>
 __global__ void __launch_bounds__(HF_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) k_head_fused(HeadFusedArgs p) {
     constexpr int NV = 9 * COUT;                       // live tap channels (27)
-    constexpr int C = 32 * NCH;
-    constexpr int STG = BF ? HF_STG_BF : HF_STG_F32;
+    constexpr int C = 32 * NCH, NK = C / 16, NL = C / 8;   // K-steps and loads per tile
+    constexpr int WFL = BF ? C * 48 : C * 32;          // floats of W' this form reads
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W = p.W, H = p.H, G = gridDim.x;
@@ -146,34 +127,15 @@ __global__ void __launch_bounds__(HF_NT) __attribute__((amdgpu_waves_per_eu(2, 2
     // sides (MFMA registers 4 j .. 4 j + 3 in; a gather item's pixel quad out), the + 4 spreads the 27 lanes of a store over the banks
     const int PL = RR * W + 4;
     float *P = sm;
-    float *stg = sm + NV * PL + wave * STG;
-    float *cf = sm + NV * PL + HF_NW * STG;            // [2 slots][2][C] GroupNorm affine: slot = parity of the image's position in this workgroup's walk
-    const bf16x8 *wl2 = reinterpret_cast<const bf16x8 *>(cf + 4 * C);   // bf16 form: the LOWEST plane of W' [C/32][2][64 lanes] (registers are short by 20)
+    const float *wl = sm + NV * PL;                    // W' (this form's slot order)
+    float *cf = sm + NV * PL + WFL;                    // [2 slots][2][C] GroupNorm affine: slot = parity of the image's position in this workgroup's walk
     const int64_t HW = (int64_t)H * W;
-    const int lp = lane >> 3, lc = lane & 7;           // load role: pixel 8 i + lp, channels 4 lc .. 4 lc + 3 of the chunk
-    const int lm = lane & 31, kh = lane >> 5;          // MFMA role: pixel lm, k slot kh
-    // bf16 form, dword offsets into the wave's patch: a pixel row is 16 dwords = four 16-byte units (8 channels each), unit u of pixel
-    // px sits at slot u ^ ((px >> 1) & 3) -- the 8 lanes of a b128 read phase (8 consecutive pixels, same u) then cover all 32 banks
-    const int wr_off = lp * 16 + 4 * ((lc >> 1) ^ ((lp >> 1) & 3)) + 2 * (lc & 1);      // + plane 512 + i 128
-    const int rd_sw = (lm >> 1) & 3;                                                      // unit 2 j + kh -> slot ^ rd_sw
+    const int lm = lane & 31, kh = lane >> 5;          // pixel lm of the tile, k-half kh
 
-    // ---- W' fragments: registers for the whole kernel
-    float4 bw[BF ? 1 : NCH][4];
-    bf16x8 bwb[BF ? NCH : 1][2][2];
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-        if constexpr (BF) {
-            const bf16x8 *wb = reinterpret_cast<const bf16x8 *>(p.wf + (int64_t)C * 32);
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-#pragma unroll
-                for (int pl = 0; pl < 2; pl++) bwb[c][j][pl] = wb[((c * 2 + j) * 3 + pl) * 64 + lane];
-                if (wave == ((c * 2 + j) & (HF_NW - 1))) const_cast<bf16x8 *>(wl2)[(c * 2 + j) * 64 + lane] = wb[((c * 2 + j) * 3 + 2) * 64 + lane];
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; q++) bw[c][q] = reinterpret_cast<const float4 *>(p.wf)[(c * 4 + q) * 64 + lane];
-        }
+    {   // W' -> LDS, once
+        const float4 *src = reinterpret_cast<const float4 *>(p.wf + (BF ? (int64_t)C * 32 : 0));
+        float4 *dst = reinterpret_cast<float4 *>(sm + NV * PL);
+        for (int i = tid; i < WFL / 4; i += HF_NT) dst[i] = src[i];
     }
     // the coefficients of an image: threads 0 .. C / 2 - 1 fetch one float4 each (A then B) ...
     auto fetch_coefs = [&](int b) __attribute__((always_inline)) {
@@ -184,42 +146,76 @@ __global__ void __launch_bounds__(HF_NT) __attribute__((amdgpu_waves_per_eu(2, 2
     auto put_coefs = [&](float4 v, int slot) __attribute__((always_inline)) {
         if (tid < C / 2) *reinterpret_cast<float4 *>(cf + slot * 2 * C + 4 * tid) = v;
     };
-    // tile s (0 / 1) of phase ph of image b for this wave; past the last image a harmless L2-resident address (the loads stay unconditional)
+    // tile s (0 / 1) of phase ph of image b for this wave: this lane's pixel, + its k-half; past the last image a harmless L2-resident
+    // address (the loads stay unconditional)
     auto tile_src = [&](int b, int ph, int s) __attribute__((always_inline)) {
         const int id = wave + HF_NW * s, y = ph * NR + id / tpr, x0 = (id - (id / tpr) * tpr) * 32;
-        return b < p.B ? p.h + (((int64_t)b * H + y) * W + x0) * C + 4 * lc : p.wf + 4 * lc;
+        return b < p.B ? p.h + (((int64_t)b * H + y) * W + x0 + lm) * C + 4 * kh : p.wf + 4 * lane;
     };
-    float4 xb[NCH][4];
-    auto load_chunk = [&](const float *src, int c) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (!(HF_ABLATE & 8)) xb[c][i] = *reinterpret_cast<const float4 *>(src + 32 * c + (int64_t)(8 * i + lp) * C);
+    float4 xb[2][NL];
+    auto load2 = [&](const float *src, int s, int m) __attribute__((always_inline)) {       // the two loads of K-step m
+        if (!(HF_ABLATE & 8)) {
+            xb[s][2 * m] = *reinterpret_cast<const float4 *>(src + 16 * m);
+            xb[s][2 * m + 1] = *reinterpret_cast<const float4 *>(src + 16 * m + 8);
+        }
     };
-    // stage(c, slot): GroupNorm affine + SiLU (+ the three-plane split) of buffer c into the wave's patch
-    auto stage = [&](int c, const float *cfs) __attribute__((always_inline)) {
-        const float4 cA = *reinterpret_cast<const float4 *>(cfs + 32 * c + 4 * lc), cB = *reinterpret_cast<const float4 *>(cfs + C + 32 * c + 4 * lc);
-        const f32x2 a01 = {cA.x, cA.y}, a23 = {cA.z, cA.w}, b01 = {cB.x, cB.y}, b23 = {cB.z, cB.w};
+    // stage(s, m, slot): GroupNorm affine + SiLU of the lane's eight values of K-step m -> its A operand: three bf16 planes, or the
+    // eight fp32 values
+    struct AFrag { hf_u32x4 pl[3]; };
+    auto stage = [&](int s, int m, const float *cfs) __attribute__((always_inline)) {
+        AFrag a;
+        uint32_t q[3][4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const float4 xr = xb[c][i];
+        for (int h = 0; h < 2; h++) {
+            const float4 xr = xb[s][2 * m + h];
+            const float4 cA = *reinterpret_cast<const float4 *>(cfs + 16 * m + 8 * h + 4 * kh);
+            const float4 cB = *reinterpret_cast<const float4 *>(cfs + C + 16 * m + 8 * h + 4 * kh);
             f32x2 v01, v23;
-            if (HF_ABLATE & 2) { v01 = f32x2{xr.x, xr.y} + a01; v23 = f32x2{xr.z, xr.w} + b23; }
-            else { v01 = hf_act2(f32x2{xr.x, xr.y}, a01, b01); v23 = hf_act2(f32x2{xr.z, xr.w}, a23, b23); }
+            if (HF_ABLATE & 2) { v01 = f32x2{xr.x, xr.y} + f32x2{cA.x, cA.y}; v23 = f32x2{xr.z, xr.w} + f32x2{cB.z, cB.w}; }
+            else {
+                v01 = hf_act2(f32x2{xr.x, xr.y}, f32x2{cA.x, cA.y}, f32x2{cB.x, cB.y});
+                v23 = hf_act2(f32x2{xr.z, xr.w}, f32x2{cA.z, cA.w}, f32x2{cB.z, cB.w});
+            }
             if constexpr (BF) {
-                uint32_t q0[2], q1[2], q2[2];
                 if (HF_ABLATE & 2) {
-                    q0[0] = q1[0] = q2[0] = __float_as_uint(v01.x) ^ __float_as_uint(v01.y);
-                    q0[1] = q1[1] = q2[1] = __float_as_uint(v23.x) ^ __float_as_uint(v23.y);
+                    q[0][2 * h] = q[1][2 * h] = q[2][2 * h] = __float_as_uint(v01.x) ^ __float_as_uint(v01.y);
+                    q[0][2 * h + 1] = q[1][2 * h + 1] = q[2][2 * h + 1] = __float_as_uint(v23.x) ^ __float_as_uint(v23.y);
                 } else {
-                    hf_split2(v01.x, v01.y, q0[0], q1[0], q2[0]);
-                    hf_split2(v23.x, v23.y, q0[1], q1[1], q2[1]);
+                    hf_split2(v01.x, v01.y, q[0][2 * h], q[1][2 * h], q[2][2 * h]);
+                    hf_split2(v23.x, v23.y, q[0][2 * h + 1], q[1][2 * h + 1], q[2][2 * h + 1]);
                 }
-                uint32_t *dst = reinterpret_cast<uint32_t *>(stg) + wr_off + i * 128;
-                *reinterpret_cast<uint2 *>(dst) = make_uint2(q0[0], q0[1]);
-                *reinterpret_cast<uint2 *>(dst + 512) = make_uint2(q1[0], q1[1]);
-                *reinterpret_cast<uint2 *>(dst + 1024) = make_uint2(q2[0], q2[1]);
-            } else {
-                *reinterpret_cast<float4 *>(stg + (8 * i + lp) * HF_SLD + 4 * lc) = make_float4(v01.x, v01.y, v23.x, v23.y);
+            } else {   // fp32 form: planes 0 / 1 carry the eight values themselves
+                q[h][0] = __float_as_uint(v01.x); q[h][1] = __float_as_uint(v01.y);
+                q[h][2] = __float_as_uint(v23.x); q[h][3] = __float_as_uint(v23.y);
+                q[2][2 * h] = q[2][2 * h + 1] = 0;
+            }
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) a.pl[pl] = hf_u32x4{q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
+        return a;
+    };
+    // K-step m's MFMAs: W' fragments straight from LDS
+    auto mfmas = [&](floatx16 &acc, const AFrag &a, int m) __attribute__((always_inline)) {
+        if (HF_ABLATE & 1) { asm volatile("" :: "v"(a.pl[0]), "v"(a.pl[1]), "v"(a.pl[2])); return; }
+        if constexpr (BF) {
+            bf16x8 Bf[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) Bf[pl] = reinterpret_cast<const bf16x8 *>(wl)[(m * 3 + pl) * 64 + lane];
+            const bf16x8 A0 = __builtin_bit_cast(bf16x8, a.pl[0]), A1 = __builtin_bit_cast(bf16x8, a.pl[1]), A2 = __builtin_bit_cast(bf16x8, a.pl[2]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, Bf[0], acc, 0, 0, 0);      // small terms first (conv_split.hip's order)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bf[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bf[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bf[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bf[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bf[0], acc, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const float4 bq = reinterpret_cast<const float4 *>(wl)[(2 * m + h) * 64 + lane];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.pl[h][0]), bq.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.pl[h][1]), bq.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.pl[h][2]), bq.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.pl[h][3]), bq.w, acc, 0, 0, 0);
             }
         }
     };
@@ -244,18 +240,18 @@ __global__ void __launch_bounds__(HF_NT) __attribute__((amdgpu_waves_per_eu(2, 2
     // ---- the walk: position (image b, phase ph); n = the image's index in this workgroup's sequence (its coefficient slot is n & 1)
     int b = blockIdx.x, ph = 0, n = 0;
     put_coefs(fetch_coefs(b), 0);
-    {
-        const float *src = tile_src(b, 0, 0);
 #pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            load_chunk(src, c);
+    for (int s = 0; s < 2; s++) {
+        const float *src = tile_src(b, 0, s);
+#pragma unroll
+        for (int m = 0; m < NK; m++) {
+            load2(src, s, m);
             __builtin_amdgcn_sched_barrier(0);         // (issue order = consumption order: the loop's vmcnt waits count on it)
         }
     }
     HF_LDS_BARRIER();
-    stage(0, cf);
-    load_chunk(tile_src(b, 0, 1), 0);
-    HF_LDS_EXCHANGE();
+    AFrag acur = stage(0, 0, cf);
+    load2(tile_src(b, 1, 0), 0, 0);                    // (NPH >= 2)
     __builtin_amdgcn_sched_barrier(0);
     for (;;) {
 #ifdef DLPM_PHASE_TIMING
@@ -264,73 +260,35 @@ __global__ void __launch_bounds__(HF_NT) __attribute__((amdgpu_waves_per_eu(2, 2
         // the next two positions of the walk
         const bool lastph = ph + 1 == NPH;
         const int b1 = lastph ? b + G : b, ph1 = lastph ? 0 : ph + 1, n1 = lastph ? n + 1 : n;
+        const bool lastph1 = ph1 + 1 == NPH;
+        const int b2 = lastph1 ? b1 + G : b1, ph2 = lastph1 ? 0 : ph1 + 1;
         const float *cf0 = cf + (n & 1) * 2 * C, *cf1 = cf + (n1 & 1) * 2 * C;
-        // the wave's next three tiles after (ph, 0): t1 = (ph, 1), t2 / t3 = the two of the next position
-        const float *t1 = tile_src(b, ph, 1), *t2 = tile_src(b1, ph1, 0), *t3 = tile_src(b1, ph1, 1);
-
+        const float *nx0 = tile_src(b1, ph1, 0), *nx1 = tile_src(b1, ph1, 1), *nxx = tile_src(b2, ph2, 0);
         // the gather covers the rows whose P rows will be complete, g_lo .. g_hi - 1; an item = (channel, row, 4 pixels), one per thread
         const int g_lo = ph == 0 ? 0 : ph * NR - 1, g_hi = lastph ? H : (ph + 1) * NR - 1;
-        // the next image's coefficients travel during its predecessor's first phase (its first chunk is staged in the LAST step of the
+        // the next image's coefficients travel during its predecessor's first phase (its first K-step is staged in the LAST step of the
         // predecessor's last phase; NPH >= 2)
         const bool carry = ph == 0 && b + G < p.B;
         float4 xq = make_float4(0.f, 0.f, 0.f, 0.f), ncf = make_float4(0.f, 0.f, 0.f, 0.f);
         float bv = 0.f, ce = 0.f, cn = 0.f;
 
-        // ---- tile steps.  step(s, c): chunk c's A fragments out of the patch, then its MFMAs next to the staging of the NEXT chunk of the
-        // wave's sequence -- (s, c + 1), or (1, 0), or chunk 0 of the next position's first tile -- whose buffer is reloaded from the
-        // same tile one position on.  Wave-private exchanges: LDS operations of one wave execute in order; the LDS-only fences keep
-        // the compiler from moving them (a plain wavefront fence also drains the GLOBAL loads in flight).  The sched_barrier: nothing
-        // of a later step moves up (hipcc otherwise hoists the affine FMAs of ALL later chunks and waits for their loads here).
+        // ---- tile steps.  Step (s, m): K-step m's MFMAs next to the staging of the NEXT K-step of the wave's sequence -- (s, m + 1), or
+        // (1, 0), or K-step 0 of the next position's first tile -- whose two loads are then reissued for the same tile one position on.
+        // The sched_barrier: nothing of a later step moves up (hipcc otherwise hoists the affine FMAs of ALL later K-steps and waits for
+        // their loads here).
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             floatx16 acc;
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[r] = 0.f;
 #pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                // the next chunk of the wave's sequence: chunk c + 1 of this tile, else chunk 0 of the next tile (already in its buffer);
-                // the buffer is then reloaded from the tile after the one just staged
-                auto stage_next = [&]() __attribute__((always_inline)) {
-                    if (c + 1 < NCH) { stage(c + 1, cf0); load_chunk(s == 0 ? t1 : t2, c + 1); }
-                    else if (s == 0) { stage(0, cf0); load_chunk(t2, 0); }
-                    else { stage(0, cf1); load_chunk(t3, 0); }
-                };
-                if constexpr (BF) {
-                    bf16x8 A[2][3];
-#pragma unroll
-                    for (int j = 0; j < 2; j++)
-#pragma unroll
-                        for (int pl = 0; pl < 3; pl++)
-                            A[j][pl] = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const uint32_t *>(stg) + pl * 512 + lm * 16 +
-                                                                         4 * ((2 * j + kh) ^ rd_sw));
-                    HF_LDS_EXCHANGE();
-                    stage_next();
-#pragma unroll
-                    for (int j = 0; j < 2; j++) {      // small terms first (conv_split.hip's order)
-                        if (HF_ABLATE & 1) { asm volatile("" :: "v"(A[j][0]), "v"(A[j][1]), "v"(A[j][2])); continue; }
-                        const bf16x8 b2 = wl2[(c * 2 + j) * 64 + lane];
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][2], bwb[c][j][0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][1], bwb[c][j][1], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], b2, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][1], bwb[c][j][0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], bwb[c][j][1], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][0], bwb[c][j][0], acc, 0, 0, 0);
-                    }
-                } else {
-                    float4 a[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) a[q] = *reinterpret_cast<const float4 *>(stg + lm * HF_SLD + 8 * q + 4 * kh);
-                    HF_LDS_EXCHANGE();
-                    stage_next();
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bw[c][q].x, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bw[c][q].y, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bw[c][q].z, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bw[c][q].w, acc, 0, 0, 0);
-                    }
-                }
-                HF_LDS_EXCHANGE();
+            for (int m = 0; m < NK; m++) {
+                AFrag anext;
+                if (m + 1 < NK) { anext = stage(s, m + 1, cf0); load2(s == 0 ? nx0 : nx1, s, m + 1); }
+                else if (s == 0) { anext = stage(1, 0, cf0); load2(nx1, 1, 0); }
+                else { anext = stage(0, 0, cf1); load2(nxx, 0, 0); }
+                mfmas(acc, acur, m);
+                acur = anext;
                 __builtin_amdgcn_sched_barrier(0);
             }
             // D layout of the 32x32 MFMA: register i holds row 8 (i / 4) + 4 kh + (i % 4) (pixel), column lm (tap channel)
@@ -439,32 +397,37 @@ __global__ void __launch_bounds__(HF_NT) __attribute__((amdgpu_waves_per_eu(2, 2
     }
 }
 
-// OIHW (3x3, Cout <= 3) -> W' fragments [C/32][4 q][lane][e]: lane (n = lane % 32, kh = lane / 32) holds W'[ci = 32 c + 8 q + 4 kh + e][n],
-// W'[ci][n = tap Cout + co] = w[co][ci][tap], columns n >= 9 Cout zero
+// OIHW (3x3, Cout <= 3) -> W' in the kernel's slot order, W'[ci][n = tap Cout + co] = w[co][ci][tap], columns n >= 9 Cout zero.
+// fp32 form [C/8 j][lane][4]: lane (n = lane % 32, g = lane / 32) holds W'[ci = 8 j + 4 g + e][n], e < 4 -- what the lane (pixel, k-half g)
+// of the activations reads with its load j
 __global__ void k_relayout_weight_head_fused(const float *oihw, float *dst, int Cout, int Cin) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Cin * 32) return;
-    const int e = i & 3, lane = (i >> 2) & 63, q = (i >> 8) & 3, c = i >> 10;
-    const int n = lane & 31, kh = lane >> 5, ci = 32 * c + 8 * q + 4 * kh + e;
+    const int e = i & 3, lane = (i >> 2) & 63, j = i >> 8;
+    const int n = lane & 31, g = lane >> 5, ci = 8 * j + 4 * g + e;
     const int tap = n / Cout, co = n - tap * Cout;
     dst[i] = n < 9 * Cout ? oihw[((int64_t)co * Cin + ci) * 9 + tap] : 0.f;
 }
 
-// ... -> the bf16 planes [C/32][2 j][3 planes][lane][8]: lane (n, g = lane / 32) holds W'[ci = 32 c + 16 j + 8 g + e][n], e < 8
+// ... -> the bf16 planes [C/16 m][3 planes][lane][8]: lane (n, g) holds the k slots of K-step m, slot e < 4: ci = 16 m + 4 g + e,
+// slot e >= 4: ci = 16 m + 8 + 4 g + (e - 4)  (loads 2 m and 2 m + 1 of the activations)
 __global__ void k_relayout_weight_head_fused_bf(const float *oihw, uint4 *dst, int Cout, int Cin) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;        // one thread per (c, j, lane)
-    if (i >= (Cin / 32) * 2 * 64) return;
-    const int lane = i & 63, j = (i >> 6) & 1, c = i >> 7;
-    const int n = lane & 31, g = lane >> 5, ci0 = 32 * c + 16 * j + 8 * g;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;        // one thread per (m, lane)
+    if (i >= (Cin / 16) * 64) return;
+    const int lane = i & 63, m = i >> 6;
+    const int n = lane & 31, g = lane >> 5;
     const int tap = n / Cout, co = n - tap * Cout;
     float w[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) w[e] = n < 9 * Cout ? oihw[((int64_t)co * Cin + ci0 + e) * 9 + tap] : 0.f;
+    for (int e = 0; e < 8; e++) {
+        const int ci = 16 * m + (e < 4 ? 4 * g + e : 8 + 4 * g + (e - 4));
+        w[e] = n < 9 * Cout ? oihw[((int64_t)co * Cin + ci) * 9 + tap] : 0.f;
+    }
     uint32_t P[3][4];
 #pragma unroll
     for (int e = 0; e < 4; e++) hf_split2(w[2 * e], w[2 * e + 1], P[0][e], P[1][e], P[2][e]);
 #pragma unroll
-    for (int pl = 0; pl < 3; pl++) dst[((c * 2 + j) * 3 + pl) * 64 + lane] = make_uint4(P[pl][0], P[pl][1], P[pl][2], P[pl][3]);
+    for (int pl = 0; pl < 3; pl++) dst[(m * 3 + pl) * 64 + lane] = make_uint4(P[pl][0], P[pl][1], P[pl][2], P[pl][3]);
 }
 
 bool head_fused_bf(const ConvLaunch &c) {     // which matrix pipe: bf16 x 3 unless the fp32 GEMM policy (or DLPM_HEAD_F32=1) asks otherwise
@@ -473,10 +436,10 @@ bool head_fused_bf(const ConvLaunch &c) {     // which matrix pipe: bf16 x 3 unl
     return !f32 && c.gemm != DLPM_GEMM_F32;
 }
 
-// LDS: the ring of P rows + the four transpose patches + two coefficient slots
+// LDS: the ring of P rows + W' + two coefficient slots
 size_t head_fused_lds_floats(const ConvLaunch &c) {
     const int nr = 8 / (c.Wout >> 5);
-    return (size_t)9 * c.Cout * ((nr + 2) * c.Wout + 4) + HF_NW * (head_fused_bf(c) ? HF_STG_BF : HF_STG_F32) + 4 * c.C0 + (c.C0 / 32) * 2 * 64 * 4;
+    return (size_t)9 * c.Cout * ((nr + 2) * c.Wout + 4) + (size_t)c.C0 * (head_fused_bf(c) ? 48 : 32) + 4 * c.C0;
 }
 
 }  // namespace
@@ -496,7 +459,7 @@ int64_t head_fused_weight_floats(int Cin) { return (int64_t)Cin * 32 + (int64_t)
 int relayout_weight_head_fused(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st) {
     k_relayout_weight_head_fused<<<(unsigned)ceil_div(Cin * 32, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin);
     DLPM_LAUNCH_CHECK();
-    k_relayout_weight_head_fused_bf<<<(unsigned)ceil_div((Cin / 32) * 128, 128), 128, 0, st>>>(
+    k_relayout_weight_head_fused_bf<<<(unsigned)ceil_div((Cin / 16) * 64, 128), 128, 0, st>>>(
         oihw_dev, reinterpret_cast<uint4 *>(dst_dev + (int64_t)Cin * 32), Cout, Cin);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
