@@ -194,20 +194,28 @@ __global__ void __launch_bounds__(HF_NT) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int pl = 0; pl < 3; pl++) a.pl[pl] = hf_u32x4{q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
         return a;
     };
-    // K-step m's MFMAs: W' fragments straight from LDS
-    auto mfmas = [&](floatx16 &acc, const AFrag &a, int m) __attribute__((always_inline)) {
+    // W' fragments of K-step m out of LDS (bf16 form: read one step AHEAD, so that a step's MFMAs have their operands when it begins
+    // and can be issued between the staging's VALU instructions)
+    struct BFrag { bf16x8 pl[3]; };
+    auto load_b = [&](int m) __attribute__((always_inline)) {
+        BFrag r;
+        if constexpr (BF) {
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) r.pl[pl] = reinterpret_cast<const bf16x8 *>(wl)[(m * 3 + pl) * 64 + lane];
+        }
+        return r;
+    };
+    // K-step m's MFMAs
+    auto mfmas = [&](floatx16 &acc, const AFrag &a, const BFrag &bfr, int m) __attribute__((always_inline)) {
         if (HF_ABLATE & 1) { asm volatile("" :: "v"(a.pl[0]), "v"(a.pl[1]), "v"(a.pl[2])); return; }
         if constexpr (BF) {
-            bf16x8 Bf[3];
-#pragma unroll
-            for (int pl = 0; pl < 3; pl++) Bf[pl] = reinterpret_cast<const bf16x8 *>(wl)[(m * 3 + pl) * 64 + lane];
             const bf16x8 A0 = __builtin_bit_cast(bf16x8, a.pl[0]), A1 = __builtin_bit_cast(bf16x8, a.pl[1]), A2 = __builtin_bit_cast(bf16x8, a.pl[2]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, Bf[0], acc, 0, 0, 0);      // small terms first (conv_split.hip's order)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bf[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bf[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bf[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bf[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bf[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, bfr.pl[0], acc, 0, 0, 0);      // small terms first (conv_split.hip's order)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, bfr.pl[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, bfr.pl[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, bfr.pl[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, bfr.pl[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, bfr.pl[0], acc, 0, 0, 0);
         } else {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -251,6 +259,7 @@ __global__ void __launch_bounds__(HF_NT) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     HF_LDS_BARRIER();
     AFrag acur = stage(0, 0, cf);
+    BFrag bcur = load_b(0);
     load2(tile_src(b, 1, 0), 0, 0);                    // (NPH >= 2)
     __builtin_amdgcn_sched_barrier(0);
     for (;;) {
@@ -284,11 +293,23 @@ __global__ void __launch_bounds__(HF_NT) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
             for (int m = 0; m < NK; m++) {
                 AFrag anext;
+                const BFrag bnext = load_b(m + 1 < NK ? m + 1 : 0);
                 if (m + 1 < NK) { anext = stage(s, m + 1, cf0); load2(s == 0 ? nx0 : nx1, s, m + 1); }
                 else if (s == 0) { anext = stage(1, 0, cf0); load2(nx1, 1, 0); }
                 else { anext = stage(0, 0, cf1); load2(nxx, 0, 0); }
-                mfmas(acc, acur, m);
+                mfmas(acc, acur, bcur, m);
                 acur = anext;
+                bcur = bnext;
+                if constexpr (BF) {
+                    // the LDS reads first, then one MFMA and a share of the staging's VALU work, six times: left alone, hipcc issues the
+                    // six MFMAs in a row BEHIND the staging (SQ_VALU_MFMA_COEXEC_CYCLES 7 % of the MFMA cycles)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);          // DS reads: W' of the next step, the coefficients
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);     // VALU
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             // D layout of the 32x32 MFMA: register i holds row 8 (i / 4) + 4 kh + (i % 4) (pixel), column lm (tap channel)
