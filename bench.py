@@ -660,8 +660,9 @@ def main():
             sec = hf['ms'] / hf['launches'] * 1e-3
             gbs = alg / sec / 1e9
             traffic, tnote = pmc_traffic('k_head_fused', args.workload if not args.batch else '%s@B%d' % (args.workload, B))
-            upd = dict(kernel='k_head_fused: the head convolution (GroupNorm + SiLU + 3x3 conv to the image channels, as an MFMA GEMM onto the 9 Cout '
-                              'tap channels whose result stays in LDS) and the x_{t-1} update (Philox noise) in ONE launch, one workgroup per image',
+            upd = dict(kernel='k_head_fused: the head convolution (GroupNorm + SiLU + 3x3 conv to the image channels, as a GEMM onto the 9 Cout tap '
+                              'channels -- bf16 matrix pipe, exact three-plane split, fp32 result -- whose result stays in an LDS ring) and the '
+                              'x_{t-1} update (Philox noise) in ONE launch of persistent workgroups',
                        bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(gbs / PEAK_HBM_GBS, 4),
                        traffic=traffic, traffic_note=tnote, bytes_per_launch=alg, bytes_moved_per_launch=moved,
                        achieved_on_moved_bytes=round(moved / sec / 1e9, 1), avg_launch_ms=round(sec * 1e3, 5),

@@ -44,12 +44,13 @@ def test_unet_forward_matches_reference(name):
 
 @pytest.mark.parametrize('env,bound', [({'DLPM_WINO_F4': '0'}, 1e-5), ({'DLPM_WINO_F4': '0', 'DLPM_NO_WINO': '1'}, 1e-5),
                                        ({}, 2e-5), ({'DLPM_WINO_VS': '1'}, 2e-5), ({'DLPM_WINO_SPEC': '1'}, 2e-5),
-                                       ({'DLPM_NO_FUSED_BLOCKS': '1', 'DLPM_NO_HEAD_FUSED': '1'}, 2e-5)],
+                                       ({'DLPM_NO_FUSED_BLOCKS': '1', 'DLPM_NO_HEAD_FUSED': '1'}, 2e-5), ({'DLPM_HEAD_F32': '1'}, 2e-5)],
                          ids=['winograd_f2x2_only', 'implicit_gemm_only', 'default_f4x4', 'f4x4_v_split_waves', 'f4x4_channel_specialised',
-                              'round3_blocks_and_head'])
+                              'round3_blocks_and_head', 'head_on_the_fp32_mfma'])
 def test_unet_every_convolution_generation_against_reference(env, bound):
     """(Round 4: also the measured-neutral F(4x4) variants kept behind switches -- waves = position halves x channel quarters,
-    the channel-specialised instantiation -- and the per-layer launches / GEMM + gather head the fused kernels replaced.)
+    the channel-specialised instantiation --, the per-layer launches / GEMM + gather head the fused kernels replaced, and the one-pass head
+    on the fp32 MFMA instead of the bf16 pipe with the exact three-plane split.)
     The kernel choice is read once per process, so each generation runs in a child process (tools/err_report.py):
     CIFAR UNet vs the reference's own output.  Observed: F(4x4) 5.1e-6 (round 4's interpolation points; 1.35e-5 with the textbook
     ones, when the bound here was 5e-5), F(2x2) 3e-6, implicit GEMM 4.4e-6."""

@@ -1,9 +1,10 @@
-// What HBM read rate does the head kernel's access pattern allow?  One 512-thread workgroup per CU, every wave walks 16-KB tiles
+// What HBM read rate do the head kernel's access patterns allow?  One workgroup per CU, every wave walks 16-KB tiles
 // (32 pixels x 128 channels fp32, NHWC) one tile ahead in registers, as k_head_fused does, and only sums what it reads.
-//   pattern 0: the kernel's -- a load instruction = 8 pixels x 128 B (32 channels), 512-B stride; the 4 channel chunks of a tile are
-//              separate instructions
+//   pattern 0: the transposing forms of the kernel -- a load instruction = 8 pixels x 128 B (32 channels), 512-B stride; the 4 channel
+//              chunks of a tile are separate instructions
 //   pattern 1: a load instruction = 1 KB contiguous (2 whole pixels)
-//   pattern 3: a load instruction = 32 pixels x 32 B (lane = pixel + 32 k-half, 16 B each): the MFMA's own operand layout, no transposition
+//   pattern 3: the shipped kernel -- a load instruction = 32 pixels x 32 B (lane = pixel + 32 k-half, 16 B each): the MFMA's own operand
+//              layout, no transposition
 //   pattern 2: as 0, but the chunk loads of a tile are issued chunk-interleaved with ALU delay between them (as the pipelined kernel does)
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/mb/stream_pattern tools/mb/stream_pattern.hip
 #include <hip/hip_runtime.h>
@@ -66,11 +67,11 @@ int main() {
     hipMalloc(&out, 256 * 1024 * 4);
     hipMemset(h, 0, (size_t)nimg * 32 * 16384);
     run<1, 8>("1 KB contiguous per load instruction, 8 waves", h, out, nimg, 0);
-    run<0, 8>("8 pixels x 128 B per load instruction (the kernel's), 8 waves", h, out, nimg, 0);
+    run<0, 8>("8 pixels x 128 B per load instruction (line-coalesced forms), 8 waves", h, out, nimg, 0);
     run<2, 8>("... + 16 dependent rcp between the chunks", h, out, nimg, 16);
     run<2, 8>("... + 64 dependent rcp between the chunks", h, out, nimg, 64);
     run<2, 8>("... + 128 dependent rcp between the chunks", h, out, nimg, 128);
-    run<3, 8>("32 pixels x 32 B per load instruction (MFMA operand layout), 8 waves", h, out, nimg, 0);
+    run<3, 8>("32 pixels x 32 B per load instruction (MFMA operand layout: the kernel's), 8 waves", h, out, nimg, 0);
     run<3, 4>("32 pixels x 32 B per load instruction (MFMA operand layout), 4 waves", h, out, nimg, 0);
     run<1, 16>("1 KB contiguous per load instruction, 16 waves", h, out, nimg, 0);
     run<0, 16>("8 pixels x 128 B per load instruction, 16 waves", h, out, nimg, 0);
