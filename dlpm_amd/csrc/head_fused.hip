@@ -228,6 +228,9 @@ __global__ void __launch_bounds__(HF_NT) __attribute__((amdgpu_waves_per_eu(2, 2
         }
     };
 
+#if defined(DLPM_PHASE_TIMING) && defined(HF_CLOCK_ONLY)     // the clock the chip holds in this kernel, at the cost of two atomics per workgroup
+    const long long _k0 = clock64(), _w0 = wall_clock64();
+#endif
     const HeadUpdate &u = p.u;
     const int nq = W >> 2;
     const int64_t D = (int64_t)COUT * HW;
@@ -263,7 +266,7 @@ __global__ void __launch_bounds__(HF_NT) __attribute__((amdgpu_waves_per_eu(2, 2
     load2(tile_src(b, 1, 0), 0, 0);                    // (NPH >= 2)
     __builtin_amdgcn_sched_barrier(0);
     for (;;) {
-#ifdef DLPM_PHASE_TIMING
+#if defined(DLPM_PHASE_TIMING) && !defined(HF_CLOCK_ONLY)
         const long long _c0 = clock64(), _r0 = wall_clock64();
 #endif
         // the next two positions of the walk
@@ -337,11 +340,11 @@ __global__ void __launch_bounds__(HF_NT) __attribute__((amdgpu_waves_per_eu(2, 2
 
         // ---- gather + update.  k_head_gather's arithmetic, tap by tap in its order; taps outside the picture add a literal zero where
         // k_head_gather adds the zero its padded P holds.
-#ifdef DLPM_PHASE_TIMING
+#if defined(DLPM_PHASE_TIMING) && !defined(HF_CLOCK_ONLY)
         const long long _c2 = clock64();
 #endif
         HF_LDS_BARRIER();
-#ifdef DLPM_PHASE_TIMING
+#if defined(DLPM_PHASE_TIMING) && !defined(HF_CLOCK_ONLY)
         const long long _c3 = clock64();
 #endif
         asm volatile("" :: "v"(xq.x), "v"(xq.y), "v"(xq.z), "v"(xq.w), "v"(bv), "v"(ce), "v"(cn));   // (every path consumes what it requested)
@@ -399,7 +402,7 @@ __global__ void __launch_bounds__(HF_NT) __attribute__((amdgpu_waves_per_eu(2, 2
                 for (int px = 0; px < 4; px++) p.out[((int64_t)b * HW + pix + px) * COUT + co] = acc[px];
             }
         }
-#ifdef DLPM_PHASE_TIMING
+#if defined(DLPM_PHASE_TIMING) && !defined(HF_CLOCK_ONLY)
         if (p.phase && lane == 0) {
             atomicAdd(p.phase + 16 + wave, (unsigned long long)(_c3 - _c2));
             if (wave == 0) {
@@ -416,6 +419,13 @@ __global__ void __launch_bounds__(HF_NT) __attribute__((amdgpu_waves_per_eu(2, 2
         HF_LDS_BARRIER();                              // the gather has read the ring: the next phase's tiles may land
         b = b1; ph = ph1; n = n1;
     }
+#if defined(DLPM_PHASE_TIMING) && defined(HF_CLOCK_ONLY)
+    if (p.phase && tid == 0) {
+        atomicAdd(p.phase + 3, 1ull);
+        atomicAdd(p.phase + 12, (unsigned long long)(clock64() - _k0));
+        atomicAdd(p.phase + 13, (unsigned long long)(wall_clock64() - _w0));
+    }
+#endif
 }
 
 // OIHW (3x3, Cout <= 3) -> W' in the kernel's slot order, W'[ci][n = tap Cout + co] = w[co][ci][tap], columns n >= 9 Cout zero.
@@ -506,7 +516,9 @@ int launch_conv_head_fused(const ConvLaunch &c, const HeadUpdate *hu, hipStream_
         DLPM_HIP(hipGetDevice(&dev));
         DLPM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     }
-    const unsigned grid = (unsigned)(c.B < 2 * ncu ? c.B : 2 * ncu);     // persistent: two workgroups per CU walk the images
+    static int wgs = 0;                                                  // (DLPM_HEAD_WGS=1: one workgroup per CU -- A/B runs)
+    if (!wgs) { const char *e = getenv("DLPM_HEAD_WGS"); wgs = (e && e[0] == '1') ? 1 : 2; }
+    const unsigned grid = (unsigned)(c.B < wgs * ncu ? c.B : wgs * ncu);   // persistent: two workgroups per CU walk the images
 #define DLPM_HF1(CO, NCH, BFV)                                                                            \
     do {                                                                                                  \
         int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_head_fused<CO, NCH, BFV>), 160 * 1024); \

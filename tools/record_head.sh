@@ -1,8 +1,8 @@
 #!/bin/bash
 # tools/record_head.sh <outdir>: the one-pass head kernel's records of one build, on the GPU box from the repo root --
 # the access-pattern microbenchmark, the head's forms side by side, the timing-only ablations (HF_ABLATE variant libraries built
-# beforehand with DLPM_BUILD_DEFS="HF_ABLATE=<bits>" python -m dlpm_amd.build), the phase clocks (DLPM_PHASE_TIMING library) and the SQ /
-# FETCH / WRITE counters.
+# beforehand with DLPM_BUILD_DEFS="HF_ABLATE=<bits>" python -m dlpm_amd.build), the phase clocks (DLPM_PHASE_TIMING library), the clock the
+# chip holds (DLPM_BUILD_DEFS="DLPM_PHASE_TIMING HF_CLOCK_ONLY [HF_ABLATE=1|2|3|7|8]") and the SQ / FETCH / WRITE counters.
 out=${1:-gpurun_out/head_forms}
 mkdir -p $out
 ./tools/mb/stream_pattern > $out/mb_stream_pattern.txt 2>&1
@@ -27,6 +27,18 @@ mkdir -p $out
 } > $out/ablations.txt
 tag=$(python -c "import hashlib; print(hashlib.sha256('DLPM_PHASE_TIMING'.encode()).hexdigest()[:8])")
 [ -f dlpm_amd/lib/libdlpm_amd_$tag.so ] && DLPM_LIB=dlpm_amd/lib/libdlpm_amd_$tag.so python tools/bench_head.py --reps 30 --only fused > $out/phase_clocks.txt 2>/dev/null
+{
+  echo "# the clock the chip holds inside k_head_fused (shader cycles / 100-MHz ticks over each workgroup's life; DLPM_PHASE_TIMING + HF_CLOCK_ONLY"
+  echo "# libraries: two atomics per workgroup): the full kernel, no MFMAs (1), no SiLU / split arithmetic (2), memory only (3), memory only"
+  echo "# without the gather (7), arithmetic only (8).  cycles = ms x MHz."
+  for a in 0 1 2 3 7 8; do
+    defs="DLPM_PHASE_TIMING HF_CLOCK_ONLY"; [ $a != 0 ] && defs="$defs HF_ABLATE=$a"
+    tag=$(python -c "import hashlib,sys; print(hashlib.sha256(' '.join(sorted(sys.argv[1].split())).encode()).hexdigest()[:8])" "$defs")
+    [ -f dlpm_amd/lib/libdlpm_amd_$tag.so ] || continue
+    echo "HF_ABLATE=$a  $(DLPM_LIB=dlpm_amd/lib/libdlpm_amd_$tag.so python tools/bench_head.py --reps 30 --only fused 2>/dev/null | grep -E -o 'clock [0-9]+ MHz|total [0-9.]+ ms')" | tr '\n' ' '; echo
+  done
+} > $out/held_clock.txt
+cat $out/held_clock.txt
 bash tools/pmc_head.sh $GRAFT_REPO_ROOT/$out/pmc fused > $out/pmc_head_fused.txt 2>&1
 rm -rf $out/pmc
 cat $out/ablations.txt $out/phase_clocks.txt
