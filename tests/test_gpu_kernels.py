@@ -365,6 +365,27 @@ def test_head_conv_as_gemm_plus_gather(B, C, H, Cout, nchw):
     assert (got2 - ref_conv(h, w, None)).abs().max().item() < conv_tol(w, C)
 
 
+@pytest.mark.parametrize('C,Cout,H,f32', [(32, 3, 32, False), (64, 2, 32, False), (96, 1, 32, True), (32, 3, 64, False)])
+def test_head_one_pass_walks_many_images(C, Cout, H, f32):
+    """The one-pass head kernel is PERSISTENT: two workgroups per CU walk the images (head_fused.hip), carrying the next image's
+    GroupNorm coefficients and two tiles of read-ahead across image boundaries.  A batch of more images than workgroups (every
+    workgroup walks two or three, the last ones one fewer), per-image coefficients that differ wildly between neighbours, every channel
+    count the kernel instantiates (32 / 64 / 96; 128 is the bench's) and both picture widths: every image against the fp64 reference."""
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    B = 2 * ncu * 2 + 37 if H == 32 else 2 * ncu + 5
+    g = torch.Generator().manual_seed(C + Cout + H)
+    h = torch.randn(B, C, H, H, generator=g)
+    w = torch.randn(Cout, C, 3, 3, generator=g) / math.sqrt(9 * C)
+    b = torch.randn(Cout, generator=g)
+    coef = ((1 + 0.3 * torch.randn(B, C, generator=g)) * (1 + (torch.arange(B) % 3)[:, None].float()), 0.3 * torch.randn(B, C, generator=g))
+    want = ref_conv(h, w, b, coef=coef, silu=True)
+    got = run_conv(h, w, b, coef=coef, silu=True, out_nchw=True, force_direct=64 | (128 if f32 else 0), scratch_extra=80 * C + 4096)
+    err = (got - want).abs().amax(dim=(1, 2, 3))
+    print('one-pass head, %d images of %dx%d, C%d -> %d (%s): max err %.2e (image %d), tol %.2e'
+          % (B, H, H, C, Cout, 'fp32 MFMA' if f32 else 'bf16 x 3', err.max().item(), int(err.argmax()), conv_tol(w, C)))
+    assert err.max().item() < conv_tol(w, C)              # (observed 1.9e-6 .. 2.9e-6)
+
+
 def test_linear_as_conv():
     g = torch.Generator().manual_seed(5)
     x = torch.randn(37, 128, generator=g)
