@@ -29,6 +29,7 @@ import argparse
 import ctypes as C
 import hashlib
 import json
+import math
 import os
 import socket
 import subprocess
@@ -585,8 +586,12 @@ def main():
         # every rank holds the same gathered batch: each rank's shard checksum must reappear in EVERY rank's copy of those rows
         mine = [float(full[r * B:(r + 1) * B].double().sum().item()) for r in range(world)]
         shard_sums = [ri['shard_checksum'] for ri in ranks_info]
-        dist_info['gather_verified'] = bool(all(a == b for a, b in zip(mine, shard_sums)))
-        assert dist_info['gather_verified'], 'the gathered batch does not hold the shards the ranks produced'
+        # NaN-aware: a shard that holds a NaN (samples_finite = false is REPORTED, it must not void the line) has a NaN checksum on
+        # both sides, and NaN != NaN -- such a pair counts as equal; only a finite mismatch is a broken gather
+        same = [(a == b) or (math.isnan(a) and math.isnan(b)) for a, b in zip(mine, shard_sums)]
+        dist_info['gather_verified'] = bool(all(same))
+        if all(math.isfinite(v) for v in mine + shard_sums):
+            assert dist_info['gather_verified'], 'the gathered batch does not hold the shards the ranks produced'
         ids = [ri['device_uuid'] or ri['pci_bus_id'] for ri in ranks_info]
         dist_info['distinct_devices'] = len(set(ids)) if all(i is not None for i in ids) else None
         if backend == 'nccl' and os.environ.get('DLPM_BENCH_SINGLE_DEVICE') != '1' and dist_info['distinct_devices'] is not None:

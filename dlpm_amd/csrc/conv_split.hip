@@ -18,6 +18,8 @@
 // exactly this stage image (k_relayout_weight_split): staging them is a 16-byte-per-lane copy.  Activations are split
 // on the way into LDS, after the fused GroupNorm affine (+ SiLU): ~6 VALU operations per element, half of which the
 // bf16 MFMAs hide (same microbenchmark: VALU work co-issues with the bf16 pipe, unlike the fp32 MFMAs).
+#include <type_traits>
+
 #include "conv.h"
 #include "igemm_epilogue.h"
 
@@ -34,12 +36,19 @@
 #ifndef SPLIT_WGS
 #define SPLIT_WGS 2   // workgroups per CU the register budget is set for
 #endif
-
+// Row swizzle of the A stage image: chunk (16 B = the 8 k slots of one row, one k-half, one plane) of (k-step h, k-half kh, row) sits at
+// (2 h + kh) * 128 + (row ^ 4 kh).  A staging thread writes ONE dword of it (its channel pair); a ds_write_b32 banks modulo 32
+// dwords in groups of 32 lanes = 4 rows x 2 kh x 4 pairs: the XOR puts the two k-halves on opposite halves of the 128-byte bank
+// row -- conflict-free; a fragment read (one kh per 16-lane group) stays a permutation of 32 consecutive rows.  (Rounds 2-4 wrote
+// 8 bytes per lane with the XOR on row bit 3, laid out for 64 banks: every ds_write banks modulo 32, the four k slots of a row
+// shared one 16-byte slot, and the 4-way conflict on every staging write was the 37 % of LDS cycles that
+// profiles/r04/split_gemm_clock_and_mfma_busy.txt counted.)
 namespace dlpm {
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SKC = 32;                       // channels per stage
@@ -58,19 +67,24 @@ __device__ __forceinline__ void split2(float lo, float hi, uint32_t &p0, uint32_
     p2 = __builtin_amdgcn_perm(__float_as_uint(sh), __float_as_uint(sl), 0x07060302u);
 }
 
-// OIHW ([Cout][Cin][taps]) -> [tap][Cout/128][Cin/32][plane 3][k-step 2][k-half 2][row 128][8 bf16]
+// OIHW ([Cout][Cin][taps]) -> [tap][Cout/128][Cin/32][plane 3][k-step 2][k-half 2][row 128][8 bf16], a 32-channel stage's k slots
+// in STAGING order: the k index of an MFMA is free as long as both operands agree, and the activation side wants every thread of
+// the staging pass (which holds 4 consecutive channels 4q .. 4q+3 of a pixel: 8 lanes read a whole 128-byte line) to contribute to
+// BOTH k-steps of the stage -- so k-step h takes channels 4q + 2h, 4q + 2h + 1 of every q: slot (k-half q >> 2, bf16 pair q & 3).
+// Channel of slot (h, kh, j): 16 kh + 4 (j >> 1) + 2 h + (j & 1).  (Rounds 2-4 had the channels in order, k-step = channel >> 4.)
 __global__ void k_relayout_weight_split(const float *w, uint4 *dst, int Cout, int Cin, int taps) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (tap, n, group of 8 k)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (tap, n, group of 8 k slots)
     const int kg = Cin / 8;
     if (i >= (int64_t)taps * Cout * kg) return;
     const int tap = (int)(i / ((int64_t)Cout * kg));
     const int64_t j = i - (int64_t)tap * Cout * kg;
     const int n = (int)(j / kg), g = (int)(j - (int64_t)n * kg);
-    const float *src = w + ((int64_t)n * Cin + g * 8) * taps + tap;
+    const int kc = g >> 2, q = g & 3, h = q >> 1, kh = q & 1;   // q = k-step * 2 + k-half
+    const float *src = w + ((int64_t)n * Cin + kc * SKC + 16 * kh + 2 * h) * taps + tap;
     uint32_t P[3][4];
 #pragma unroll
-    for (int e = 0; e < 4; e++) split2(src[(2 * e) * taps], src[(2 * e + 1) * taps], P[0][e], P[1][e], P[2][e]);
-    const int nt = n >> 7, row = n & 127, kc = g >> 2, q = g & 3;   // q = k-step * 2 + k-half
+    for (int e = 0; e < 4; e++) split2(src[(4 * e) * taps], src[(4 * e + 1) * taps], P[0][e], P[1][e], P[2][e]);
+    const int nt = n >> 7, row = n & 127;
     uint4 *tile = dst + (((int64_t)tap * (Cout >> 7) + nt) * (Cin / SKC) + kc) * SCHUNKS;
 #pragma unroll
     for (int pl = 0; pl < 3; pl++) tile[pl * (SPLANE / 16) + q * 128 + row] = make_uint4(P[pl][0], P[pl][1], P[pl][2], P[pl][3]);
@@ -190,8 +204,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split
 
     // A staging: 8 consecutive lanes read one pixel's 32 channels (a whole 128-byte line), a wave instruction 8 pixels;
     // a thread owns channels 4q..4q+3 of pixels rb, rb + RSTEP, ...
-    const int q = tid & 7, rb = tid >> 3;
-    const int ksh = q >> 1;                       // k-step * 2 + k-half of this thread's channels; q & 1 = which 8 bytes of the chunk
+    const int q = tid & 7, rb = tid >> 3;         // the thread's channel pair of k-step h: slot (k-half q >> 2, pair q & 3)
     // a ragged last tile (B * HW not a multiple of 128: small batches of 8x8 / 4x4 tensors) re-reads its last valid pixel
     // for the rows beyond M and never stores them: the kernel a layer takes must not depend on the batch
     const int64_t M = (int64_t)p.B * HWo;
@@ -254,15 +267,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split
             }
         }
     };
-    // LDS chunk (16 B = 8 channels of one row of one plane) of (ksh, row): ksh * 128 + (row ^ 8 ksh) -- the XOR spreads the
-    // 8-byte staging writes of a wave (4 ksh x 8 rows) over the banks and leaves a fragment read (32 consecutive rows) contiguous
-    uint2 *As = reinterpret_cast<uint2 *>(smem);
+    uint32_t *As = reinterpret_cast<uint32_t *>(smem);
     u32x4 *Bs = reinterpret_cast<u32x4 *>(smem + SOPER);
     const float *cf = reinterpret_cast<const float *>(smem + (1 + NB) * SOPER);
     int cfo[NV];                                  // this thread's rows' coefficient rows in the LDS table
 #pragma unroll
     for (int v = 0; v < NV; v++) cfo[v] = (nsamp > 1 ? min(rb + RSTEP * v, mrem - 1) / HWo : 0) * Cin + 4 * q;   // rows beyond M: the last valid sample's (written) coefficients
-    const int wofs = (ksh * 128 + (rb ^ (ksh * 8))) * 2 + (q & 1);
+    const int wofs = ((q >> 2) * 128 + (rb ^ (q & 4))) * 4 + (q & 3);   // dword of k-step 0; k-step 1: + 256 chunks
     auto store_step = [&](float4 (&xa)[NV], u32x4 (&wb)[NWV], int ok, int s) {
         const int c0 = (TAPS == 1 ? s : s / TAPS) * SKC;
 #pragma unroll
@@ -292,7 +303,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split
                 split2(x.z, x.w, P[0][1], P[1][1], P[2][1]);
             }
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) As[pl * (SPLANE / 8) + wofs + v * (RSTEP * 2)] = make_uint2(P[pl][0], P[pl][1]);
+            for (int pl = 0; pl < 3; pl++) {
+                As[pl * (SPLANE / 4) + wofs + v * (RSTEP * 4)] = P[pl][0];
+                As[pl * (SPLANE / 4) + wofs + v * (RSTEP * 4) + 1024] = P[pl][1];
+            }
         }
         if (!(SABL(32) && s >= 2)) {
 #pragma unroll
@@ -311,7 +325,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split
     const bf16x8 *af = reinterpret_cast<const bf16x8 *>(smem) + kh * 128 + wm * 64;
     const bf16x8 *bf = reinterpret_cast<const bf16x8 *>(smem + SOPER + (NW == 16 ? (wn >> 2) * SOPER : 0)) + kh * 128 +
                        (NW == 16 ? (wn & 3) * 32 : wn * (RN * 32)) + l31;
-    const int ax0 = l31 ^ (kh * 8), ax1 = l31 ^ ((2 + kh) * 8);   // swizzled row of this lane for k-step 0 / 1
+    const int ax0 = l31 ^ (kh * 4), ax1 = ax0;   // swizzled row of this lane
     auto mfma_step = [&]() {
         if (SABL(8)) return;
         if (!(SPLIT_ABL & 16)) __builtin_amdgcn_s_setprio(1);   // MFMA-issuing waves first: +4-8 % on the long launches (profiles/r02/gemm_bf16x3_priority.txt)
@@ -438,6 +452,258 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? SPLIT_WGS : 1) k_conv_split
 #endif
 }
 
+
+// ---- Round 5: the same GEMM with the stage pipeline inside the workgroup -------------------------------------------------------------
+// k_conv_split (above) holds ONE 32-channel stage in LDS: store -> barrier -> MFMAs -> barrier, so within a workgroup nothing runs
+// beside the MFMAs and nothing beside the staging pass; it lives off a second workgroup on the CU being in the other half of that
+// cycle.  Counters of round 4: MFMA busy 0.48-0.60, 39 % of a workgroup's loop at its two barriers.
+// Here a stage is ONE k-step (16 channels: 12 KB per operand) and LDS holds two of them per operand (48 KB: still two workgroups per
+// CU), so iteration i = { barrier; read the fragments of k-step i; split + write k-step i + 1 into the other buffer; issue the global
+// loads of the steps behind it; the 12 MFMAs of k-step i } -- one barrier per k-step, a wave that arrives there has already written its
+// share of the next one, and the staging instructions of a wave sit in the same basic block as its MFMAs.
+// Operands wait in registers two steps deep: activations per 32-channel pair of k-steps (two float4 per thread: whole 128-byte lines;
+// the weight image's k-slot order lets every thread feed both k-steps), weights per k-step (three 8-byte loads per thread = the 12 KB
+// image of the step, copied to LDS as it lies).  Per-output accumulation order = k_conv_split's: same bits.
+__global__ void __launch_bounds__(512, 4) k_conv_split_pipe(ConvLaunch p, int nsamp, int xcd_map) {
+    constexpr int KB = 12 * 1024;                 // one k-step of one operand: 3 planes x [k-half 2][row 128] x 16 B
+    extern __shared__ __align__(16) unsigned char smem[];   // [A0][A1][B0][B1][GroupNorm coefficients of the tile's samples]
+    DLPM_PHASE_DECL;
+#ifdef DLPM_PHASE_TIMING
+    const long long _c0 = clock64(), _r0 = wall_clock64();
+#endif
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;      // 2 x 4 waves of 64 pixels x 32 channels
+    const int Cin = p.C0 + p.C1;
+    const int ntile_n = p.Cout >> 7;
+    int mt_i, nt;
+    if (xcd_map) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        mt_i = (slot / ntile_n) * 8 + xcd;
+        nt = slot % ntile_n;
+    } else {
+        mt_i = blockIdx.x / ntile_n;
+        nt = blockIdx.x % ntile_n;
+    }
+    const int64_t m0 = (int64_t)mt_i * BM;
+    const int n0 = nt * 128;
+    const int HWo = p.Hout * p.Wout;
+    const int q = tid & 7, rb = tid >> 3;         // staging: channels 4q .. 4q+3 of pixels rb and rb + 64
+    const int64_t M = (int64_t)p.B * HWo;
+    const int mrem = (int)min((int64_t)BM, M - m0);
+    // Addresses = a wave-uniform 64-bit base (SGPRs: a buffer resource at the tile's first row) + a scalar offset per stage + the thread's
+    // 32-bit byte offset: the loop keeps no pointer in VGPRs (at 128 registers a spill costs twice here -- scratch reloads count on
+    // vmcnt and drain the operand loads in flight).
+    uint32_t rcl[2];      // row of the tile (clamped: a ragged last tile re-reads its last valid pixel)
+#pragma unroll
+    for (int v = 0; v < 2; v++) rcl[v] = min(rb + 64 * v, mrem - 1);
+    const int nkc = Cin / SKC;
+    const int npairs = nkc, nks = 2 * npairs;
+    const bool has_coef = p.coefA != nullptr;
+    // (offsets stay far below the 2-GB window: a tile is 128 rows of <= 2 KB; the weights of one 128-channel tile are Cin * 768 B)
+    auto rsrc = [](const void *base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000); };
+    const __amdgpu_buffer_rsrc_t r0 = rsrc(p.src0 + m0 * p.C0), r1 = rsrc(p.src1 ? p.src1 + m0 * p.C1 : p.src0 + m0 * p.C0);
+    const __amdgpu_buffer_rsrc_t rw = rsrc(reinterpret_cast<const unsigned char *>(p.w_split) + (int64_t)nt * nkc * SOPER);
+    const uint32_t q16 = 16 * q, t8 = 8 * tid;
+
+    // activations of pair s (channels 32 s .. 32 s + 31) -> registers
+    auto load_a = [&](f32x4 (&xa)[2], int s) {
+        const int c0 = s * SKC;
+        const bool first = c0 < p.C0;             // uniform: C0 % 32 == 0
+        const __amdgpu_buffer_rsrc_t r = first ? r0 : r1;
+        const int so = 4 * (first ? c0 : c0 - p.C0);
+        const uint32_t rs4 = 4u * (uint32_t)(first ? p.C0 : p.C1);
+#pragma unroll
+        for (int v = 0; v < 2; v++) xa[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(rcl[v] * rs4 + q16), so, 0));
+    };
+    // weights of k-step i (pair i >> 1, half i & 1): plane pl of the step = 4 KB at plane * 8 KB + half * 4 KB of the pair's image
+    auto load_b = [&](u32x2 (&wb)[3], int i) {
+        const int so = (i >> 1) * SOPER + (i & 1) * (SPLANE / 2);
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) wb[pl] = __builtin_amdgcn_raw_buffer_load_b64(rw, (int)t8, so + pl * SPLANE, 0);
+    };
+    const float *cf = reinterpret_cast<const float *>(smem + 4 * KB);
+    int cfo[2];
+#pragma unroll
+    for (int v = 0; v < 2; v++) cfo[v] = (nsamp > 1 ? min(rb + 64 * v, mrem - 1) / HWo : 0) * Cin + 4 * q;
+    // GroupNorm affine and SiLU, once per loaded value (in place, before half 0 is split)
+    auto activate = [&](f32x4 (&xa)[2], int s) {
+        const int c0 = s * SKC;
+#pragma unroll
+        for (int v = 0; v < 2; v++) {
+            f32x4 x = xa[v];
+            if (has_coef) {
+                const f32x4 ca = *reinterpret_cast<const f32x4 *>(cf + cfo[v] + c0);
+                const f32x4 cb = *reinterpret_cast<const f32x4 *>(cf + nsamp * Cin + cfo[v] + c0);
+                x.x = fmaf(x.x, ca.x, cb.x);
+                x.y = fmaf(x.y, ca.y, cb.y);
+                x.z = fmaf(x.z, ca.z, cb.z);
+                x.w = fmaf(x.w, ca.w, cb.w);
+            }
+            if (p.act_silu) {
+                x.x = silu_f(x.x);
+                x.y = silu_f(x.y);
+                x.z = silu_f(x.z);
+                x.w = silu_f(x.w);
+            }
+            xa[v] = x;
+        }
+    };
+    // half h of a pair -> buffer `buf`: dword (k-half q >> 2, row ^ 4 kh, pair q & 3) of each plane
+    const int wofs = ((q >> 2) * 128 + (rb ^ (q & 4))) * 4 + (q & 3);
+    auto stage_a = [&](const f32x4 (&xa)[2], int h, int buf) {
+        uint32_t *As = reinterpret_cast<uint32_t *>(smem + buf * KB);
+#pragma unroll
+        for (int v = 0; v < 2; v++) {
+            uint32_t P0, P1, P2;
+            if (h == 0) split2(xa[v].x, xa[v].y, P0, P1, P2);
+            else split2(xa[v].z, xa[v].w, P0, P1, P2);
+            As[wofs + v * 256] = P0;
+            As[1024 + wofs + v * 256] = P1;
+            As[2048 + wofs + v * 256] = P2;
+        }
+    };
+    auto stage_b = [&](const u32x2 (&wb)[3], int buf) {
+        u32x2 *Bs = reinterpret_cast<u32x2 *>(smem + (2 + buf) * KB) + tid;
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) Bs[pl * 512] = wb[pl];
+    };
+
+    floatx16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+    const int aofs = kh * 128 + wm * 64 + (l31 ^ (kh * 4)), bofs = kh * 128 + wn * 32 + l31;
+    bf16x8 A[2][3], Bf[3];
+    auto read_frags = [&](int buf) {
+        const bf16x8 *af = reinterpret_cast<const bf16x8 *>(smem + buf * KB) + aofs;
+        const bf16x8 *bf = reinterpret_cast<const bf16x8 *>(smem + (2 + buf) * KB) + bofs;
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            A[0][pl] = af[pl * 256];
+            A[1][pl] = af[pl * 256 + 32];
+            Bf[pl] = bf[pl * 256];
+        }
+    };
+    auto mfmas = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {   // smallest terms first within a (tile, k-step)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][2], Bf[0], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], Bf[1], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], Bf[2], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], Bf[0], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], Bf[1], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], Bf[0], acc[i], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    f32x4 xa0[2], xa1[2];
+    u32x2 wb0[3], wb1[3];
+    // GroupNorm coefficients of the tile's samples -> LDS [A | B][nsamp][Cin]; their loads go out first (loads retire in order)
+    f32x4 cq[2] = {};
+    const int n4 = has_coef ? nsamp * Cin / 4 : 0;
+    const int nv4 = has_coef ? (int)min((int64_t)n4, (p.B - m0 / HWo) * (int64_t)(Cin / 4)) : 0;
+    if (has_coef) {
+        const int64_t pb0 = m0 / HWo;
+        const int i = min(tid, nv4 - 1);
+        cq[0] = reinterpret_cast<const f32x4 *>(p.coefA + pb0 * Cin)[i];
+        cq[1] = reinterpret_cast<const f32x4 *>(p.coefB + pb0 * Cin)[i];
+    }
+    // (every prologue load is unconditional -- a one-pair GEMM re-reads pair 0 / k-step 1: the loop's vmcnt counts are the minimum
+    // over the paths into it)
+    load_a(xa0, 0);
+    load_b(wb0, 0);
+    load_b(wb1, 1);
+    load_a(xa1, min(1, npairs - 1));
+    if (has_coef) {
+        f32x4 *dst = reinterpret_cast<f32x4 *>(smem + 4 * KB);
+        if (tid < n4) { dst[tid] = cq[0]; dst[n4 + tid] = cq[1]; }
+        const int64_t pb0 = m0 / HWo;
+        for (int i = tid + 512; i < nv4; i += 512) {
+            dst[i] = reinterpret_cast<const f32x4 *>(p.coefA + pb0 * Cin)[i];
+            dst[n4 + i] = reinterpret_cast<const f32x4 *>(p.coefB + pb0 * Cin)[i];
+        }
+        __syncthreads();
+    }
+    activate(xa0, 0);
+    stage_a(xa0, 0, 0);
+    stage_b(wb0, 0);
+    load_b(wb0, min(2, nks - 1));
+    DLPM_PHASE(p, 0);
+    // iteration i: k-step i from buffer i & 1; k-step i + 1 -> the other buffer.  Unrolled by 4 = two pairs: pair (i >> 1) & 1 lives
+    // in xa0 / xa1, the weights of k-step i in wb0 / wb1 by parity; each register set is reloaded as soon as it has been staged.
+    // (The steady-state trips carry no condition around a load: hipcc's vmcnt counts are exact only when every path into a wait has
+    // issued the same loads -- with the tail's guards in the loop every staging pass waited for vmcnt(0).)
+    auto four_steps = [&](int i, auto guard) {
+        constexpr bool G = decltype(guard)::value;   // tail trips: what lies beyond the last k-step is neither loaded nor staged
+        {   // k-step i (pair P = i / 2, half 0); stage half 1 of P (xa0), then xa0 <- pair P + 2
+            __syncthreads();
+            read_frags(0);
+            stage_a(xa0, 1, 1);
+            stage_b(wb1, 1);
+            if (!G || i + 4 < nks) load_a(xa0, (i >> 1) + 2);
+            if (!G || i + 3 < nks) load_b(wb1, i + 3);
+            mfmas();
+        }
+        {   // k-step i + 1 (half 1 of P); stage half 0 of P + 1 (xa1)
+            __syncthreads();
+            read_frags(1);
+            if (!G || i + 2 < nks) {
+                activate(xa1, (i >> 1) + 1);
+                stage_a(xa1, 0, 0);
+                stage_b(wb0, 0);
+                if (!G || i + 4 < nks) load_b(wb0, i + 4);
+            }
+            mfmas();
+        }
+        if (!G || i + 2 < nks) {
+            {   // k-step i + 2 (half 0 of P + 1); stage its half 1, then xa1 <- pair P + 3
+                __syncthreads();
+                read_frags(0);
+                stage_a(xa1, 1, 1);
+                stage_b(wb1, 1);
+                if (!G || i + 6 < nks) load_a(xa1, (i >> 1) + 3);
+                if (!G || i + 5 < nks) load_b(wb1, i + 5);
+                mfmas();
+            }
+            {   // k-step i + 3; stage half 0 of P + 2 (xa0)
+                __syncthreads();
+                read_frags(1);
+                if (!G || i + 4 < nks) {
+                    activate(xa0, (i >> 1) + 2);
+                    stage_a(xa0, 0, 0);
+                    stage_b(wb0, 0);
+                    if (!G || i + 6 < nks) load_b(wb0, i + 6);
+                }
+                mfmas();
+            }
+        }
+    };
+    int i = 0;
+    for (; i + 6 < nks; i += 4) four_steps(i, std::false_type());
+    for (; i < nks; i += 4) four_steps(i, std::true_type());
+    DLPM_PHASE(p, 1);
+    floatx16 accs[2][1];
+    accs[0][0] = acc[0];
+    accs[1][0] = acc[1];
+    if (p.stats_out) {   // 8x8 images (launch_conv_split): per-image statistics from the registers
+        if (mrem == BM) split_store_from_registers<false, 1, true>(p, accs, m0, n0 + wn * 32, wm, l31, kh, BM);
+        else split_store_from_registers<true, 1, true>(p, accs, m0, n0 + wn * 32, wm, l31, kh, mrem);
+    } else if (mrem == BM) split_store_from_registers<false, 1>(p, accs, m0, n0 + wn * 32, wm, l31, kh, BM);
+    else split_store_from_registers<true, 1>(p, accs, m0, n0 + wn * 32, wm, l31, kh, mrem);
+    DLPM_PHASE(p, 2);
+#ifdef DLPM_PHASE_TIMING
+    if (p.phase && tid == 0) {
+        atomicAdd(p.phase + 3, 1ull);
+        atomicAdd(p.phase + 12, (unsigned long long)(clock64() - _c0));
+        atomicAdd(p.phase + 13, (unsigned long long)(wall_clock64() - _r0));
+    }
+#endif
+}
+
 }  // namespace
 
 int64_t split_weight_floats(int Cout, int Cin, int taps) { return ((int64_t)taps * Cout * Cin * 6 + 3) / 4; }   // 3 bf16 planes
@@ -491,9 +757,19 @@ int launch_conv_split(const ConvLaunch &c, hipStream_t st) {
         if (r != DLPM_OK) return r;                                                                                       \
         k_conv_split<NW_, DIST_, TAPS_><<<grid, NW_ * 64, lds, st>>>(c, nsamp, xcd_map);                                  \
     } while (0)
-    // 8 waves (four per SIMD with two workgroups on a CU) measured 5 % faster than 4 waves with two register stages
-    // (profiles/r02/gemm_1x1_bf16x3_variants.txt); the 4-wave shape carries the row epilogue with the fused statistics.
-    // All shapes accumulate every output in the same order: which one runs does not change a bit of the result.
+    // Round 5: the pipelined kernel (one k-step per LDS stage, two stages, one barrier per k-step) wherever the 8-wave shape ran;
+    // DLPM_SPLIT_PIPE=0 restores k_conv_split<8, 1, *> for A/B runs (same bits).  The 4-wave shape carries the row epilogue with the
+    // fused statistics.  All shapes accumulate every output in the same order: which one runs does not change a bit of the result.
+    static int pipe = -1;
+    if (pipe < 0) { const char *e = getenv("DLPM_SPLIT_PIPE"); pipe = e ? atoi(e) : 1; }
+    if (pipe && c.ks == 1 && !row_stats && !wide) {
+        const int lds_p = 48 * 1024 + (c.coefA ? nsamp * (c.C0 + c.C1) * 8 : 0);
+        const int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_conv_split_pipe), 80 * 1024);
+        if (r != DLPM_OK) return r;
+        k_conv_split_pipe<<<grid, 512, lds_p, st>>>(c, nsamp, xcd_map);
+        DLPM_LAUNCH_CHECK();
+        return DLPM_OK;
+    }
     if (c.ks == 1) {
         if (row_stats) DLPM_SPLIT_LAUNCH(4, 2, 1);
         else if (wide) DLPM_SPLIT_LAUNCH(16, 1, 1);

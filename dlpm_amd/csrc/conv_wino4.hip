@@ -42,7 +42,7 @@ namespace {
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int F4_TILES = 16;      // 4x4-output tiles per workgroup (the M of the 16x16x4 MFMA)
-constexpr int F4_NQ = 128;        // output channels per workgroup (8 waves x 16)
+constexpr int F4_NQ = 128;        // output channels per workgroup of the main shape (8 waves x 16)
 constexpr int F4_KC = 8;          // input channels per phase (2 MFMA k-steps)
 constexpr int F4_RAWPIX = 576;    // halo pixels per phase: one 18x18 patch, 4 x 10x10 or 16 x 6x6 (whole small images)
 constexpr int F4_PRLD = F4_KC + 4;
@@ -50,6 +50,14 @@ constexpr int F4_NT = 512;
 constexpr int F4_QNIT = (F4_RAWPIX * 2 + F4_NT - 1) / F4_NT;   // staging items (pixel, channel quad) per thread for a full 576-pixel patch: 3
                                                                // (only 16 one-tile images fill it; every other block shape is <= 512 pixels: QN = 2)
 constexpr int F4_RAWBUF = F4_RAWPIX * F4_PRLD + 16;   // floats per raw buffer, row skew included
+// Round 5 -- narrow layers (Cout a multiple of 32 but not of 128: the 32- and 64-channel levels of the MNIST-sized nets).  The work
+// split is the wave's: 16 output channels x 36 positions x 16 tiles, so a workgroup of NW waves covers 16 NW channels: NW = 4 (64) or
+// 2 (32) waves on the same 16-tile block, the same V / raw / weight-fragment layouts, more staging items per thread (QN), a raw buffer
+// for halo patches of <= 400 pixels (an 18x18 block patch, or four 10x10 images: two workgroups fit a CU's LDS).  With two waves the
+// three row pairs of the input transform go 2 + 1.
+constexpr int F4_RAWPIX_N = 400;
+constexpr int F4_RAWBUF_N = F4_RAWPIX_N * F4_PRLD + 16;
+constexpr int f4_nq_of(int cout) { return cout % 128 == 0 ? 128 : cout % 64 == 0 ? 64 : 32; }
 constexpr int F4_CFS = 16 * 2 * F4_KC;   // floats per GroupNorm-coefficient slot: [16 images][A | B][8]
 constexpr int F4_VBUF = 36 * F4_TILES * F4_KC;   // floats per V buffer: [18 position pairs][4 channel pairs][16 tiles][4]
 #ifndef F4_RING_DEPTH
@@ -122,8 +130,11 @@ __device__ __forceinline__ float2 f2sub(float2 x, float2 y) { return make_float2
 // the clock on that LDS traffic).  Y = A^T M A splits by rows of A^T: each wave of a pair turns its 18 positions into 16 partial outputs
 // per (tile, channel), hands the partials of the channel tile its PARTNER finalises over through LDS (one barrier pair, 128 KB: the
 // loop's buffers are dead by then) and runs the unchanged register epilogue on the other.
-template <bool UPS, int ABL = 0, int QN = F4_QNIT, int SPEC = 0, int VS = 0>
-__global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p_in, int bh_in, int bw_in, int nimg_in) {
+template <bool UPS, int ABL = 0, int QN = F4_QNIT, int SPEC = 0, int VS = 0, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, 1) k_conv3x3_wino4(ConvLaunch p_in, int bh_in, int bw_in, int nimg_in) {
+    constexpr int F4_NT = NW * 64, F4_NQ = NW * 16;                       // (shadow the main shape's constants)
+    constexpr int F4_RAWBUF = NW == 8 ? dlpm::F4_RAWBUF : F4_RAWBUF_N;
+    static_assert(NW == 8 || (VS == 0 && SPEC == 0), "wave-split and specialised forms exist for the 128-channel shape only");
     ConvLaunch p = p_in;
     int bh = bh_in, bw = bw_in, nimg = nimg_in;
     if (SPEC) {
@@ -245,8 +256,7 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p_in, int
         rbase = (timg * rpi + (UPS ? 2 : 4) * ty * RW + (UPS ? 2 : 4) * tx) * F4_PRLD + pair * 2 + (skewed ? 4 * ty : 0);
         vofs = (pair * F4_TILES + tile) * 4;
     }
-    auto transform = [&](int slot) {
-        if (wave >= 3) return;
+    auto transform_rp = [&](int slot, int rp) {
         const float *rb = raw + slot * F4_RAWBUF + rbase;
         float *vb = V + slot * F4_VBUF + vofs;
         // d(i, c): sample row i, column c of this tile's 6x6 patch (upsampled: source row (i + 1) >> 1 of the 4x4 source patch);
@@ -257,14 +267,14 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p_in, int
         };
         float2 Ta[6], Tb[6];
         int a0, a1;
-        if (wave == 0) {
+        if (rp == 0) {
 #pragma unroll
             for (int c = 0; c < 6; c++) {
                 Ta[c] = f2fma(PP2, d(0, c), f2fma(-PS2, d(2, c), d(4, c)));
                 Tb[c] = f2fma(PP2, d(1, c), f2fma(-PS2, d(3, c), d(5, c)));
             }
             a0 = 0; a1 = 5;
-        } else if (wave == 1) {
+        } else if (rp == 1) {
 #pragma unroll
             for (int c = 0; c < 6; c++) {
                 const float2 e = f2fma(-PB2, d(2, c), d(4, c)), o = f2fma(-PB2, d(1, c), d(3, c));
@@ -295,11 +305,21 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p_in, int
         row_out(Ta, a0);
         row_out(Tb, a1);
     };
+    auto transform = [&](int slot) {
+        if (NW >= 3) {
+            if (wave < 3) transform_rp(slot, wave);
+        } else if (wave == 0) {
+            transform_rp(slot, 0);
+            transform_rp(slot, 1);
+        } else {
+            transform_rp(slot, 2);
+        }
+    };
 
     // ---- weight stream of this wave: Wf[ntile][wave][phase][18 position pairs][lane][4], contiguous per wave
     // (wave-uniform pointer + lane: the per-fragment advance is scalar arithmetic)
     const float4 *__restrict__ wp = reinterpret_cast<const float4 *>(p.w_wino4) +
-                                    (int64_t)((n0 >> 7) * 8 + __builtin_amdgcn_readfirstlane(wave)) * nch * 18 * 64;
+                                    (int64_t)((n0 / F4_NQ) * NW + __builtin_amdgcn_readfirstlane(wave)) * nch * 18 * 64;
     constexpr int AHEAD = F4_RING - 1;
     float4 bq[F4_RING];
     // A fragments: lane (li = tile, lk) reads channels 2 lk, 2 lk + 1 of the phase (= k index lk of the two k-steps) for both
@@ -699,7 +719,8 @@ __global__ void __launch_bounds__(F4_NT, 1) k_conv3x3_wino4(ConvLaunch p_in, int
 // with pos = 2 pp + (e >> 1).  Computed in double, rounded once.
 // vs = 1 (the VS kernel): Wf[ntile][wave = 4 ph + q][phase][slot = 2 pp + nt][lane][4]: lane holds, for e = 0..3,
 // U_pos[cin = phase*8 + 2 lk + (e & 1)][cout = ntile*128 + 32 q + 16 nt + li] with pos = 18 ph + 2 pp + (e >> 1)
-__global__ void k_relayout_weight_wino4(const float *oihw, float *dst, int Cout, int Cin, int vs) {
+// nw = waves per workgroup (8 / 4 / 2 for 128- / 64- / 32-channel n-tiles): Wf[ntile][wave < nw][phase][18][lane][4]
+__global__ void k_relayout_weight_wino4(const float *oihw, float *dst, int Cout, int Cin, int vs, int nw) {
     const int nch = Cin / F4_KC;
     const int64_t total = (int64_t)Cout * Cin * 36;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -709,12 +730,12 @@ __global__ void k_relayout_weight_wino4(const float *oihw, float *dst, int Cout,
     int64_t r = i >> 8;
     const int pp = (int)(r % 18); r /= 18;
     const int chunk = (int)(r % nch); r /= nch;
-    const int wave = (int)(r & 7);
-    const int nt = (int)(r >> 3);
+    const int wave = (int)(r % nw);
+    const int nt = (int)(r / nw);
     const int lk = lane >> 4, li = lane & 15;
     const int pos = vs ? 18 * (wave >> 2) + 2 * (pp >> 1) + (e >> 1) : 2 * pp + (e >> 1);
     const int cin = chunk * F4_KC + 2 * lk + (e & 1);
-    const int cout = vs ? nt * F4_NQ + 32 * (wave & 3) + 16 * (pp & 1) + li : nt * F4_NQ + wave * 16 + li;
+    const int cout = vs ? nt * F4_NQ + 32 * (wave & 3) + 16 * (pp & 1) + li : nt * (16 * nw) + wave * 16 + li;
     const float *g = oihw + ((int64_t)cout * Cin + cin) * 9;
     const double a = F4_PA, b = F4_PB, a2 = a * a, b2 = b * b;
     const double n0 = a2 * b2, na = 2. * a2 * (a2 - b2), nb = 2. * b2 * (b2 - a2);    // prod_{l != j} (p_j - p_l) for p_j = 0, +-a, +-b
@@ -755,7 +776,8 @@ bool wino4_image_stats() { return F4_EPI_T == 0; }
 
 bool wino4_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
     if (!c.w_wino4 || c.ks != 3 || c.stride != 1 || c.in_nchw || c.out_nchw || c.abl) return false;
-    if ((c.Hout & 3) || (c.Wout & 3) || c.Cout % F4_NQ != 0 || (c.C0 + c.C1) % F4_KC != 0 || c.C0 % F4_KC != 0) return false;
+    if ((c.Hout & 3) || (c.Wout & 3) || c.Cout % 32 != 0 || (c.C0 + c.C1) % F4_KC != 0 || c.C0 % F4_KC != 0) return false;
+    const int rawpix = f4_nq_of(c.Cout) == F4_NQ ? F4_RAWPIX : F4_RAWPIX_N;
     if ((c.R0 & 15) != 0) return false;   // a wave's 16 output channels stay on one side of a residual concat
     const int TH = c.Hout / 4, TW = c.Wout / 4;
     int h, w, n;
@@ -770,7 +792,7 @@ bool wino4_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
         h = TH; w = TW; n = F4_TILES / (TH * TW);
     }
     const int RH = c.ups ? 2 * h + 2 : 4 * h + 2, RW = c.ups ? 2 * w + 2 : 4 * w + 2;
-    if (n * RH * RW > F4_RAWPIX) return false;
+    if (n * RH * RW > rawpix) return false;
     *bh = h; *bw = w; *nimg = n;
     return true;
 }
@@ -792,7 +814,7 @@ bool wino4_preferred(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
     if (c.dispatch_B <= 0) return true;
     const int64_t tiles = c.dispatch_B * (c.Hout / 4) * (c.Wout / 4);
     const int64_t mblocks = *nimg == 1 ? tiles / F4_TILES : ceil_div(c.dispatch_B, (int64_t)*nimg);
-    return mblocks * (c.Cout / F4_NQ) >= 256;
+    return mblocks * (c.Cout / f4_nq_of(c.Cout)) >= 256;
 }
 
 int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
@@ -805,6 +827,19 @@ int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
     const_cast<ConvLaunch &>(c).phase = phase_buffer();
 #endif
     using KFn = void (*)(ConvLaunch, int, int, int);
+    const int nq = f4_nq_of(c.Cout);
+    const int64_t tiles = (int64_t)c.B * (c.Hout / 4) * (c.Wout / 4);
+    const int64_t mblocks = nimg == 1 ? tiles / F4_TILES : ceil_div(c.B, nimg);
+    if (nq != F4_NQ) {   // narrow layers: 4 or 2 waves per workgroup, up to 400 halo pixels = 4 / 7 staging items per thread
+        KFn fn = nq == 64 ? (c.ups ? &k_conv3x3_wino4<true, 0, 4, 0, 0, 4> : &k_conv3x3_wino4<false, 0, 4, 0, 0, 4>)
+                          : (c.ups ? &k_conv3x3_wino4<true, 0, 7, 0, 0, 2> : &k_conv3x3_wino4<false, 0, 7, 0, 0, 2>);
+        const int r = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), 160 * 1024);
+        if (r != DLPM_OK) return r;
+        const size_t lds = (size_t)(2 * F4_VBUF + 2 * F4_RAWBUF_N + 2 * F4_CFS) * sizeof(float);
+        fn<<<(unsigned)(mblocks * (c.Cout / nq)), nq * 4, lds, st>>>(c, bh, bw, nimg);
+        DLPM_LAUNCH_CHECK();
+        return DLPM_OK;
+    }
     const int RHp = c.ups ? 2 * bh + 2 : 4 * bh + 2, RWp = c.ups ? 2 * bw + 2 : 4 * bw + 2;
     const bool small = nimg * RHp * RWp <= F4_NT;      // two staging items per thread cover the patch
     KFn fn = c.ups ? (small ? &k_conv3x3_wino4<true, 0, 2> : &k_conv3x3_wino4<true>) : (small ? &k_conv3x3_wino4<false, 0, 2> : &k_conv3x3_wino4<false>);
@@ -842,8 +877,6 @@ int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
     }
     size_t loop_b = (size_t)(2 * F4_VBUF + 2 * F4_RAWBUF + 2 * F4_CFS) * sizeof(float);
     if (wino4_vsplit() && loop_b < (size_t)8 * 4 * 16 * 64 * sizeof(float)) loop_b = (size_t)8 * 4 * 16 * 64 * sizeof(float);   // the epilogue's exchange buffer
-    const int64_t tiles = (int64_t)c.B * (c.Hout / 4) * (c.Wout / 4);
-    const int64_t mblocks = nimg == 1 ? tiles / F4_TILES : ceil_div(c.B, nimg);
     fn<<<(unsigned)(mblocks * (c.Cout / F4_NQ)), F4_NT, loop_b, st>>>(c, bh, bw, nimg);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
@@ -854,7 +887,8 @@ int64_t wino4_weight_floats(int Cout, int Cin) { return (int64_t)Cout * Cin * 36
 int relayout_weight_wino4(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st) {
     const int64_t n = (int64_t)Cout * Cin * 36;
     DLPM_HIP(hipMemsetAsync(dst_dev + n, 0, (size_t)F4_PAD * 256 * sizeof(float), st));
-    k_relayout_weight_wino4<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin, wino4_vsplit() ? 1 : 0);
+    const int nq = f4_nq_of(Cout);
+    k_relayout_weight_wino4<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin, (nq == F4_NQ && wino4_vsplit()) ? 1 : 0, nq / 16);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }

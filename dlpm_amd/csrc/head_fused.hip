@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(HF_NT) __attribute__((amdgpu_waves_per_eu(2, 2
                 const bool item = it.co < COUT;
                 const float *px = (u.x && item) ? u.x + (int64_t)b * D + (int64_t)it.co * HW + (int64_t)it.y * W + 4 * it.q : p.wf + 4 * lane;
                 xq = *reinterpret_cast<const float4 *>(px);
-                bv = *((p.bias && item) ? p.bias + it.co : p.wf);
+                bv = *((p.bias && item) ? p.bias + it.co : p.wf);   // (no bias: the dummy load keeps the wait counts; its value is dropped below)
                 ce = *(u.x ? u.c_eps + (int64_t)tt * u.B + b : p.wf);
                 cn = *(u.x ? u.c_noise + (int64_t)tt * u.B + b : p.wf);
                 if (carry) ncf = fetch_coefs(b + G);
@@ -356,6 +356,7 @@ __global__ void __launch_bounds__(HF_NT) __attribute__((amdgpu_waves_per_eu(2, 2
         const bool item = co < COUT && !(HF_ABLATE & 4);
         const int64_t e0 = (int64_t)co * HW + (int64_t)y * W + 4 * q;
         if (item) {
+            if (!p.bias) bv = 0.f;   // a launch without bias (valid for dlpm_conv2d_f32): the dummy load above read W'[0]
             float acc[4] = {bv, bv, bv, bv};
 #pragma unroll
             for (int ky = 0; ky < 3; ky++) {

@@ -367,7 +367,7 @@ int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 no
             r = relayout_weight_wino(src, c.w_wino, c.cout, c.cin, nullptr);
             if (r != DLPM_OK) return r;
         }
-        if (wino4_enabled() && c.cout % 128 == 0 && c.cin % 8 == 0 && boundary == 0) {   // F(4x4,3x3) copy
+        if (wino4_enabled() && c.cout % 32 == 0 && c.cin % 8 == 0 && boundary == 0) {   // F(4x4,3x3) copy (128-, 64- or 32-channel n-tiles)
             DLPM_HIP(hipMalloc(&c.w_wino4, (size_t)wino4_weight_floats(c.cout, c.cin) * sizeof(float)));
             r = relayout_weight_wino4(src, c.w_wino4, c.cout, c.cin, nullptr);
             if (r != DLPM_OK) return r;
@@ -925,6 +925,9 @@ extern "C" int dlpm_unet_bind_time_table(dlpm_unet *net, const float *table_dev,
     DLPM_CHECK_ARG(net && ((table_dev == nullptr) == (row_index_dev == nullptr)), "dlpm_unet_bind_time_table: give both pointers or neither");
     // per HOST THREAD, not per net: two samplers that share one net from different threads each see their own binding while
     // they enqueue (round 3 kept it in the net, where one thread's table could be baked into the other's captured graph)
+    // ONE binding per host thread: binding a second net replaces the first; un-binding (null pointers) clears the slot only if
+    // `net` is the net it holds -- un-binding net A must not drop net B's table
+    if (!table_dev && tl_time_net != net) return DLPM_OK;
     tl_time_net = table_dev ? net : nullptr;
     tl_time_table = table_dev;
     tl_time_index = row_index_dev;
@@ -1113,21 +1116,21 @@ extern "C" int dlpm_conv2d_f32(const dlpm_conv_args *a, float *scratch_dev, dlpm
         float *wf = scratch_dev + (int64_t)a->Cout * (a->C0 + a->C1) * 9;
         TRY(relayout_weight_frag(a->weight, wf, a->Cout, a->C0 + a->C1, st));
         L.w_frag = wf;
-        const int64_t used = (int64_t)a->Cout * (a->C0 + a->C1) * 9 + frag_weight_floats(a->Cout, a->C0 + a->C1);
-        if (!(a->force_direct & 2) && a->stride == 1 && a->Cout % 64 == 0 && !a->in_nchw && !a->out_nchw &&
-            a->scratch_floats >= used + wino_weight_floats(a->Cout, a->C0 + a->C1)) {
+        int64_t used = (int64_t)a->Cout * (a->C0 + a->C1) * 9 + frag_weight_floats(a->Cout, a->C0 + a->C1);
+        const bool wino_shape = !(a->force_direct & 2) && a->stride == 1 && !a->in_nchw && !a->out_nchw;
+        if (wino_shape && a->Cout % 64 == 0 && a->scratch_floats >= used + wino_weight_floats(a->Cout, a->C0 + a->C1)) {
             float *ww = scratch_dev + used;
             TRY(relayout_weight_wino(a->weight, ww, a->Cout, a->C0 + a->C1, st));
             L.w_wino = ww;
-            // bit 8: the F(4x4,3x3) kernel where the shape qualifies (its weights go behind the F(2x2) copy)
-            const int64_t used4 = used + wino_weight_floats(a->Cout, a->C0 + a->C1);
-            if ((a->force_direct & 8) && a->Cout % 128 == 0 && (a->C0 + a->C1) % 8 == 0 &&
-                a->scratch_floats >= used4 + wino4_weight_floats(a->Cout, a->C0 + a->C1)) {
-                float *w4 = scratch_dev + used4;
-                TRY(relayout_weight_wino4(a->weight, w4, a->Cout, a->C0 + a->C1, st));
-                L.w_wino4 = w4;
-                L.w_wino = nullptr;   // no F(2x2) alternative: every qualifying geometry takes the F(4x4) kernel
-            }
+            used += wino_weight_floats(a->Cout, a->C0 + a->C1);
+        }
+        // bit 8: the F(4x4,3x3) kernel where the shape qualifies (128-, 64- or 32-channel n-tiles; its weights go behind the F(2x2) copy)
+        if (wino_shape && (a->force_direct & 8) && a->Cout % 32 == 0 && (a->C0 + a->C1) % 8 == 0 &&
+            a->scratch_floats >= used + wino4_weight_floats(a->Cout, a->C0 + a->C1)) {
+            float *w4 = scratch_dev + used;
+            TRY(relayout_weight_wino4(a->weight, w4, a->Cout, a->C0 + a->C1, st));
+            L.w_wino4 = w4;
+            L.w_wino = nullptr;   // no F(2x2) alternative: every qualifying geometry takes the F(4x4) kernel
         }
     }
     if ((a->force_direct & 64) && a->ksize == 3 && a->Cout <= 3 && a->C0 % 32 == 0 && a->C1 == 0) {
@@ -1186,6 +1189,10 @@ extern "C" int dlpm_attention_f32(const float *qkv, float *out, int32_t B, int32
 
 extern "C" int dlpm_resblock_small_f32(const dlpm_resblock_args *a, float *scratch_dev, int64_t scratch_floats, dlpm_stream_t stream) {
     DLPM_CHECK_ARG(a && a->x0 && a->conv1_w && a->conv2_w && a->ss && a->out && scratch_dev, "dlpm_resblock_small_f32: null argument");
+    // every parameter the kernel reads at entry (it has no optional ones but the skip convolution and the statistics)
+    DLPM_CHECK_ARG(a->gn1_w && a->gn1_b && a->gn2_w && a->gn2_b && a->conv1_b && a->conv2_b, "dlpm_resblock_small_f32: null GroupNorm / bias parameter");
+    DLPM_CHECK_ARG(!a->skip_w || a->skip_b, "dlpm_resblock_small_f32: skip_w without skip_b");
+    DLPM_CHECK_ARG(a->B > 0 && a->H == a->W && (a->H == 8 || a->H == 4), "dlpm_resblock_small_f32: B %d, %d x %d images (8x8 or 4x4)", a->B, a->H, a->W);
     DLPM_CHECK_ARG((a->C1 == 0) == (a->x1 == nullptr), "dlpm_resblock_small_f32: x1/C1 mismatch");
     const int Cin = a->C0 + a->C1;
     const int64_t n1 = (int64_t)64 * Cin * 9, n2 = (int64_t)64 * 64 * 9, ns = a->skip_w ? (int64_t)64 * Cin : 0;
@@ -1208,6 +1215,8 @@ extern "C" int dlpm_resblock_small_f32(const dlpm_resblock_args *a, float *scrat
 
 extern "C" int dlpm_attnblock_small_f32(const dlpm_attnblock_args *a, float *scratch_dev, int64_t scratch_floats, dlpm_stream_t stream) {
     DLPM_CHECK_ARG(a && a->x && a->qkv_w && a->proj_w && a->out && scratch_dev, "dlpm_attnblock_small_f32: null argument");
+    DLPM_CHECK_ARG(a->gn_w && a->gn_b && a->qkv_b && a->proj_b, "dlpm_attnblock_small_f32: null GroupNorm / bias parameter");
+    DLPM_CHECK_ARG(a->B > 0 && a->H == a->W && (a->H == 8 || a->H == 4), "dlpm_attnblock_small_f32: B %d, %d x %d images (8x8 or 4x4)", a->B, a->H, a->W);
     DLPM_CHECK_ARG(a->C == 64 && a->heads == 4, "dlpm_attnblock_small_f32: 64 channels, 4 heads (got %d, %d)", a->C, a->heads);
     const int64_t nq = (int64_t)192 * 64, np = (int64_t)64 * 64;
     DLPM_CHECK_ARG(scratch_floats >= nq + np, "dlpm_attnblock_small_f32: scratch of %lld floats, need %lld", (long long)scratch_floats,

@@ -316,8 +316,9 @@ int dlpm_unet_forward(dlpm_unet *net, const float *x_dev, const float *t_dev, fl
  * and binds the table with the device step counter that picks the row: while a table is bound, dlpm_unet_forward_uniform_t /
  * dlpm_unet_forward_update read row *row_index_dev instead of running the four time-path launches (same kernels produced the
  * rows: same bits).  Bind (NULL, NULL) to unbind.  The pointers are baked into a captured graph like every other argument.
- * The binding belongs to the CALLING HOST THREAD (and names the net): forward calls this thread enqueues for that net read the
- * table; other threads, and other nets, do not see it.  The rows depend on the net's weights and GEMM policy: whoever caches
+ * ONE binding per CALLING HOST THREAD, which names the net: forward calls this thread enqueues for THAT net read the table; other
+ * threads, and other nets, do not see it.  Binding a second net on the same thread REPLACES the first (no per-net map: bind, enqueue,
+ * unbind -- as dlpm_sampler does); unbinding net A while net B is the one bound leaves B's binding alone.  The rows depend on the net's weights and GEMM policy: whoever caches
  * a table recomputes it when dlpm_unet_plan_version moves (dlpm_sampler does, before its next step). */
 int64_t dlpm_unet_time_embedding_width(const dlpm_unet *net);
 int64_t dlpm_unet_time_embeddings_scratch_bytes(const dlpm_unet *net, int64_t M);

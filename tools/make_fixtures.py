@@ -486,8 +486,28 @@ def f5_bounded_unet_trajectories():
              ('f5_traj_unet_mnist_clip_T1000', 1000, 2, 100, 'EPSILON', 1.0, 'mnist', 1, 32, 1.7, 20, 200),
              # BASELINE configs[4]'s per-GPU net: the CIFAR architecture at 64x64 (dlpm_amd/configs/celeba64.yml), alpha = 1.8, B = 1
              ('f5_traj_unet_celeba64_clip_T1000', 1000, 1, 100, 'EPSILON', 1.0, 'cifar', 3, 64, 1.8, 10, 50)]
+    # Round 5: the headline configuration at B = 8 as well (B = 2 was the only batch the cifar10.yml net had been compared at; recorded
+    # every 250th state to keep the file small), and -- for EVERY case -- how informative the fixture is: the same reference run is
+    # repeated with the network's output multiplied by (1 + 1e-4 N(0, 1)) (its own seeded generator: the sampler's streams are
+    # untouched), and `sensitivity` = max |delta of the post-processed final pixels| / 1e-4 (`sensitivity_state`: of the raw final
+    # state) is stored beside the trajectory.  A sensitivity of 0.3 means a network that is wrong by 3e-4 relative -- any reduced-
+    # precision arithmetic -- breaks the 1e-4 pixel contract on this fixture; tests print it beside the error they measure.
+    cases.append(('f5_traj_unet_cifar_clip_T1000_b8', 1000, 8, 250, 'EPSILON', 1.0, 'cifar', 3, 32, 1.7, 10, 50))
     only = os.environ.get('F5B_ONLY')
     archs = {'wide': (128, [1, 2], [2], 2), 'cifar': (128, [1, 2, 2, 2], [4, 8, 16], 2), 'mnist': (32, [1, 2, 2, 2], [2, 4], 2)}
+
+    class Perturbed(torch.nn.Module):   # net(x, t) * (1 + rel * N(0, 1)), drawn from a generator of its own
+        def __init__(self, net, rel, seed):
+            super().__init__()
+            self.net, self.rel, self.g = net, rel, torch.Generator().manual_seed(seed)
+
+        def forward(self, x, t, **kw):
+            y = self.net(x, t, **kw)
+            return y * (1 + self.rel * torch.randn(y.shape, generator=self.g))
+
+    def post(x):   # what GenerationManager returns for images (bem/GenerationManager.py:50-63)
+        return (x.clamp(-1, 1) + 1) / 2
+
     for name, T, B, every, mean_type, head_scale, arch, chans, size, alpha, ca, ce in cases:
         if only and only not in name:
             continue
@@ -499,19 +519,34 @@ def f5_bounded_unet_trajectories():
             with torch.no_grad():
                 net.out[2].weight.mul_(head_scale)
                 net.out[2].bias.mul_(head_scale)
-        np.random.seed(0)
-        torch.manual_seed(0)
         shape = [B, chans, size, size]
-        meth = GenerativeLevyProcess(alpha=alpha, device='cpu', reverse_steps=T, rescale_timesteps=True)
-        meth.model_mean_type = mean_type
-        x, hist = meth.sample({'default': net}, shape, T, clamp_a=ca, clamp_eps=ce, clip_denoised=True, get_sample_history=True)
+
+        def run(model):
+            np.random.seed(0)
+            torch.manual_seed(0)
+            meth = GenerativeLevyProcess(alpha=alpha, device='cpu', reverse_steps=T, rescale_timesteps=True)
+            meth.model_mean_type = mean_type
+            return meth.sample({'default': model}, shape, T, clamp_a=ca, clamp_eps=ce, clip_denoised=True, get_sample_history=True)
+
+        x, hist = run(net)
         inside = float((x.abs() < 1).float().mean())
         print('%s: |x| max %.4g, %.1f %% of the final pixels inside (-1, 1), max |state| over the run %.4g'
               % (name, float(x.abs().max()), 100 * inside, float(hist.abs().max())))
         assert inside >= 0.5, name
+        path = os.path.join(OUT, name + '.npz')
+        if os.path.exists(path):   # a fixture that is already committed keeps its trajectory: this run must reproduce it bit for bit
+            old = np.load(path)
+            assert np.array_equal(old['final'], x.numpy()) and np.array_equal(old['history_sub'], hist[::every].numpy()), \
+                '%s: this run of the reference does not reproduce the committed trajectory' % name
+        REL = 1e-4
+        xp, _ = run(Perturbed(net, REL, 77))
+        sens = float((post(xp) - post(x)).abs().max()) / REL
+        sens_state = float((xp - x).abs().max()) / REL
+        print('    sensitivity to a %.0e relative perturbation of the network output: post-processed pixels %.3g, final state %.3g'
+              % (REL, sens, sens_state))
         save(name, final=x, history_sub=hist[::every], every=np.array(every), meta=np.array([T, alpha, ca, ce]),
              mean_type=np.array(mean_type), shape=np.array(shape), inside=np.array(inside), head_scale=np.array(head_scale),
-             arch=np.array(arch),
+             arch=np.array(arch), sensitivity=np.array(sens), sensitivity_state=np.array(sens_state), sensitivity_rel=np.array(REL),
              digest=np.frombuffer(bytes.fromhex(weight_digest(net)), dtype=np.uint8))
 
 

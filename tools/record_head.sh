@@ -5,6 +5,8 @@
 # chip holds (DLPM_BUILD_DEFS="DLPM_PHASE_TIMING HF_CLOCK_ONLY [HF_ABLATE=1|2|3|7|8]") and the SQ / FETCH / WRITE counters.
 out=${1:-gpurun_out/head_forms}
 mkdir -p $out
+# the access-pattern microbenchmark is built on demand (no binary in the tree)
+[ -x tools/mb/stream_pattern ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/mb/stream_pattern tools/mb/stream_pattern.hip
 ./tools/mb/stream_pattern > $out/mb_stream_pattern.txt 2>&1
 {
   echo "# tools/bench_head.py --reps 30: the one-pass kernel on the bf16 pipe (fused) and on the fp32 MFMA (fused32), round 3's GEMM + gather pair, the VALU kernel"
