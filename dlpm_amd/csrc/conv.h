@@ -92,7 +92,7 @@ int relayout_weight_wino(const float *oihw_dev, float *dst_dev, int Cout, int Ci
 // Winograd F(4x4,3x3) path (conv_wino4.hip): 16 tiles of 4x4 outputs x 128 channels per workgroup
 bool wino4_enabled();                  // DLPM_WINO_F4
 bool wino4_vsplit();                   // DLPM_WINO_VS: waves = position halves x channel quarters (weight fragment order follows)
-bool wino4_image_stats();              // the build's epilogue emits per-image statistics for blocks of four 8x8 images
+bool wino4_image_stats(int cout);      // this layer's epilogue emits per-image statistics for blocks of four 8x8 images
 bool wino4_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg);
 bool wino4_preferred(const ConvLaunch &c, int *bh, int *bw, int *nimg);   // geometry + dispatch policy
 int launch_conv_wino4(const ConvLaunch &c, hipStream_t st);

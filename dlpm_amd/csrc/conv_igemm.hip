@@ -1158,7 +1158,7 @@ int conv_stats_pixels(const ConvLaunch &c) {
         const int64_t hw = (int64_t)c.Hout * c.Wout;
         return (c.R0 & 3) ? 0 : hw % BM == 0 ? BM : hw == 64 ? 64 : 0;
     }
-    if (wino4_preferred(c, &a, &b, &n)) return n == 1 ? 256 : (n == 4 && a * b == 4 && wino4_image_stats()) ? 64 : 0;   // (four whole 8x8 images per block: one partial per image)
+    if (wino4_preferred(c, &a, &b, &n)) return n == 1 ? 256 : (n == 4 && a * b == 4 && wino4_image_stats(c.Cout)) ? 64 : 0;   // (four whole 8x8 images per block: one partial per image)
     if (wino_geometry(c, &a, &b, &n)) return n == 1 ? 4 * wino_tiles(c) : 0;
     if (c.out_nchw || (c.Cout & 3) || (c.R0 & 3)) return 0;
     return ((int64_t)c.Hout * c.Wout) % BM == 0 ? BM : 0;

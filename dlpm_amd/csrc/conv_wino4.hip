@@ -51,10 +51,15 @@ constexpr int F4_QNIT = (F4_RAWPIX * 2 + F4_NT - 1) / F4_NT;   // staging items 
                                                                // (only 16 one-tile images fill it; every other block shape is <= 512 pixels: QN = 2)
 constexpr int F4_RAWBUF = F4_RAWPIX * F4_PRLD + 16;   // floats per raw buffer, row skew included
 // Round 5 -- narrow layers (Cout a multiple of 32 but not of 128: the 32- and 64-channel levels of the MNIST-sized nets).  The work
-// split is the wave's: 16 output channels x 36 positions x 16 tiles, so a workgroup of NW waves covers 16 NW channels: NW = 4 (64) or
-// 2 (32) waves on the same 16-tile block, the same V / raw / weight-fragment layouts, more staging items per thread (QN), a raw buffer
-// for halo patches of <= 400 pixels (an 18x18 block patch, or four 10x10 images: two workgroups fit a CU's LDS).  With two waves the
-// three row pairs of the input transform go 2 + 1.
+// split is the wave's: 16 output channels x 36 positions x 16 tiles, so a 16-tile block of a 64- / 32-channel n-tile has MFMA work for
+// NW = 4 / 2 waves only -- and the SAME staging and input transform as a 128-channel one.  Letting those few waves carry the side
+// work between their MFMAs (the 8-wave kernel's scheme, where it is 1/8 of a wave's instructions) made a phase 6-15 k cycles for
+// 2.3 k cycles of MFMAs: one wave per SIMD, nothing hides a wait.  So the input transform gets waves of its own: NW MFMA waves (weight
+// ring, A fragments, MFMAs, their share of the staging between the MFMAs as in the 8-wave kernel, epilogue) + HELPER waves that stage
+// their share and run the transform -- 3 (one row pair of B^T each) beside 4 MFMA waves, 2 (row pairs 0 + 1 | 2) beside 2, so that two
+// of the 32-channel workgroups fit a CU (4 waves x 255 registers).  (Helpers that also did ALL the staging were the long pole: 6.2 k
+// cycles per phase against 2.3 k of MFMAs, profiles/r05/.)  One barrier per phase as before; same V / raw / weight-fragment layouts, same
+// arithmetic per output as the 8-wave shape; raw buffer for halo patches of <= 400 pixels (an 18x18 block patch, or four 10x10 images).
 constexpr int F4_RAWPIX_N = 400;
 constexpr int F4_RAWBUF_N = F4_RAWPIX_N * F4_PRLD + 16;
 constexpr int f4_nq_of(int cout) { return cout % 128 == 0 ? 128 : cout % 64 == 0 ? 64 : 32; }
@@ -81,6 +86,9 @@ constexpr int F4_PAD = 8;         // float4 fragments of zero padding behind the
                     // instructions per lane -- bit-identical outputs, measured 0.3-0.7 % SLOWER over the eight layer shapes
                     // (profiles/r03/conv_layers_transposed_epilogue.txt: the same 512 cache-line accesses per wave either way);
                     // 0 (the build): lane = channel, 4 tiles
+#endif
+#ifndef F4N_ABL
+#define F4N_ABL 0   // developer builds (DLPM_BUILD_DEFS), narrow shapes' epilogue, timing only (results are wrong): 1 no stores, 2 no residual loads, 4 no statistics
 #endif
 #ifndef F4_SKIP_TAIL
 #define F4_SKIP_TAIL 0   // 1: skip the look-ahead staging / transform of the last phases (they feed chunks that do not exist): 2 of 16 phases'
@@ -131,8 +139,14 @@ __device__ __forceinline__ float2 f2sub(float2 x, float2 y) { return make_float2
 // per (tile, channel), hands the partials of the channel tile its PARTNER finalises over through LDS (one barrier pair, 128 KB: the
 // loop's buffers are dead by then) and runs the unchanged register epilogue on the other.
 template <bool UPS, int ABL = 0, int QN = F4_QNIT, int SPEC = 0, int VS = 0, int NW = 8>
-__global__ void __launch_bounds__(NW * 64, 1) k_conv3x3_wino4(ConvLaunch p_in, int bh_in, int bw_in, int nimg_in) {
-    constexpr int F4_NT = NW * 64, F4_NQ = NW * 16;                       // (shadow the main shape's constants)
+__global__ void __launch_bounds__((NW + (NW == 8 ? 0 : NW == 4 ? 3 : 2)) * 64, NW == 2 ? 2 : 1) k_conv3x3_wino4(ConvLaunch p_in, int bh_in, int bw_in, int nimg_in) {
+    constexpr bool HELP = NW != 8;                                        // MFMA waves 0 .. NW-1 + helper waves NW .. NW+NH-1
+    constexpr int NH = NW == 8 ? 0 : NW == 4 ? 3 : 2;
+    constexpr int F4_NT = (NW + NH) * 64, F4_NQ = NW * 16;                // threads, channels (shadow the main shape's constants)
+    // Transposed accumulators (lane = tile, 4 consecutive channels: 16-byte epilogue accesses, 32 instead of 128 memory instructions per
+    // lane): F4_EPI_T above.
+    constexpr bool EPI_T = F4_EPI_T != 0;   // (measured on the narrow shapes too, with the residual requested ahead: 64 float4 of residual + Y beside the
+                                            //  accumulators spill 48-63 registers and the epilogue gets LONGER, 28 -> 35 k cycles: profiles/r05/)
     constexpr int F4_RAWBUF = NW == 8 ? dlpm::F4_RAWBUF : F4_RAWBUF_N;
     static_assert(NW == 8 || (VS == 0 && SPEC == 0), "wave-split and specialised forms exist for the 128-channel shape only");
     ConvLaunch p = p_in;
@@ -157,6 +171,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_conv3x3_wino4(ConvLaunch p_in, i
     const long long _c0 = clock64(), _r0 = wall_clock64();   // shader cycles and 100-MHz ticks: their ratio is the clock the chip holds
 #endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool mfma_wave = !HELP || wave < NW;                 // wave-uniform
     const int li = lane & 15, lk = lane >> 4;
     const int W = p.Wout, H = p.Hout, TW = W >> 2, TH = H >> 2;
     const int Ws = UPS ? (W >> 1) : W, Hs = UPS ? (H >> 1) : H;
@@ -306,13 +321,18 @@ __global__ void __launch_bounds__(NW * 64, 1) k_conv3x3_wino4(ConvLaunch p_in, i
         row_out(Tb, a1);
     };
     auto transform = [&](int slot) {
-        if (NW >= 3) {
-            if (wave < 3) transform_rp(slot, wave);
-        } else if (wave == 0) {
-            transform_rp(slot, 0);
-            transform_rp(slot, 1);
-        } else {
-            transform_rp(slot, 2);
+        if (HELP) {
+            if (mfma_wave) return;
+            if (NH == 3) {
+                transform_rp(slot, wave - NW);
+            } else if (wave == NW) {
+                transform_rp(slot, 0);
+                transform_rp(slot, 1);
+            } else {
+                transform_rp(slot, 2);
+            }
+        } else if (wave < 3) {
+            transform_rp(slot, wave);
         }
     };
 
@@ -343,8 +363,10 @@ __global__ void __launch_bounds__(NW * 64, 1) k_conv3x3_wino4(ConvLaunch p_in, i
         cfr1 = *reinterpret_cast<const float4 *>(cf_base + min(1, last) * F4_KC);
         cfr2 = *reinterpret_cast<const float4 *>(cf_base + min(2, last) * F4_KC);
     }
+    if (mfma_wave) {
 #pragma unroll
-    for (int a = 0; a < AHEAD; a++) bq[a] = wp[a * 64 + lane];
+        for (int a = 0; a < AHEAD; a++) bq[a] = wp[a * 64 + lane];
+    }
     store_coef(0);
     cfr = cfr1;
     store_coef(1);
@@ -374,7 +396,13 @@ __global__ void __launch_bounds__(NW * 64, 1) k_conv3x3_wino4(ConvLaunch p_in, i
         for (int a = 0; a < F4_AAHEAD; a++)
             if (!VS) aq[a] = (ABL & 64) ? make_float4(1.f, 2.f, 1.f, 2.f) : *reinterpret_cast<const float4 *>(ab + a * (4 * F4_TILES * 4));
         if (ABL & 64) aq[F4_AAHEAD] = make_float4(1.f, 2.f, 1.f, 2.f);
-        if (VS) {
+        if (HELP && !mfma_wave) {
+            // helper wave: its share of S(chunk+2) raw stores and G(chunk+3) global loads, X(chunk+1) its row pair(s) of the transform
+#pragma unroll
+            for (int it = 0; it < QN; it++) store_raw_item(cur, it);
+            load_raw_into(xr, min(chunk + 3, last));
+            transform(nxt);
+        } else if (VS) {
             // slot s = (position pair pp = s / 2 of this wave's nine, channel tile nt = s % 2): 18 slots, one weight fragment and four
             // MFMAs each, side work keyed on the slot exactly as on the position pair of the VS = 0 loop
             const float *abh = ab + (wave >> 2) * 9 * (4 * F4_TILES * 4);
@@ -410,7 +438,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_conv3x3_wino4(ConvLaunch p_in, i
 #else
             if (!(ABL & 1) && pp >= F4_S0 && pp < F4_S0 + QN) store_raw_item(cur, pp - F4_S0);   // S(chunk+2): raw[cur] was read by X(chunk), a barrier ago
             if (!(ABL & 4) && pp == F4_S0 + QN) load_raw_into(xr, min(chunk + 3, last));        // G(chunk+3)
-            if (!(ABL & 2) && pp == F4_X) transform(nxt);                                             // X(chunk+1): raw[nxt] -> V[nxt]
+            if (!HELP && !(ABL & 2) && pp == F4_X) transform(nxt);                                    // X(chunk+1): raw[nxt] -> V[nxt] (narrow shapes: the helper waves')
 #endif
             if (!(ABL & 16)) bq[(pp + AHEAD) % F4_RING] = wp[AHEAD * 64 + lane];
             wp += 64;
@@ -426,19 +454,19 @@ __global__ void __launch_bounds__(NW * 64, 1) k_conv3x3_wino4(ConvLaunch p_in, i
             // fill the pipe behind it.  Measured 45.6 -> 43.9 ms/step (the opposite assignment: 44.4)
             if (F4_PRIO) __builtin_amdgcn_s_setprio(0);
             if (!(ABL & 32)) {
-#if F4_EPI_T
+            if constexpr (EPI_T) {
             // operands swapped: D rows = the wave's 16 output channels, D columns = the 16 tiles, i.e. a lane (li = tile, lk)
             // ends up with FOUR CONSECUTIVE CHANNELS (4 lk + r) of one tile -- same products, same order, transposed registers
             acc[2 * pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, a0.x, acc[2 * pp], 0, 0, 0);
             acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, a1.x, acc[2 * pp + 1], 0, 0, 0);
             acc[2 * pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, a0.y, acc[2 * pp], 0, 0, 0);
             acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.w, a1.y, acc[2 * pp + 1], 0, 0, 0);
-#else
+            } else {
             acc[2 * pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc[2 * pp], 0, 0, 0);
             acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.z, acc[2 * pp + 1], 0, 0, 0);
             acc[2 * pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc[2 * pp], 0, 0, 0);
             acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.w, acc[2 * pp + 1], 0, 0, 0);
-#endif
+            }
             } else {
                 acc[2 * pp][0] += a0.x * b.x + a0.y * b.y;   // keep the operands alive
                 acc[2 * pp + 1][0] += a1.x * b.z + a1.y * b.w;
@@ -458,12 +486,12 @@ __global__ void __launch_bounds__(NW * 64, 1) k_conv3x3_wino4(ConvLaunch p_in, i
     if (ABL & 8) __syncthreads();
     if (F4_PRIO) __builtin_amdgcn_s_setprio(0);
     DLPM_PHASE(p, 9);
+    if (HELP && !mfma_wave) return;   // (no barrier behind the loop: the epilogue runs out of the MFMA waves' registers)
 #ifdef DLPM_PHASE_TIMING
     if (p.phase && lane == 0) atomicAdd(p.phase + 16 + wave, (unsigned long long)_wait);
 #endif
 
-#if F4_EPI_T
-    {
+    if constexpr (EPI_T) {
         // ---- epilogue from registers: no LDS, no barrier.  With the MFMA operands swapped a lane (li = tile, lk) holds
         // M_pos[tile li][channels 16 wave + 4 lk .. + 3] in acc[pos][0..3]: the output transform runs once per channel, and
         // bias / residual / stores move FOUR consecutive channels of a pixel per instruction (16 bytes per lane, the four lk
@@ -559,9 +587,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_conv3x3_wino4(ConvLaunch p_in, i
                 for (int c = 0; c < 4; c++) so[c] = make_float2(mean[c], M2[c]);
             }
         }
-    }
-#else
-    {
+    } else {
         // ---- epilogue from registers: no LDS, no barrier.  A lane holds 64 outputs of ONE channel (4 tiles x 16 pixels:
         // M_pos[tile 4 lk + r][channel 16 wave + li] in acc[pos][r]), so the output transform, bias, residual, the fused
         // GroupNorm statistics (per-lane shifted sums, then the four 16-lane groups merged in a fixed order) and the stores
@@ -622,8 +648,9 @@ __global__ void __launch_bounds__(NW * 64, 1) k_conv3x3_wino4(ConvLaunch p_in, i
         // statistics: one partial per 256-pixel block inside an image (nimg == 1), or -- four whole 8x8 images per block, four tiles
         // each -- one per IMAGE: a lane's 64 outputs (tiles 4 lk .. 4 lk + 3) are then exactly image lk's pixels of its channel
         const bool img_stats = p.stats_out != nullptr && nimg == 4 && bh * bw == 4;
-        const bool do_stats = (p.stats_out != nullptr && nimg == 1) || img_stats;
+        const bool do_stats = ((p.stats_out != nullptr && nimg == 1) || img_stats) && !(HELP && (F4N_ABL & 4));
         float K = 0.f, s1 = 0.f, s2 = 0.f;
+        float rs_all[HELP ? 4 : 1][16];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int tile = 4 * lk + r;
@@ -633,7 +660,24 @@ __global__ void __launch_bounds__(NW * 64, 1) k_conv3x3_wino4(ConvLaunch p_in, i
             float rs[16];
             // addresses = wave-uniform base (block origin + pixel (i, j) of the tile) + a 32-bit per-lane byte offset
             const uint32_t bo_o = (uint32_t)(tpix * p.Cout + ch) * 4u, bo_r = (uint32_t)(tpix * res_ld + ch) * 4u;
-            if (has_res && ok) {
+            if (HELP) {
+                // narrow shapes (one or two waves per SIMD, nothing else hides a wait): ALL four tiles' residual values are requested
+                // before the first output transform -- the registers of the weight ring and the A fragments are free by now
+                if (r == 0 && has_res && !(F4N_ABL & 2)) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) {
+                        const int t2 = 4 * lk + rr;
+                        const int tp2 = ((t2 >> lbhw) * H + 4 * ((t2 & (bh * bw - 1)) >> lbw)) * W + 4 * (t2 & (bw - 1));
+                        const uint32_t b2 = (uint32_t)(tp2 * res_ld + ch) * 4u;
+                        const bool ok2 = img0 + (t2 >> lbhw) < p.B;
+#pragma unroll
+                        for (int k = 0; k < 16; k++)
+                            rs_all[rr][k] = ok2 ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(res_blk + ((k >> 2) * W + (k & 3)) * res_ld) + b2) : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++) rs[k] = rs_all[r][k];
+            } else if (has_res && ok) {
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -681,6 +725,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_conv3x3_wino4(ConvLaunch p_in, i
                         s1 += dd;
                         s2 = fmaf(dd, dd, s2);
                     }
+                    if (HELP && (F4N_ABL & 1)) { if (v == 123.456f) *reinterpret_cast<float *>(reinterpret_cast<char *>(out_blk) + bo_o) = v; continue; }
                     *reinterpret_cast<float *>(reinterpret_cast<char *>(out_blk + (i * W + j) * p.Cout) + bo_o) = v;
                 }
             }
@@ -703,7 +748,6 @@ __global__ void __launch_bounds__(NW * 64, 1) k_conv3x3_wino4(ConvLaunch p_in, i
             if (lk == 0) p.stats_out[((int64_t)img0 * ((H * W) / 256) + blk_in_img) * p.Cout + ch] = make_float2(mean, M2);
         }
     }
-#endif
     DLPM_PHASE(p, 10);
 #ifdef DLPM_PHASE_TIMING
     if (p.phase && tid == 0) {
@@ -772,9 +816,17 @@ bool wino4_vsplit() {
     if (v < 0) { const char *e = getenv("DLPM_WINO_VS"); v = e ? atoi(e) : 0; }
     return v != 0;
 }
-bool wino4_image_stats() { return F4_EPI_T == 0; }
+bool wino4_image_stats(int cout) { (void)cout; return F4_EPI_T == 0; }
+
+// DLPM_WINO4_NARROW=0 (A/B runs): the 64- / 32-channel n-tile shapes off -- those layers take F(2x2) / the implicit GEMM as in rounds 1-4
+static bool narrow_enabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DLPM_WINO4_NARROW"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
 
 bool wino4_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
+    if (c.Cout % F4_NQ != 0 && !narrow_enabled()) return false;
     if (!c.w_wino4 || c.ks != 3 || c.stride != 1 || c.in_nchw || c.out_nchw || c.abl) return false;
     if ((c.Hout & 3) || (c.Wout & 3) || c.Cout % 32 != 0 || (c.C0 + c.C1) % F4_KC != 0 || c.C0 % F4_KC != 0) return false;
     const int rawpix = f4_nq_of(c.Cout) == F4_NQ ? F4_RAWPIX : F4_RAWPIX_N;
@@ -830,13 +882,13 @@ int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
     const int nq = f4_nq_of(c.Cout);
     const int64_t tiles = (int64_t)c.B * (c.Hout / 4) * (c.Wout / 4);
     const int64_t mblocks = nimg == 1 ? tiles / F4_TILES : ceil_div(c.B, nimg);
-    if (nq != F4_NQ) {   // narrow layers: 4 or 2 waves per workgroup, up to 400 halo pixels = 4 / 7 staging items per thread
-        KFn fn = nq == 64 ? (c.ups ? &k_conv3x3_wino4<true, 0, 4, 0, 0, 4> : &k_conv3x3_wino4<false, 0, 4, 0, 0, 4>)
-                          : (c.ups ? &k_conv3x3_wino4<true, 0, 7, 0, 0, 2> : &k_conv3x3_wino4<false, 0, 7, 0, 0, 2>);
+    if (nq != F4_NQ) {   // narrow layers: 4 MFMA + 3 helper waves (448 threads: 2 staging items cover 400 halo pixels), or 2 + 2 (256 threads: 4 items)
+        KFn fn = nq == 64 ? (c.ups ? &k_conv3x3_wino4<true, 0, 2, 0, 0, 4> : &k_conv3x3_wino4<false, 0, 2, 0, 0, 4>)
+                          : (c.ups ? &k_conv3x3_wino4<true, 0, 4, 0, 0, 2> : &k_conv3x3_wino4<false, 0, 4, 0, 0, 2>);
         const int r = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), 160 * 1024);
         if (r != DLPM_OK) return r;
         const size_t lds = (size_t)(2 * F4_VBUF + 2 * F4_RAWBUF_N + 2 * F4_CFS) * sizeof(float);
-        fn<<<(unsigned)(mblocks * (c.Cout / nq)), nq * 4, lds, st>>>(c, bh, bw, nimg);
+        fn<<<(unsigned)(mblocks * (c.Cout / nq)), (nq == 64 ? 7 : 4) * 64, lds, st>>>(c, bh, bw, nimg);
         DLPM_LAUNCH_CHECK();
         return DLPM_OK;
     }

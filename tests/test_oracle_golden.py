@@ -340,8 +340,9 @@ def test_tiny_unet_trajectory_T1000_oracle_vs_reference():
 
 
 BOUNDED = ['f5_traj_unet_wide_clip', 'f5_traj_unet_wide_startx_clip', 'f5_traj_unet_wide_startx_clip_damped', 'f5_traj_unet_wide_clip_T1000',
-           'f5_traj_unet_cifar_clip_T1000', 'f5_traj_unet_mnist_clip_T1000', 'f5_traj_unet_celeba64_clip_T1000']
-# the last three: BASELINE configs[2], [1] and [4]'s own nets, image sizes, T = 1000 and alpha (B = 2, 2, 1)
+           'f5_traj_unet_cifar_clip_T1000', 'f5_traj_unet_mnist_clip_T1000', 'f5_traj_unet_celeba64_clip_T1000',
+           'f5_traj_unet_cifar_clip_T1000_b8']
+# the last four: BASELINE configs[2], [1] and [4]'s own nets, image sizes, T = 1000 and alpha (B = 2, 2, 1), and configs[2]'s at B = 8
 
 
 @pytest.mark.parametrize('name', BOUNDED)
@@ -381,7 +382,7 @@ def test_bounded_wide_unet_trajectories_oracle_vs_reference(name):
         k0 = 900
         for _ in range(k0):
             streams.randn(shape)                                       # the z of the steps already taken
-        x = T_(want[k0 // every])
+        x = T_(f['state_900'] if 'state_900' in f else want[k0 // every])
         states = {}
         with torch.no_grad():
             for k in range(k0, T - 1):                                 # step k takes state k to state k + 1 at i = T - 1 - k
@@ -400,8 +401,10 @@ def test_bounded_wide_unet_trajectories_oracle_vs_reference(name):
     err_state = float(np.abs(got - want).max())
     post = lambda v: P.generation_postprocess(torch.from_numpy(np.asarray(v)), True).numpy()
     err = float(np.abs(post(x.numpy()) - post(fin)).max())
-    print('%s: %.1f %% of the final pixels inside (-1, 1); oracle vs reference: states %.3g, post-processed pixels %.3g (absolute)'
-          % (name, 100 * inside, err_state, err))
+    print('%s: %.1f %% of the final pixels inside (-1, 1); oracle vs reference: states %.3g, post-processed pixels %.3g (absolute); '
+          'fixture sensitivity %.3g (max |delta pixels| per unit relative error of the network output, measured on the reference)'
+          % (name, 100 * inside, err_state, err, float(f['sensitivity'])))
+    assert float(f['sensitivity']) > 0.05, 'an uninformative fixture: a 1e-3-relative network error would pass the 1e-4 bound'
     assert err_state < 1e-4 and err < 1e-4
 
 
