@@ -53,9 +53,10 @@ def main(argv=None):
     ap.add_argument('--out', default=None, help='.npy file for the generated samples')
     ap.add_argument('--gen_data_path', default=None,
                     help='directory for <i>.png files (EvaluationManager image dump); images only')
-    ap.add_argument('--device_batch', type=int, default=None,
-                    help='with --gen_data_path and --rng philox: sample in chunks of at least this many images '
-                         '(pixels do not depend on the chunking)')
+    ap.add_argument('--device_batch', default='auto',
+                    help='with --gen_data_path and --rng philox: sample in chunks of at least this many images (pixels do not '
+                         'depend on the chunking).  auto (default) = up to 1024, as many as free HBM holds; 0 = eval.batch_size '
+                         'chunks exactly as the reference')
     a = ap.parse_args(argv)
 
     p = dlpm_amd.load_config(a.config)
@@ -111,7 +112,7 @@ def main(argv=None):
     if a.gen_data_path:
         assert is_image, '--gen_data_path dumps images; 2-D data has no image form'
         ev = dlpm_amd.EvaluationManager(method, gm, None, is_image=True, gen_data_path=a.gen_data_path,
-                                        device_batch=a.device_batch)
+                                        device_batch=a.device_batch if a.device_batch == 'auto' else int(a.device_batch))
         r = ev.evaluate_model({'default': model}, data_to_generate=p['eval']['data_to_generate'],
                               batch_size=p['eval']['batch_size'])
         print('wrote %d png files to %s' % (r['generated'], r['gen_data_path']))

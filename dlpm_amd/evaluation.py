@@ -100,12 +100,34 @@ class ImageDump:
             raise self.error
 
 
+DEVICE_BATCH = 1024   # images per chunk under device_batch='auto' (the per-sample rate of the image nets is flat beyond it)
+
+
+def auto_device_batch(models, chw, data_to_generate, reserve=0.5):
+    """Largest power of two <= DEVICE_BATCH (and not beyond the dump) whose network workspaces + state fit in `reserve` of the
+    free HBM.  Nets that cannot tell their workspace (`workspace_bytes(B, image_size)`) count as 64 x the state."""
+    free, _ = torch.cuda.mem_get_info()
+    b = 1
+    while b * 2 <= min(DEVICE_BATCH, max(1, int(data_to_generate))):
+        b *= 2
+    state = 4 * chw[0] * chw[1] * chw[2]
+    while b > 1:
+        need = 4 * b * state
+        for m in (models or {}).values():
+            wb = getattr(m, 'workspace_bytes', None)
+            need += wb(b, chw[1]) if wb is not None else 64 * b * state
+        if need <= reserve * free:
+            break
+        b //= 2
+    return b
+
+
 class EvaluationManager:
     """Constructor and entry points of bem/evaluate/EvaluationManager.py:33-118; `_evaluate_model` covers the
     generation + image-dump part (:174-196) and the 2-D generation call (:135)."""
 
     def __init__(self, method, gen_manager, dataloader, verbose=True, logger=None, is_image=False, gen_data_path=None,
-                 real_data_path=None, overlap=True, png_level=6, png_threads=4, device_batch=None, **kwargs):
+                 real_data_path=None, overlap=True, png_level=6, png_threads=4, device_batch='auto', **kwargs):
         self.method, self.gen_manager, self.dataloader = method, gen_manager, dataloader
         self.verbose, self.logger, self.is_image = verbose, logger, is_image
         self.gen_data_path, self.real_data_path = gen_data_path, real_data_path
@@ -146,8 +168,14 @@ class EvaluationManager:
             stream = getattr(self.method, 'dataset_stream', None)
             if self.device_batch and stream is not None and getattr(self.method, 'rng', None) == 'philox':
                 # inside dataset_stream() the i-th sample does not depend on the chunking, so the chunk can be
-                # sized for the GPU (eval.batch_size = 64 leaves an MI355X half idle) without changing any pixel
-                batch_size = max(batch_size, self.device_batch)
+                # sized for the GPU (eval.batch_size = 64 leaves an MI355X half idle: the CIFAR net runs at 46 % of its
+                # B = 1024 per-sample rate there) without changing any pixel.  'auto' (the default since round 5: a caller
+                # that drops the classes in unchanged gets the fast shape) = up to DEVICE_BATCH images, as many as the nets'
+                # workspaces leave room for in free HBM; device_batch=0 / None keeps the reference's chunking.
+                dev_b = self.device_batch
+                if dev_b == 'auto':
+                    dev_b = auto_device_batch(models, [Cc, H, W], data_to_generate)
+                batch_size = max(batch_size, int(dev_b))
             dump = ImageDump(self.gen_data_path, Cc, H, W, min(batch_size, data_to_generate), level=self.png_level,
                              threads=self.png_threads, overlap=self.overlap)
             remaining = data_to_generate

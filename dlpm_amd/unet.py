@@ -194,6 +194,13 @@ class UNetModel(nn.Module):
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
         return self._ws
 
+    def workspace_bytes(self, B, image_size):
+        """Peak activation workspace of a forward at batch B (dlpm_unet_workspace_bytes: a dry run of the plan's arena)."""
+        need = _lib.lib().dlpm_unet_workspace_bytes(self.native_handle(image_size), B)
+        if need < 0:
+            raise _lib.DlpmError(_lib.lib().dlpm_last_error().decode())
+        return int(need)
+
     def flops_per_sample(self, image_size):
         return _lib.lib().dlpm_unet_flops_per_sample(self.native_handle(image_size))
 

@@ -812,6 +812,11 @@ SPLIT_CASES = [
     ('ragged_qkv_4x4_b3', 3, 256, 0, 4, 768, True, False, False),       # M = 48: one partial tile, 3 samples of 8 in its table
     ('ragged_proj_res_8x8_b3', 3, 256, 0, 8, 256, False, False, True),  # M = 192: a full and a half tile
     ('xcd_mapped_qkv_8x8_b16', 16, 256, 0, 8, 384, True, False, False),  # 8 pixel tiles x 3 channel tiles
+    # round 5, k_conv_split_pipe's loop tails: a 32-channel pair = 2 k-steps, the loop is unrolled by 4 with a guarded tail
+    ('pipe_one_pair_k32', 2, 32, 0, 8, 128, True, True, False),          # 2 k-steps: prologue + tail only (clamped prologue loads)
+    ('pipe_three_pairs_concat_64_32', 2, 64, 32, 16, 128, True, False, True),   # 6 k-steps: the tail trip is half a trip
+    ('pipe_five_pairs_k160', 1, 160, 0, 8, 256, False, False, False),    # 10 k-steps: one steady trip + a whole + half tail
+    ('pipe_seven_pairs_k224_ragged', 3, 128, 96, 4, 128, True, False, True),    # 14 k-steps, M = 48
 ]
 
 

@@ -176,3 +176,23 @@ def test_evaluation_manager_one_channel_and_2d(tmp_path):
     got = _read_dir(tmp_path, 3)
     assert got.shape == (3, 32, 32, 3) and np.array_equal(got[..., 0], got[..., 1]) and np.array_equal(got[..., 0], got[..., 2])
     assert set(ev.evals) >= {'fid', 'precision', 'recall', 'density', 'coverage', 'wass', 'mmd', 'losses'}
+
+
+def test_auto_device_batch_sizes_the_chunk_from_free_hbm(monkeypatch):
+    """EvaluationManager(device_batch='auto') (the default): the largest power of two <= 1024 -- and not beyond the dump --
+    whose workspaces fit in half of the free HBM.  No GPU needed: mem_get_info and the net's workspace are stubbed."""
+    from dlpm_amd import evaluation as E
+
+    class Net:
+        def workspace_bytes(self, B, image_size):
+            return B * 5 * 2 ** 20                      # 5 MiB per image (the CIFAR net's is 4.8)
+
+    monkeypatch.setattr(torch.cuda, 'mem_get_info', lambda *a: (280 * 2 ** 30, 288 * 2 ** 30))
+    assert E.auto_device_batch({'default': Net()}, [3, 32, 32], 5000) == 1024          # a free MI355X
+    assert E.auto_device_batch({'default': Net()}, [3, 32, 32], 300) == 256            # never beyond the dump
+    assert E.auto_device_batch({'default': Net()}, [3, 32, 32], 1) == 1
+    monkeypatch.setattr(torch.cuda, 'mem_get_info', lambda *a: (3 * 2 ** 30, 288 * 2 ** 30))
+    assert E.auto_device_batch({'default': Net()}, [3, 32, 32], 5000) == 256           # 1.5 GiB to spend: 256 x 5 MiB fits
+    assert E.auto_device_batch({'default': object()}, [3, 32, 32], 5000) == 1024       # unknown nets: 64 x the state per image
+    ev = E.EvaluationManager(None, None, None, is_image=True)
+    assert ev.device_batch == 'auto'

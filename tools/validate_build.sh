@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/validate_build.sh <tag>: on the GPU box, from the repo root -- the full GPU suite (verbose), the driver's bench line, the MNIST workload,
 # rocprofv3 kernel stats + the PMC traffic record of THIS build (profiles/pmc_traffic.json), and the bench line again with `traffic` filled in.
-tag=${1:-r4m}
+tag=${1:-r5}
 mkdir -p gpurun_out/$tag
 python -m pytest tests -m gpu -q -s > gpurun_out/$tag/gpu_tests_verbose.log 2>&1
 tail -3 gpurun_out/$tag/gpu_tests_verbose.log
@@ -9,7 +9,7 @@ python bench.py > gpurun_out/$tag/bench_cifar.json 2> gpurun_out/$tag/bench_cifa
 python bench.py --workload mnist_unet_b256_T1000 --no-cpu-baseline > gpurun_out/$tag/bench_mnist.json 2>&1
 bash tools/profile_bench.sh gpurun_out/$tag/prof > gpurun_out/$tag/profile_bench.log 2>&1
 cp profiles/pmc_traffic.json gpurun_out/$tag/pmc_traffic.json
-cp profiles/r04/pmc_hbm_traffic.txt gpurun_out/$tag/pmc_hbm_traffic.txt 2>/dev/null
+cp profiles/r05/pmc_hbm_traffic.txt gpurun_out/$tag/pmc_hbm_traffic.txt 2>/dev/null
 python bench.py --no-cpu-baseline > gpurun_out/$tag/bench_cifar_with_traffic.json 2>&1
 python -c "
 import json
