@@ -3,6 +3,7 @@
 fp32 tolerances are written at each assert.  Marked gpu: runs on the MI355X box only."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -855,6 +856,41 @@ def test_conv1x1_bf16_split_gemm_is_fp32_grade(case):
     assert e16 <= 1.5 * e32 + 1.2e-7 * mag, name
     assert e16 < 3e-7 * math.sqrt(Cin) * mag, name
     assert not torch.equal(got16, got32) or e16 == 0.0   # the split kernel really ran (different rounding order)
+
+
+_PIPE_DIGEST_SCRIPT = r"""
+import hashlib, sys, torch
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, sys.argv[1] + '/tests')
+import test_gpu_kernels as T
+h = hashlib.sha256()
+for name, B, C0, C1, H, Cout, use_coef, silu, use_res in T.SPLIT_CASES:
+    g = torch.Generator().manual_seed(len(name))
+    x0 = torch.randn(B, C0, H, H, generator=g)
+    x1 = torch.randn(B, C1, H, H, generator=g) if C1 else None
+    w = torch.randn(Cout, C0 + C1, 1, 1, generator=g) / (C0 + C1) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    coef = (1 + 0.3 * torch.randn(B, C0 + C1, generator=g), 0.3 * torch.randn(B, C0 + C1, generator=g)) if use_coef else None
+    res = torch.randn(B, Cout, H, H, generator=g) if use_res else None
+    h.update(T.run_conv(x0, w, bias, x1, 1, 0, coef, silu, res, force_direct=16).numpy().tobytes())
+print(h.hexdigest())
+"""
+
+
+def test_pipelined_split_gemm_is_bit_identical_to_the_two_barrier_kernel():
+    """k_conv_split_pipe (round 5: one k-step per LDS stage, one barrier per k-step) accumulates every output in the order of
+    k_conv_split<8, 1, 1>: every SPLIT_CASES shape -- ragged tiles, every loop-tail length, concat, GroupNorm table, residual --
+    must come out bit for bit the same from both.  DLPM_SPLIT_PIPE is read once per process: two child processes, one digest each."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for pipe in ('1', '0'):
+        e = dict(os.environ, DLPM_SPLIT_PIPE=pipe)
+        r = subprocess.run([sys.executable, '-c', _PIPE_DIGEST_SCRIPT, root], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[pipe] = r.stdout.strip().splitlines()[-1]
+    assert len(out['1']) == 64 and out['1'] == out['0'], out
 
 
 SPLIT3_CASES = [
