@@ -42,7 +42,7 @@ SHAPES = [s for s in [
 ] if os.environ.get('PHASE_ONLY', '') in s[0]]
 
 
-def run(name, B, C0, C1, H, Cout, ks, coef, res, reps=5):
+def run(name, B, C0, C1, H, Cout, ks, coef, res, reps=int(os.environ.get('PHASE_REPS', '5'))):   # PHASE_REPS=4000: long enough for tools/power_probe.py
     B = int(os.environ.get('PHASE_B', B))    # e.g. 8: a launch of 32 workgroups, every one alone on its CU and (nearly) alone on the HBM
     Cin = C0 + C1
     x0 = torch.randn(B, H, H, C0, device=DEV)
