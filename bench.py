@@ -334,6 +334,82 @@ def spawn_ranks(n, argv, timeout_s=None):
     return rc
 
 
+class BoardSampler:
+    """Board power and shader clock while the timed steps and the whole trajectory run: a thread of THIS
+    process starts `rocm-smi --showpower --showclocks --json` as a fresh child about twice a second (a subprocess of a process
+    that holds the GPU is fine; nothing is ever exec'ed in place) and keeps (time, sclk MHz, package W).  `window(t0, t1)`
+    summarises the samples taken between two perf_counter readings.  A box without rocm-smi, or one whose output does not
+    parse, gives null fields -- never an error."""
+
+    CMD = ['rocm-smi', '--showpower', '--showclocks', '--json']
+
+    def __init__(self, period_s=0.5):
+        import threading
+        self.period, self.rows, self.limit, self.err = period_s, [], None, None
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._loop, daemon=True)
+
+    @staticmethod
+    def parse(txt):
+        """(sclk MHz, package W, package limit W) of the first card in rocm-smi's JSON; None where a field is absent."""
+        import re as _re
+        c = next(iter(json.loads(txt).values()))
+        sclk = _re.sub('[^0-9]', '', str(c.get('sclk clock speed:', '')))
+        pw = c.get('Current Socket Graphics Package Power (W)', c.get('Average Graphics Package Power (W)'))
+        lim = c.get('Max Graphics Package Power (W)')
+        return (int(sclk) if sclk else None, float(pw) if pw not in (None, 'N/A') else None,
+                float(lim) if lim not in (None, 'N/A') else None)
+
+    def _once(self):
+        r = subprocess.run(self.CMD, capture_output=True, text=True, timeout=10)
+        return self.parse(r.stdout[r.stdout.index('{'):])
+
+    def _loop(self):
+        while not self._stop.is_set():
+            t = time.perf_counter()
+            try:
+                sclk, pw, lim = self._once()
+                self.rows.append((0.5 * (t + time.perf_counter()), sclk, pw))
+                if lim is not None:
+                    self.limit = lim
+            except Exception as e:      # a sample that fails is a gap; a box without rocm-smi yields nulls
+                self.err = repr(e)[:120]
+                if isinstance(e, FileNotFoundError):
+                    return
+            self._stop.wait(self.period)
+
+    def start(self):
+        self._th.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        self._th.join(timeout=15)
+
+    def window(self, t0, t1):
+        rows = [r for r in self.rows if t0 <= r[0] <= t1]
+        pw = [r[2] for r in rows if r[2] is not None]
+        ck = [r[1] for r in rows if r[1] is not None]
+        return dict(samples=len(rows),
+                    board_power_w=dict(mean=round(sum(pw) / len(pw), 1), max=round(max(pw), 1)) if pw else None,
+                    sclk_mhz=dict(mean=round(sum(ck) / len(ck)), min=min(ck)) if ck else None)
+
+    def block(self, windows):
+        """The JSON block: one summary per named (t0, t1) window + the union of them as the top-level fields."""
+        out = {k: self.window(*w) for k, w in windows.items() if w is not None}
+        lo, hi = min(w[0] for w in windows.values() if w), max(w[1] for w in windows.values() if w)
+        allw = [r for k, w in windows.items() if w for r in self.rows if w[0] <= r[0] <= w[1]]
+        pw = [r[2] for r in allw if r[2] is not None]
+        ck = [r[1] for r in allw if r[1] is not None]
+        return dict(board_power_w=dict(mean=round(sum(pw) / len(pw), 1), max=round(max(pw), 1)) if pw else None,
+                    sclk_mhz=dict(mean=round(sum(ck) / len(ck)), min=min(ck)) if ck else None,
+                    package_limit_w=self.limit, samples=len(allw), period_s=self.period, windows=out,
+                    source='rocm-smi --showpower --showclocks --json, a fresh child about every %.1f s from a thread of rank 0 while the '
+                           'timed steps and the whole trajectory run (sclk = the PLL reading at the sample instant, power = socket '
+                           'package power)' % self.period,
+                    error=self.err if not allw else None)
+
+
 class NativeRunner:
     """The hot path through the C ABI: dlpm_sampler_begin / _steps / _copy_state on this rank's GPU."""
 
@@ -353,8 +429,9 @@ class NativeRunner:
         self.meth = dlpm_amd.GenerativeLevyProcess(alpha, str(dev), T, rescale_timesteps=True, seed=0, sample_offset=rank * B,
                                                    use_graph=not args.no_graph, isotropic=not args.non_iso, LIM=args.lim)
         self.st = _lib.stream_ptr()
-        self.h = self.meth._native_sampler(self.net, self.shape, _lib.SMP_LIM if args.lim else 0, 0.0, ev['clamp_a'],
-                                           ev['clamp_eps'], 0)
+        flags = (_lib.SMP_LIM if args.lim else 0) | (_lib.UPD_CLIP if args.clip else 0) | (_lib.UPD_DLIM if args.deterministic else 0)
+        self.h = self.meth._native_sampler(self.net, self.shape, flags, float(ev.get('dlim_eta', 0.0)) if args.deterministic else 0.0,
+                                           ev['clamp_a'], ev['clamp_eps'], 0)
         self.flops_per_sample = self.net.flops_per_sample(self.shape[2])
 
     def begin(self):
@@ -472,6 +549,12 @@ def main():
                     help='non-isotropic noise variant (--non_iso of the reference): [T,B,D] tables; not the headline config')
     ap.add_argument('--rank-timeout', type=float, default=7200.0,
                     help='N > 1 started plainly: seconds after which the parent ends its ranks (their own process group) and exits 124')
+    ap.add_argument('--clip', action='store_true',
+                    help='clip_denoised variant (--clip of the reference): x0 predicted, clamped, eps recomputed; the update runs in '
+                         'k_update_rows behind the head convolution instead of inside k_head_fused; not the headline config')
+    ap.add_argument('--deterministic', action='store_true',
+                    help='DLIM variant (--deterministic of the reference, the config\'s dlim_eta); update in k_update_rows; not the headline config')
+    ap.add_argument('--no-board-sampler', action='store_true', help='do not sample rocm-smi during the run (board = null)')
     ap.add_argument('--lim', action='store_true',
                     help='LIM sampler variant (--method lim of the reference, SDE updates): T network evaluations; '
                          'not the headline config')
@@ -540,6 +623,9 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t.tolist()
 
+    board = None
+    if rank == 0 and not args.no_board_sampler:
+        board = BoardSampler().start()
     # ---- init (A, tables, x_T)
     barrier()
     t0 = time.perf_counter()
@@ -554,6 +640,7 @@ def main():
     run.steps(K)
     barrier()
     dt = time.perf_counter() - t0
+    win_steps, win_traj = (t0, t0 + dt), None
     own_ms_per_step = dt / K * 1e3          # this rank's clock (the line's ms_per_step is the max over ranks)
     dt, init_s = max_over_ranks(dt, init_s)
     ms_per_step = dt / K * 1e3
@@ -590,8 +677,8 @@ def main():
         # both sides, and NaN != NaN -- such a pair counts as equal; only a finite mismatch is a broken gather
         same = [(a == b) or (math.isnan(a) and math.isnan(b)) for a, b in zip(mine, shard_sums)]
         dist_info['gather_verified'] = bool(all(same))
-        if all(math.isfinite(v) for v in mine + shard_sums):
-            assert dist_info['gather_verified'], 'the gathered batch does not hold the shards the ranks produced'
+        # per pair, unconditionally: one NaN shard must not switch the check off for a finite mismatch elsewhere
+        assert dist_info['gather_verified'], 'the gathered batch does not hold the shards the ranks produced: %s vs %s' % (mine, shard_sums)
         ids = [ri['device_uuid'] or ri['pci_bus_id'] for ri in ranks_info]
         dist_info['distinct_devices'] = len(set(ids)) if all(i is not None for i in ids) else None
         if backend == 'nccl' and os.environ.get('DLPM_BENCH_SINGLE_DEVICE') != '1' and dist_info['distinct_devices'] is not None:
@@ -612,6 +699,7 @@ def main():
         x = run.state()
         full = all_gather_samples(x, B * world) if world > 1 else x
         barrier()
+        win_traj = (t0, time.perf_counter())
         full_s = max_over_ranks(time.perf_counter() - t0)[0]
         finite = finite and bool(torch.isfinite(full).all().item())
     if full_s is not None:
@@ -622,7 +710,12 @@ def main():
         value, value_source = B * world / total_s, 'extrapolated: init + %d x ms_per_step (%d timed steps)%s' % (
             nsteps, K, ' + all-gather' if world > 1 else '')
 
+    board_block = None
+    if board is not None:
+        board.stop()
+        board_block = board.block(dict(timed_steps=win_steps, whole_trajectory=win_traj))
     roofline, upd, breakdown, att, split = None, None, None, None, None
+    upd_unfused = None
     if not args.no_prof and rank == 0 and not dry:
         # instrumented eager pass on the same stream: HIP events around every launch, by kernel class
         nprof = 3
@@ -701,6 +794,18 @@ def main():
                        note='algorithmic bytes = read x + read eps + write x (12 B/element, in-kernel Philox); in-loop launch '
                             'time from HIP events (the state was last touched a whole UNet forward earlier: HBM, not cache)')
 
+        # the standalone update launch (k_update_rows): every variant that cannot take the fused head -- --clip, --deterministic, LIM,
+        # START_X / Z / PREVIOUS_X -- and the path all bounded parity fixtures run
+        uu = prof.get('update') or prof.get('lim_update')
+        if uu and ((hf or hu) is None or args.clip or args.deterministic or args.lim):
+            gbs = uu['bytes'] / (uu['ms'] * 1e-3) / 1e9
+            upd_unfused = dict(kernel='k_update_lim' if args.lim else ('k_update_rows (x_{t-1} update as its own launch behind the head convolution, Philox noise%s)'
+                                      % (', clip_denoised: x0 predicted, clamped, eps recomputed' if args.clip else ', DLIM' if args.deterministic else '')),
+                               bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(gbs / PEAK_HBM_GBS, 4),
+                               traffic=None, bytes_per_launch=uu['bytes'] / uu['launches'], avg_launch_ms=round(uu['ms'] / uu['launches'], 5),
+                               note='algorithmic bytes = read x + read eps + write x (12 B/element, in-kernel Philox); in-loop launch time from '
+                                    'HIP events of the instrumented eager pass (eps was written by the head convolution just before: partly L2 / MALL)')
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
         cpu = cpu_baseline(cfg_name, T, alpha, threads=args.cpu_threads or None)
@@ -713,7 +818,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if args.gemm == 'f32' or cfg_name == 'mnist' else 'f32 (1x1 / stride-2 convolutions: fp32 operands split exactly into 3 bf16 planes, bf16 MFMA products, fp32 accumulate)',
             'data': 'synthetic',
-            'config': {'workload': args.workload + ('+non_iso' if args.non_iso else '') + ('+lim_sde' if args.lim else ''), 'state_shape_per_gpu': shape, 'global_batch': B * world,
+            'config': {'workload': args.workload + ('+non_iso' if args.non_iso else '') + ('+lim_sde' if args.lim else '') + ('+clip' if args.clip else '') + ('+dlim' if args.deterministic else ''), 'state_shape_per_gpu': shape, 'global_batch': B * world,
                        'reverse_steps': T, 'alpha': alpha, 'timed_steps': K, 'trajectory_steps': nsteps,
                        'init_ms': round(init_s * 1e3, 3), 'allgather_ms': None if gather_s is None else round(gather_s * 1e3, 3),
                        'net': 'reference cifar10.yml UNet (mc=128, 39.6M params), random init + re-drawn zero tensors'
@@ -726,11 +831,16 @@ def main():
             'extrapolated_value': round(B * world / (init_s + nsteps * ms_per_step / 1e3 + (gather_s or 0.0)), 4),
             'gflop_per_sample_step': round(run.flops_per_sample / 1e9, 4),
             'whole_step_tflops': round(step_tflops, 3),
-            'whole_step_frac_of_fp32_peak': round(step_tflops / (PEAK_FP32_MFMA_TFLOPS * world), 4),
+            'algorithmic_tflops_over_fp32_peak': round(step_tflops / (PEAK_FP32_MFMA_TFLOPS * world), 4),
+            'algorithmic_tflops_note': 'whole_step_tflops counts the DIRECT-convolution FLOPs of the step (SURVEY 8d); the Winograd kernels execute 36/144 '
+                                       '(F(4x4)) or 16/36 (F(2x2)) of those multiplies, so this ratio may exceed 1 -- the fraction of a hardware '
+                                       'peak is roofline.frac',
             'samples_finite': finite,
             'ranks': ranks_info, 'backend': dist_info['backend'], 'rccl_world_size': dist_info['world_size'],
             'allgather_bytes': dist_info['allgather_bytes'], 'distributed': dist_info,
-            'roofline': roofline, 'split_gemm_kernel': split, 'update_kernel': upd, 'attention_kernel': att, 'ms_per_step_by_kernel_class': breakdown, 'cpu_baseline': cpu,
+            'board_power_w': None if not board_block else board_block['board_power_w'], 'sclk_mhz': None if not board_block else board_block['sclk_mhz'],
+            'package_limit_w': None if not board_block else board_block['package_limit_w'], 'board': board_block,
+            'roofline': roofline, 'split_gemm_kernel': split, 'update_kernel': upd, 'update_kernel_unfused': upd_unfused, 'attention_kernel': att, 'ms_per_step_by_kernel_class': breakdown, 'cpu_baseline': cpu,
         }
         if dry:
             out['dry_run'] = 'control-flow test only (DLPM_BENCH_DRY_RUN=1): stub sampler on CPU, NOT a measurement'

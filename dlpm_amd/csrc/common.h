@@ -60,6 +60,31 @@ struct ProfScope {
 // ConvLaunch add clock64() deltas of their phases (thread 0 of every workgroup) into this device buffer.
 #ifdef DLPM_PHASE_TIMING
 unsigned long long *phase_buffer();   // 32 counters, zero-initialised device memory (allocated on first use)
+#ifdef DLPM_PHASE_DEFER
+// Round 6: the SAME counters, but nothing touches memory until the kernel's last instruction.  The in-place form below issues one
+// 64-bit atomicAdd per marker from thread 0 of EVERY workgroup onto the same two cache lines; on gfx9 an atomic without return counts
+// on vmcnt like a store, so the next s_waitcnt vmcnt(0) of that wave (the epilogue's bias / residual loads, the loop's first operand
+// wait) waits for the atomic's round trip -- and with all 256 CUs in lockstep those atomics queue up behind each other at the one
+// address.  That queue, not the arithmetic, was the "epilogue that costs 4x more on 256 workgroups than on 16"
+// (profiles/r06/epilogue_lockstep/).  Here the deltas stay in scalar registers (s_memtime is a scalar instruction, the arithmetic
+// is wave-uniform) and DLPM_PHASE_FLUSH adds them at the very end.  Markers i, i+1, i+2 of a kernel map to slots (i & 3).
+#define DLPM_PHASE_DECL long long _pt = clock64(); unsigned long long _pd0 = 0, _pd1 = 0, _pd2 = 0
+#define DLPM_PHASE(p, i)                                                                              \
+    do {                                                                                              \
+        const long long _n = clock64();                                                               \
+        const unsigned long long _d = (unsigned long long)(_n - _pt);                                 \
+        if (((i) & 3) == 0) _pd0 += _d; else if (((i) & 3) == 1) _pd1 += _d; else _pd2 += _d;          \
+        _pt = _n;                                                                                     \
+    } while (0)
+#define DLPM_PHASE_FLUSH(p, base)                                                                     \
+    do {                                                                                              \
+        if ((p).phase && threadIdx.x == 0) {                                                          \
+            atomicAdd((p).phase + (base), _pd0);                                                      \
+            atomicAdd((p).phase + (base) + 1, _pd1);                                                  \
+            atomicAdd((p).phase + (base) + 2, _pd2);                                                  \
+        }                                                                                             \
+    } while (0)
+#else
 #define DLPM_PHASE_DECL long long _pt = clock64()
 #define DLPM_PHASE(p, i)                                                                              \
     do {                                                                                              \
@@ -69,9 +94,12 @@ unsigned long long *phase_buffer();   // 32 counters, zero-initialised device me
             _pt = _n;                                                                                 \
         }                                                                                             \
     } while (0)
+#define DLPM_PHASE_FLUSH(p, base)
+#endif
 #else
 #define DLPM_PHASE_DECL
 #define DLPM_PHASE(p, i)
+#define DLPM_PHASE_FLUSH(p, base)
 #endif
 
 }  // namespace dlpm

@@ -762,8 +762,10 @@ int launch_conv_split(const ConvLaunch &c, hipStream_t st) {
     // fused statistics.  All shapes accumulate every output in the same order: which one runs does not change a bit of the result.
     static int pipe = -1;
     if (pipe < 0) { const char *e = getenv("DLPM_SPLIT_PIPE"); pipe = e ? atoi(e) : 1; }
-    if (pipe && c.ks == 1 && !row_stats && !wide) {
-        const int lds_p = 48 * 1024 + (c.coefA ? nsamp * (c.C0 + c.C1) * 8 : 0);
+    // (the pipelined kernel's LDS limit is 80 KB = 48 KB of stages + the fused GroupNorm coefficients, nsamp x Cin x 8 bytes; launches
+    //  beyond it -- Cin > 4096 with coefficients -- stay on k_conv_split<8, 1, 1>, whose 104-KB limit takes Cin up to 7168: ADVICE r05)
+    const int lds_p = 48 * 1024 + (c.coefA ? nsamp * (c.C0 + c.C1) * 8 : 0);
+    if (pipe && c.ks == 1 && !row_stats && !wide && lds_p <= 80 * 1024) {
         const int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_conv_split_pipe), 80 * 1024);
         if (r != DLPM_OK) return r;
         k_conv_split_pipe<<<grid, 512, lds_p, st>>>(c, nsamp, xcd_map);

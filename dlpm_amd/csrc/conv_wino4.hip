@@ -487,7 +487,7 @@ __global__ void __launch_bounds__((NW + (NW == 8 ? 0 : NW == 4 ? 3 : 2)) * 64, N
     if (F4_PRIO) __builtin_amdgcn_s_setprio(0);
     DLPM_PHASE(p, 9);
     if (HELP && !mfma_wave) return;   // (no barrier behind the loop: the epilogue runs out of the MFMA waves' registers)
-#ifdef DLPM_PHASE_TIMING
+#if defined(DLPM_PHASE_TIMING) && !defined(DLPM_PHASE_DEFER)
     if (p.phase && lane == 0) atomicAdd(p.phase + 16 + wave, (unsigned long long)_wait);
 #endif
 
@@ -650,7 +650,7 @@ __global__ void __launch_bounds__((NW + (NW == 8 ? 0 : NW == 4 ? 3 : 2)) * 64, N
         const bool img_stats = p.stats_out != nullptr && nimg == 4 && bh * bw == 4;
         const bool do_stats = ((p.stats_out != nullptr && nimg == 1) || img_stats) && !(HELP && (F4N_ABL & 4));
         float K = 0.f, s1 = 0.f, s2 = 0.f;
-        float rs_all[HELP ? 4 : 1][16];
+        float rs_all[HELP ? 4 : 1][16] = {};   // (read unconditionally below, used only under has_res)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int tile = 4 * lk + r;
@@ -749,6 +749,10 @@ __global__ void __launch_bounds__((NW + (NW == 8 ? 0 : NW == 4 ? 3 : 2)) * 64, N
         }
     }
     DLPM_PHASE(p, 10);
+    DLPM_PHASE_FLUSH(p, 8);
+#ifdef DLPM_PHASE_DEFER
+    if (p.phase && lane == 0) atomicAdd(p.phase + 16 + wave, (unsigned long long)_wait);
+#endif
 #ifdef DLPM_PHASE_TIMING
     if (p.phase && tid == 0) {
         atomicAdd(p.phase + 11, 1ull);

@@ -1130,7 +1130,15 @@ extern "C" int dlpm_conv2d_f32(const dlpm_conv_args *a, float *scratch_dev, dlpm
             float *w4 = scratch_dev + used;
             TRY(relayout_weight_wino4(a->weight, w4, a->Cout, a->C0 + a->C1, st));
             L.w_wino4 = w4;
-            L.w_wino = nullptr;   // no F(2x2) alternative: every qualifying geometry takes the F(4x4) kernel
+            // bit 8 ASKS for the F(4x4) kernel: a geometry it rejects (e.g. 16 one-tile 4x4 images on a 64- / 32-channel n-tile: 576 halo
+            // pixels > F4_RAWPIX_N) is an error, not a silent drop to the implicit GEMM -- tests that compare "the F(4x4) kernel" with the
+            // default path must not pass for the wrong reason
+            int bh_, bw_, ni_;
+            if (!wino4_geometry(L, &bh_, &bw_, &ni_)) {
+                set_error("dlpm_conv2d_f32: force_direct bit 8 asks for the F(4x4,3x3) kernel, which does not take this geometry");
+                return DLPM_ERR_UNSUPPORTED;
+            }
+            L.w_wino = nullptr;   // no F(2x2) alternative: the launch takes the F(4x4) kernel
         }
     }
     if ((a->force_direct & 64) && a->ksize == 3 && a->Cout <= 3 && a->C0 % 32 == 0 && a->C1 == 0) {

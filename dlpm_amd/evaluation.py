@@ -103,10 +103,13 @@ class ImageDump:
 DEVICE_BATCH = 1024   # images per chunk under device_batch='auto' (the per-sample rate of the image nets is flat beyond it)
 
 
-def auto_device_batch(models, chw, data_to_generate, reserve=0.5):
+def auto_device_batch(models, chw, data_to_generate, reserve=0.5, device=None):
     """Largest power of two <= DEVICE_BATCH (and not beyond the dump) whose network workspaces + state fit in `reserve` of the
-    free HBM.  Nets that cannot tell their workspace (`workspace_bytes(B, image_size)`) count as 64 x the state."""
-    free, _ = torch.cuda.mem_get_info()
+    free HBM OF `device` (the GPU the method and its nets live on -- not the process's current device: a sharded evaluation
+    runs the method on cuda:k with current device 0).  Nets that cannot tell their workspace (`workspace_bytes(B, image_size)`)
+    count as 64 x the state.  The sampler's [T,B] tables, graph pools and the dump's pinned buffers live in the reserve; the
+    caller halves the chunk if the first one still runs out of memory (`_evaluate_model`)."""
+    free, _ = torch.cuda.mem_get_info(device)
     b = 1
     while b * 2 <= min(DEVICE_BATCH, max(1, int(data_to_generate))):
         b *= 2
@@ -166,6 +169,7 @@ class EvaluationManager:
             _, (data, _) = next(enumerate(self.gen_manager.original_data))
             Cc, H, W = data.shape[1:]
             stream = getattr(self.method, 'dataset_stream', None)
+            min_batch = None
             if self.device_batch and stream is not None and getattr(self.method, 'rng', None) == 'philox':
                 # inside dataset_stream() the i-th sample does not depend on the chunking, so the chunk can be
                 # sized for the GPU (eval.batch_size = 64 leaves an MI355X half idle: the CIFAR net runs at 46 % of its
@@ -174,7 +178,9 @@ class EvaluationManager:
                 # workspaces leave room for in free HBM; device_batch=0 / None keeps the reference's chunking.
                 dev_b = self.device_batch
                 if dev_b == 'auto':
-                    dev_b = auto_device_batch(models, [Cc, H, W], data_to_generate)
+                    mdev = torch.device(getattr(self.method, 'device', 'cuda'))
+                    dev_b = auto_device_batch(models, [Cc, H, W], data_to_generate, device=mdev if mdev.type == 'cuda' else None)
+                    min_batch = batch_size                                          # an OOM on the first chunk halves down to the config's own
                 batch_size = max(batch_size, int(dev_b))
             dump = ImageDump(self.gen_data_path, Cc, H, W, min(batch_size, data_to_generate), level=self.png_level,
                              threads=self.png_threads, overlap=self.overlap)
@@ -186,7 +192,19 @@ class EvaluationManager:
                 with ctx:
                     while remaining > 0:                                           # EvaluationManager.py:181-193
                         n = min(batch_size, remaining)
-                        self.gen_manager.generate(models, n, to_host=False, **kwargs)
+                        try:
+                            self.gen_manager.generate(models, n, to_host=False, **kwargs)
+                        except (torch.cuda.OutOfMemoryError, RuntimeError) as e:
+                            # 'auto' sized the chunk from free HBM with a reserve; should the FIRST chunk not fit after all, halve it
+                            # (the pixels do not depend on the chunking inside dataset_stream()) instead of failing the dump
+                            oom = isinstance(e, torch.cuda.OutOfMemoryError) or 'out of memory' in str(e).lower()
+                            if not (oom and total == 0 and min_batch is not None and batch_size // 2 >= max(1, min_batch)):
+                                raise
+                            batch_size //= 2
+                            torch.cuda.empty_cache()
+                            if self.verbose:
+                                print('device_batch=auto: out of memory, chunk halved to {}'.format(batch_size))
+                            continue
                         dump.submit(self.gen_manager.samples, total)
                         total += n
                         remaining -= n

@@ -57,3 +57,39 @@ def test_bench_prints_one_line_with_the_contracts_keys():
     assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3 and 0 < roof['frac'] < 1
     assert roof['traffic'] is None or roof['traffic'] > 0            # PMC record exists for the default workload only
     assert j.get('cpu_baseline') is None                             # switched off for this run
+    # round 6: board power / shader clock sampled by rocm-smi while the timed steps (and the trajectory) run -- the keys are always
+    # there; the values are null only on a box without rocm-smi (then `board.error` says why)
+    for k in ('board_power_w', 'sclk_mhz', 'package_limit_w', 'board'):
+        assert k in j, k
+    assert isinstance(j['board'], dict) and 'windows' in j['board'] and 'timed_steps' in j['board']['windows']
+    if j['board_power_w'] is not None:
+        assert 0 < j['board_power_w']['mean'] <= j['board_power_w']['max'] < 3000
+        assert 0 < j['sclk_mhz']['min'] <= j['sclk_mhz']['mean'] < 4000
+    assert 'algorithmic_tflops_over_fp32_peak' in j and 'whole_step_frac_of_fp32_peak' not in j
+    assert 'update_kernel_unfused' in j
+
+
+def test_board_sampler_parses_rocm_smi_and_tolerates_its_absence():
+    """BoardSampler (bench.py): the JSON of `rocm-smi --showpower --showclocks --json` as the MI355X boxes print it (profiles/r05/
+    power_probe/idle.json) -> (sclk MHz, package W, limit W); a box without rocm-smi gives a block of nulls, never an exception."""
+    sys.path.insert(0, ROOT)
+    import time
+    import bench
+    txt = ('{"card0": {"fclk clock speed:": "(1250Mhz)", "mclk clock speed:": "(2000Mhz)", "sclk clock speed:": "(1624Mhz)", "sclk clock level:": "S", '
+           '"Max Graphics Package Power (W)": "1400.0", "Current Socket Graphics Package Power (W)": "1398.0"}}')
+    assert bench.BoardSampler.parse(txt) == (1624, 1398.0, 1400.0)
+    assert bench.BoardSampler.parse('{"card0": {}}') == (None, None, None)
+    s = bench.BoardSampler(period_s=0.05)
+    s.CMD = ['/nonexistent/rocm-smi-for-the-test']
+    s.start()
+    t0 = time.perf_counter()
+    time.sleep(0.2)
+    s.stop()
+    blk = s.block(dict(timed_steps=(t0, time.perf_counter()), whole_trajectory=None))
+    assert blk['board_power_w'] is None and blk['sclk_mhz'] is None and blk['samples'] == 0 and 'FileNotFoundError' in blk['error']
+    # and with samples in hand: mean / max / min over the window, per window and over their union
+    s.rows = [(1.0, 2400, 1000.0), (2.0, 1600, 1400.0), (9.0, 100, 200.0)]
+    s.limit = 1400.0
+    blk = s.block(dict(timed_steps=(0.5, 2.5), whole_trajectory=None))
+    assert blk['board_power_w'] == dict(mean=1200.0, max=1400.0) and blk['sclk_mhz'] == dict(mean=2000, min=1600)
+    assert blk['package_limit_w'] == 1400.0 and blk['windows']['timed_steps']['samples'] == 2

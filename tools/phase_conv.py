@@ -18,10 +18,10 @@ import torch
 from dlpm_amd import _lib
 
 L = _lib.lib()
-if not hasattr(L, 'dlpm_debug_phases'):
-    sys.exit('library was built without -DDLPM_PHASE_TIMING')
-L.dlpm_debug_phases.restype = C.c_int
-L.dlpm_debug_phases.argtypes = [C.POINTER(C.c_ulonglong * 32)]
+HAVE_PHASES = hasattr(L, 'dlpm_debug_phases')     # the product build has none: launch times only (PHASE_B sweeps of the product kernel)
+if HAVE_PHASES:
+    L.dlpm_debug_phases.restype = C.c_int
+    L.dlpm_debug_phases.argtypes = [C.POINTER(C.c_ulonglong * 32)]
 DEV = 'cuda'
 
 # name, B, C0, C1, H, Cout, ks, coef+silu, res
@@ -39,6 +39,7 @@ SHAPES = [s for s in [
     ('3x3 mnist H8 64->64', 256, 64, 0, 8, 64, 3, True, True),
     ('3x3 mnist H4 64->64', 256, 64, 0, 4, 64, 3, True, True),
     ('3x3 mnist H32 32->32', 256, 32, 0, 32, 32, 3, True, True),
+    ('3x3 cifar8w H32 128->128', 1024, 128, 0, 32, 128, 3, True, True),     # the 8-wave kernel's worst layer: PHASE_ONLY=cifar8w PHASE_B=64 (256 workgroups)
 ] if os.environ.get('PHASE_ONLY', '') in s[0]]
 
 
@@ -48,6 +49,11 @@ def run(name, B, C0, C1, H, Cout, ks, coef, res, reps=int(os.environ.get('PHASE_
     x0 = torch.randn(B, H, H, C0, device=DEV)
     x1 = torch.randn(B, H, H, C1, device=DEV) if C1 else None
     w = torch.randn(Cout, Cin, ks, ks, device=DEV) * 0.05
+    if os.environ.get('PHASE_ZEROS') == '1':     # all-zero operands: the same instruction stream without data toggling (power vs structure)
+        x0.zero_()
+        w.zero_()
+        if x1 is not None:
+            x1.zero_()
     bias = torch.randn(Cout, device=DEV)
     out = torch.empty(B, H, H, Cout, device=DEV)
     a = _lib.ConvArgs()
@@ -73,13 +79,33 @@ def run(name, B, C0, C1, H, Cout, ks, coef, res, reps=int(os.environ.get('PHASE_
     st = _lib.stream_ptr()
     ph = (C.c_ulonglong * 32)()
     _lib.check(L.dlpm_conv2d_f32(C.byref(a), scratch.data_ptr(), st))
-    _lib.check(L.dlpm_debug_phases(C.byref(ph)))
+    torch.cuda.synchronize()
+    # the convolution kernel's own launch time (HIP events around it on the launch stream: the weight relayout launches of
+    # dlpm_conv2d_f32 fall into classes of their own), min-free mean over `preps` launches
+    preps = int(os.environ.get('PHASE_PROF_REPS', '200'))
+    _lib.check(L.dlpm_prof_enable(1))
+    for _ in range(preps):
+        _lib.check(L.dlpm_conv2d_f32(C.byref(a), scratch.data_ptr(), st))
+    pbuf = C.create_string_buffer(1 << 16)
+    _lib.check(L.dlpm_prof_report(pbuf, len(pbuf)))
+    _lib.check(L.dlpm_prof_enable(0))
+    kern_us = None
+    for line in pbuf.value.decode().strip().splitlines():
+        nm, n_, t_, f_, by_ = line.split()
+        if nm.startswith('conv'):
+            kern_us = 1e3 * float(t_) / int(n_)
+    if HAVE_PHASES:
+        _lib.check(L.dlpm_debug_phases(C.byref(ph)))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
         _lib.check(L.dlpm_conv2d_f32(C.byref(a), scratch.data_ptr(), st))
     e1.record()
     torch.cuda.synchronize()
+    if not HAVE_PHASES:
+        print('%-30s B %5d  kernel %8.2f us/launch (events around the launch, %d launches)  %8.3f ms/call(+relayout)   [product build: no phase counters]'
+              % (name, B, kern_us or -1, preps, e0.elapsed_time(e1) / reps))
+        return
     _lib.check(L.dlpm_debug_phases(C.byref(ph)))
     base = 8 if ph[11] else 0
     n = ph[base + 3]
@@ -88,8 +114,8 @@ def run(name, B, C0, C1, H, Cout, ks, coef, res, reps=int(os.environ.get('PHASE_
     if tot == 0:
         print('%-30s %8.3f ms/call(+relayout)  (this shape\'s kernel carries no phase counters)' % (name, e0.elapsed_time(e1) / reps))
         return
-    print('%-30s %8.3f ms/call(+relayout)  wgs/launch %6d  cycles/wg: prologue %7.0f (%4.1f%%)  loop %7.0f (%4.1f%%)  epilogue %7.0f (%4.1f%%)'
-          % (name, e0.elapsed_time(e1) / reps, n // reps, pro, 100 * pro / tot, main, 100 * main / tot, epi, 100 * epi / tot))
+    print('%-30s %8.3f ms/call(+relayout)  kernel %7.2f us  wgs/launch %6d  cycles/wg: prologue %7.0f (%4.1f%%)  loop %7.0f (%4.1f%%)  epilogue %7.0f (%4.1f%%)'
+          % (name, e0.elapsed_time(e1) / reps, kern_us or -1, n // reps, pro, 100 * pro / tot, main, 100 * main / tot, epi, 100 * epi / tot))
     if any(ph[4 + i] for i in range(4)):
         print('    loop, per workgroup: stage+wait %7.0f  barrier %7.0f  MFMAs %7.0f  barrier %7.0f' % tuple(ph[4 + i] / max(n, 1) for i in range(4)))
     if ph[13]:
