@@ -336,12 +336,12 @@ def spawn_ranks(n, argv, timeout_s=None):
 
 class BoardSampler:
     """Board power and shader clock while the timed steps and the whole trajectory run: a thread of THIS
-    process starts `rocm-smi --showpower --showclocks --json` as a fresh child about twice a second (a subprocess of a process
+    process starts `rocm-smi --showpower --showmaxpower --showclocks --json` as a fresh child about twice a second (a subprocess of a process
     that holds the GPU is fine; nothing is ever exec'ed in place) and keeps (time, sclk MHz, package W).  `window(t0, t1)`
     summarises the samples taken between two perf_counter readings.  A box without rocm-smi, or one whose output does not
     parse, gives null fields -- never an error."""
 
-    CMD = ['rocm-smi', '--showpower', '--showclocks', '--json']
+    CMD = ['rocm-smi', '--showpower', '--showmaxpower', '--showclocks', '--json']
 
     def __init__(self, period_s=0.5):
         import threading
@@ -404,7 +404,7 @@ class BoardSampler:
         return dict(board_power_w=dict(mean=round(sum(pw) / len(pw), 1), max=round(max(pw), 1)) if pw else None,
                     sclk_mhz=dict(mean=round(sum(ck) / len(ck)), min=min(ck)) if ck else None,
                     package_limit_w=self.limit, samples=len(allw), period_s=self.period, windows=out,
-                    source='rocm-smi --showpower --showclocks --json, a fresh child about every %.1f s from a thread of rank 0 while the '
+                    source='rocm-smi --showpower --showmaxpower --showclocks --json, a fresh child about every %.1f s from a thread of rank 0 while the '
                            'timed steps and the whole trajectory run (sclk = the PLL reading at the sample instant, power = socket '
                            'package power)' % self.period,
                     error=self.err if not allw else None)
