@@ -90,6 +90,10 @@ constexpr int F4_PAD = 8;         // float4 fragments of zero padding behind the
 #ifndef F4N_ABL
 #define F4N_ABL 0   // developer builds (DLPM_BUILD_DEFS), narrow shapes' epilogue, timing only (results are wrong): 1 no stores, 2 no residual loads, 4 no statistics
 #endif
+#ifndef F4_RES_AHEAD
+#define F4_RES_AHEAD 0   // 1: the 8-wave shape, too, requests all four tiles' residual values before the first output transform (the narrow
+                         // shapes always do): 64 more live registers in the epilogue, where the weight ring / A fragments / staging items are dead
+#endif
 #ifndef F4_SKIP_TAIL
 #define F4_SKIP_TAIL 0   // 1: skip the look-ahead staging / transform of the last phases (they feed chunks that do not exist): 2 of 16 phases'
                          // side work on the K = 128 layers -- measured 1.3-2.5 % SLOWER (the two uniform branches cost the phase its schedule:
@@ -650,7 +654,8 @@ __global__ void __launch_bounds__((NW + (NW == 8 ? 0 : NW == 4 ? 3 : 2)) * 64, N
         const bool img_stats = p.stats_out != nullptr && nimg == 4 && bh * bw == 4;
         const bool do_stats = ((p.stats_out != nullptr && nimg == 1) || img_stats) && !(HELP && (F4N_ABL & 4));
         float K = 0.f, s1 = 0.f, s2 = 0.f;
-        float rs_all[HELP ? 4 : 1][16] = {};   // (read unconditionally below, used only under has_res)
+        constexpr bool RES_AHEAD = HELP || F4_RES_AHEAD != 0;
+        float rs_all[RES_AHEAD ? 4 : 1][16] = {};   // (read unconditionally below, used only under has_res)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int tile = 4 * lk + r;
@@ -660,10 +665,10 @@ __global__ void __launch_bounds__((NW + (NW == 8 ? 0 : NW == 4 ? 3 : 2)) * 64, N
             float rs[16];
             // addresses = wave-uniform base (block origin + pixel (i, j) of the tile) + a 32-bit per-lane byte offset
             const uint32_t bo_o = (uint32_t)(tpix * p.Cout + ch) * 4u, bo_r = (uint32_t)(tpix * res_ld + ch) * 4u;
-            if (HELP) {
+            if (RES_AHEAD) {
                 // narrow shapes (one or two waves per SIMD, nothing else hides a wait): ALL four tiles' residual values are requested
                 // before the first output transform -- the registers of the weight ring and the A fragments are free by now
-                if (r == 0 && has_res && !(F4N_ABL & 2)) {
+                if (r == 0 && has_res && !(HELP && (F4N_ABL & 2))) {
 #pragma unroll
                     for (int rr = 0; rr < 4; rr++) {
                         const int t2 = 4 * lk + rr;
@@ -753,6 +758,304 @@ __global__ void __launch_bounds__((NW + (NW == 8 ? 0 : NW == 4 ? 3 : 2)) * 64, N
 #ifdef DLPM_PHASE_DEFER
     if (p.phase && lane == 0) atomicAdd(p.phase + 16 + wave, (unsigned long long)_wait);
 #endif
+#ifdef DLPM_PHASE_TIMING
+    if (p.phase && tid == 0) {
+        atomicAdd(p.phase + 11, 1ull);
+        atomicAdd(p.phase + 12, (unsigned long long)(clock64() - _c0));
+        atomicAdd(p.phase + 13, (unsigned long long)(wall_clock64() - _r0));
+    }
+#endif
+}
+
+// =====================================================================================================================================
+// Round 6 -- the WHOLE-IMAGE shape: 32 output channels on 32x32 images (the first level of the MNIST-sized nets: 10 of the step's 3x3
+// launches, 0.68 of its 2.37 ms).  The 2 + 2-wave shape above gives such a layer 1024 workgroups of 16 tiles whose phases are mostly NOT
+// matrix work: per 8-channel phase a workgroup has 2.3 k cycles of MFMAs on each of two waves, and as much VALU again in staging
+// (GroupNorm affine + SiLU on 324 halo pixels) and the input transform, all on critical paths of one wave per SIMD; measured with the
+// deferred counters (profiles/r06/epilogue_lockstep/): 47.5 k cycles per workgroup alone on a CU, 83 k with its twin, 62 us per launch.
+// On gfx950 the fp32 MFMA and the VALU do not overlap on a SIMD anyway (tools/mb/mfma_valu_2waves), so nothing is lost by giving the
+// side work to EVERY wave and running the phases one after the other:
+//   * one workgroup = one image = 64 tiles (four 16-tile M-blocks = the image's quadrants) x 32 channels, 8 waves = 4 M-blocks x 2 channel
+//     halves: every wave is an MFMA wave (36 accumulator tiles), and two waves per SIMD hide each other's waits;
+//   * per 8-channel chunk:  transform(c): raw -> V, 24 (row group, M-block) units over the 8 waves (rows {1,2}+{0} | {3,4}+{5});
+//     barrier;  MFMAs(c) with the global loads of chunk c+1 in flight, then activate + store raw(c+1);  barrier.  V and raw are single
+//     buffers (73.7 + 55.7 KB); the barriers order LDS only, so the read-ahead stays in flight across them;
+//   * the halo is the image's own border: 1156 staged pixels per 1024 outputs (the 16-tile blocks stage 1296), every element activated once;
+//   * SAME arithmetic per output as the 2 + 2-wave shape -- same staged values, same transform expressions, same k order per accumulator,
+//     same register epilogue and the same four 256-pixel statistics partials per image -- so the results are bit-identical to it
+//     (tests/test_gpu_kernels.py::test_conv_winograd_f4_whole_image_is_bit_identical) and the weights are its fragment stream
+//     Wf[ntile][wave < 2][phase][18][lane][4], here read by the four M-block waves of a channel half.
+constexpr int FI_TILES = 64, FI_RW = 34, FI_NPIX = FI_RW * FI_RW, FI_NT = 512;
+constexpr int FI_QN = (FI_NPIX * 2 + FI_NT - 1) / FI_NT;      // staging items (pixel, channel quad) per thread: 5
+constexpr int FI_RAWBUF = FI_NPIX * F4_PRLD + 48;             // + the row skew (4 floats per four patch rows: <= 32)
+constexpr int FI_VPP = 4 * FI_TILES * 4;                      // floats per position pair: [4 channel pairs][64 tiles][4]
+constexpr int FI_VBUF = 18 * FI_VPP;
+
+// workgroup barrier that orders LDS only (__syncthreads() fences every address space: s_waitcnt vmcnt(0) would sit out the read-ahead)
+#define F4_LDS_BARRIER()                                                  \
+    do {                                                                  \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   \
+        __builtin_amdgcn_s_barrier();                                     \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");   \
+    } while (0)
+
+__global__ void __launch_bounds__(FI_NT, 1) k_conv3x3_wino4_img(ConvLaunch p) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float *V = wsm;                      // [18 position pairs][4 channel pairs][64 tiles][2 pos x 2 ch]
+    float *raw = V + FI_VBUF;            // [34 x 34][F4_PRLD] (+ skew)
+    float *Cf = raw + FI_RAWBUF;         // [A | B][Cin] GroupNorm affine of this image
+    DLPM_PHASE_DECL;
+#ifdef DLPM_PHASE_TIMING
+    const long long _c0 = clock64(), _r0 = wall_clock64();
+#endif
+    constexpr int H = 32, W = 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int mb = wave >> 1, nw = wave & 1;        // MFMA role: M-block (image quadrant, row-major) and channel half
+    const int img = blockIdx.x;
+    const int Cin = p.C0 + p.C1, nch = Cin / F4_KC, last = nch - 1;
+    const bool has_coef = p.coefA != nullptr;
+
+    // ---- raw staging: item = (halo pixel, channel quad of the chunk), 5 per thread
+    // One register per item: LDS float offset (bits 0..13) | source pixel inside the image (bits 14..23) | padding (bit 24) | no item (bit 25)
+    const int squad = tid & 1;
+    int itm[FI_QN];
+#pragma unroll
+    for (int it = 0; it < FI_QN; it++) {
+        const int pix = it * (FI_NT / 2) + (tid >> 1);
+        const int ry = pix / FI_RW, rx = pix - ry * FI_RW;
+        const int iy = ry - 1, ix = rx - 1;
+        const bool pad = iy < 0 || iy >= H || ix < 0 || ix >= W;
+        const int lo = pix * F4_PRLD + squad * 4 + 4 * (ry >> 2);      // patch row ry starts 4 (ry >> 2) floats late (bank spread of the transform's reads)
+        itm[it] = pix >= FI_NPIX ? (1 << 25) : (lo | (pad ? (1 << 24) : ((iy * W + ix) << 14)));
+    }
+    float4 xr[FI_QN];
+    auto load_raw = [&](int chunk) {
+        const int c = chunk * F4_KC + squad * 4;
+        const bool first = c < p.C0;
+        const int ld = first ? p.C0 : p.C1;
+        const float *sb = (first ? p.src0 + c : p.src1 + (c - p.C0)) + (int64_t)img * (H * W) * ld;
+#pragma unroll
+        for (int it = 0; it < FI_QN; it++) xr[it] = *reinterpret_cast<const float4 *>(sb + ((itm[it] >> 14) & 1023) * ld);   // (padding / no item: pixel 0)
+    };
+    auto store_raw = [&](int chunk) {
+        const int c = chunk * F4_KC + squad * 4;
+        float4 ca = make_float4(1.f, 1.f, 1.f, 1.f), cb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_coef) {
+            ca = *reinterpret_cast<const float4 *>(Cf + c);
+            cb = *reinterpret_cast<const float4 *>(Cf + Cin + c);
+        }
+#pragma unroll
+        for (int it = 0; it < FI_QN; it++) {
+            int iv = itm[it];
+            asm volatile("" : "+v"(iv));     // (opaque: hoisted out of the chunk loop, the five LDS addresses and padding masks cost registers the loop does not have)
+            if (iv & (1 << 25)) continue;
+            float4 x = xr[it];
+            if (has_coef) {
+                x.x = fmaf(x.x, ca.x, cb.x);
+                x.y = fmaf(x.y, ca.y, cb.y);
+                x.z = fmaf(x.z, ca.z, cb.z);
+                x.w = fmaf(x.w, ca.w, cb.w);
+            }
+            if (p.act_silu) {
+                x.x = silu_f(x.x);
+                x.y = silu_f(x.y);
+                x.z = silu_f(x.z);
+                x.w = silu_f(x.w);
+            }
+            if (iv & (1 << 24)) x = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding applies AFTER the activation
+            *reinterpret_cast<float4 *>(raw + (iv & 16383)) = x;
+        }
+    };
+
+    // ---- input transform V = B^T d B: wave (tg = wave & 3, th = wave >> 2) takes M-block tg, transform rows {1, 2} + {0} (th = 0) or
+    // {3, 4} + {5} (th = 1); lane = (channel pair, tile), tile fastest
+    int rbase, vofs;
+    {
+        const int tg = wave & 3, tile = lane & 15, pair = lane >> 4;
+        const int ty = 4 * (tg >> 1) + (tile >> 2), tx = 4 * (tg & 1) + (tile & 3);
+        rbase = (4 * ty * FI_RW + 4 * tx) * F4_PRLD + pair * 2 + 4 * ty;
+        vofs = (pair * FI_TILES + 16 * tg + tile) * 4;
+    }
+    const int th = wave >> 2;
+    auto transform = [&]() {
+        const float *rb = raw + rbase;
+        float *vb = V + vofs;
+        auto d = [&](int i, int c) {      // sample row i, column c of this tile's 6x6 patch; rows 4 and 5 lie in the next skew group
+            return *reinterpret_cast<const float2 *>(rb + (i * FI_RW + c) * F4_PRLD + (i >= 4 ? 4 : 0));
+        };
+        auto row_out = [&](const float2 (&T)[6], int a) {
+            float *vr = vb + a * 3 * FI_VPP;
+            const float2 e1 = f2fma(-PB2, T[2], T[4]), o1 = f2fma(-PB2, T[1], T[3]);
+            const float2 e2 = f2fma(-PA2, T[2], T[4]), o2 = f2fma(-PA2, T[1], T[3]);
+            const float2 v0 = f2fma(PP2, T[0], f2fma(-PS2, T[2], T[4])), v1 = f2fma(PA, o1, e1), v2 = f2fma(-PA, o1, e1);
+            const float2 v3 = f2fma(PB, o2, e2), v4 = f2fma(-PB, o2, e2), v5 = f2fma(PP2, T[1], f2fma(-PS2, T[3], T[5]));
+            *reinterpret_cast<float4 *>(vr + 0 * FI_VPP) = make_float4(v0.x, v0.y, v1.x, v1.y);
+            *reinterpret_cast<float4 *>(vr + 1 * FI_VPP) = make_float4(v2.x, v2.y, v3.x, v3.y);
+            *reinterpret_cast<float4 *>(vr + 2 * FI_VPP) = make_float4(v4.x, v4.y, v5.x, v5.y);
+        };
+        float2 Ta[6], Tb[6];
+        if (th == 0) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const float2 e = f2fma(-PB2, d(2, c), d(4, c)), o = f2fma(-PB2, d(1, c), d(3, c));
+                Ta[c] = f2fma(PA, o, e);
+                Tb[c] = f2fma(-PA, o, e);
+            }
+            row_out(Ta, 1);
+            row_out(Tb, 2);
+#pragma unroll
+            for (int c = 0; c < 6; c++) Ta[c] = f2fma(PP2, d(0, c), f2fma(-PS2, d(2, c), d(4, c)));
+            row_out(Ta, 0);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const float2 e = f2fma(-PA2, d(2, c), d(4, c)), o = f2fma(-PA2, d(1, c), d(3, c));
+                Ta[c] = f2fma(PB, o, e);
+                Tb[c] = f2fma(-PB, o, e);
+            }
+            row_out(Ta, 3);
+            row_out(Tb, 4);
+#pragma unroll
+            for (int c = 0; c < 6; c++) Tb[c] = f2fma(PP2, d(1, c), f2fma(-PS2, d(3, c), d(5, c)));
+            row_out(Tb, 5);
+        }
+    };
+
+    // ---- weight stream of this wave's channel half (the 2 + 2-wave shape's Wf[ntile 0][wave nw][phase][18][lane][4]) and its A fragments
+    const float4 *__restrict__ wp = reinterpret_cast<const float4 *>(p.w_wino4) + (int64_t)nw * nch * 18 * 64;
+    constexpr int AHEAD = F4_RING - 1;
+    float4 bq[F4_RING];
+    const float *asrc = V + (lk * FI_TILES + 16 * mb + li) * 4;
+    floatx4 acc[36];
+#pragma unroll
+    for (int q = 0; q < 36; q++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[q][r] = 0.f;
+
+    // ---- prologue: coefficients -> LDS, chunk 0 staged
+    load_raw(0);
+    if (has_coef) {
+        for (int i = tid; i < 2 * Cin; i += FI_NT) Cf[i] = i < Cin ? p.coefA[(int64_t)img * Cin + i] : p.coefB[(int64_t)img * Cin + (i - Cin)];
+    }
+    F4_LDS_BARRIER();
+    store_raw(0);
+    F4_LDS_BARRIER();
+    DLPM_PHASE(p, 8);
+
+#pragma unroll 1
+    for (int chunk = 0; chunk < nch; chunk++) {
+        transform();                                   // raw(chunk) -> V
+        // (the weight ring is refilled per chunk, BEHIND the transform: kept across it, its 20 registers beside the 36 accumulators
+        //  and the transform's patch rows were scratch memory; the fragments are L2-resident and land during the barrier)
+#pragma unroll
+        for (int a = 0; a < AHEAD; a++) bq[a] = wp[a * 64 + lane];
+        load_raw(min(chunk + 1, last));                // in flight across the barrier and the MFMAs
+        F4_LDS_BARRIER();                              // V complete, raw free
+        float4 aq[2];
+        aq[0] = *reinterpret_cast<const float4 *>(asrc);
+#pragma unroll
+        for (int pp = 0; pp < 18; pp++) {
+            if (pp + AHEAD < 18) bq[(pp + AHEAD) % F4_RING] = wp[(pp + AHEAD) * 64 + lane];
+            if (pp + 1 < 18) aq[(pp + 1) & 1] = *reinterpret_cast<const float4 *>(asrc + (pp + 1) * FI_VPP);
+            const float4 aa = aq[pp & 1];
+            const float4 b = bq[pp % F4_RING];
+            acc[2 * pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.x, b.x, acc[2 * pp], 0, 0, 0);
+            acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.z, b.z, acc[2 * pp + 1], 0, 0, 0);
+            acc[2 * pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.y, b.y, acc[2 * pp], 0, 0, 0);
+            acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.w, b.w, acc[2 * pp + 1], 0, 0, 0);
+        }
+        wp += 18 * 64;
+        if (chunk < last) store_raw(chunk + 1);
+        F4_LDS_BARRIER();                              // raw(chunk + 1) complete, V free
+    }
+    DLPM_PHASE(p, 9);
+
+    // ---- epilogue from registers (the 2 + 2-wave shape's: lane = channel, 4 tiles x 16 pixels; all four tiles' residual values are
+    // requested before the first output transform; statistics = one partial per 256-pixel quadrant)
+    {
+        const int ty0 = 4 * (mb >> 1), tx0 = 4 * (mb & 1);
+        const int64_t pix0 = ((int64_t)img * H + 4 * ty0) * W + 4 * tx0;      // wave-uniform
+        const int ch = 16 * nw + li;
+        const float bias_v = p.bias ? p.bias[ch] : 0.f;
+        const bool has_res = p.res0 != nullptr;
+        const bool res_first = 16 * nw < p.R0;   // R0 % 16 == 0 (wino4_geometry)
+        const float *res_u = has_res ? (res_first ? p.res0 : p.res1 - p.R0) : nullptr;
+        const int res_ld = res_first ? p.R0 : p.Cout - p.R0;
+        float *__restrict__ out_blk = p.out + pix0 * p.Cout;
+        const float *__restrict__ res_blk = has_res ? res_u + pix0 * res_ld : nullptr;
+        const bool do_stats = p.stats_out != nullptr;
+        float K = 0.f, s1 = 0.f, s2 = 0.f;
+        float rs_all[4][16] = {};
+        if (has_res) {
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int t2 = 4 * lk + rr;
+                const int tp2 = (4 * (t2 >> 2)) * W + 4 * (t2 & 3);
+                const uint32_t b2 = (uint32_t)(tp2 * res_ld + ch) * 4u;
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    rs_all[rr][k] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(res_blk + ((k >> 2) * W + (k & 3)) * res_ld) + b2);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int tile = 4 * lk + r;
+            const int tpix = (4 * (tile >> 2)) * W + 4 * (tile & 3);
+            const uint32_t bo_o = (uint32_t)(tpix * p.Cout + ch) * 4u;
+            float Yt[16];
+            float Z[4][6];
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                const float m0 = acc[0 * 6 + b][r], m1 = acc[1 * 6 + b][r], m2 = acc[2 * 6 + b][r];
+                const float m3 = acc[3 * 6 + b][r], m4 = acc[4 * 6 + b][r], m5 = acc[5 * 6 + b][r];
+                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                Z[0][b] = m0 + s12 + s34;
+                Z[1][b] = fmaf(PB, d34, PA * d12);
+                Z[2][b] = fmaf(PB2, s34, PA2 * s12);
+                Z[3][b] = fmaf(PB3, d34, PA3 * d12) + m5;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float s12 = Z[i][1] + Z[i][2], d12 = Z[i][1] - Z[i][2], s34 = Z[i][3] + Z[i][4], d34 = Z[i][3] - Z[i][4];
+                Yt[i * 4 + 0] = Z[i][0] + s12 + s34;
+                Yt[i * 4 + 1] = fmaf(PB, d34, PA * d12);
+                Yt[i * 4 + 2] = fmaf(PB2, s34, PA2 * s12);
+                Yt[i * 4 + 3] = fmaf(PB3, d34, PA3 * d12) + Z[i][5];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float v = Yt[i * 4 + j] + bias_v;
+                    if (has_res) v += rs_all[r][i * 4 + j];
+                    if (do_stats) {
+                        if (r == 0 && i == 0 && j == 0) K = v;
+                        const float dd = v - K;
+                        s1 += dd;
+                        s2 = fmaf(dd, dd, s2);
+                    }
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(out_blk + (i * W + j) * p.Cout) + bo_o) = v;
+                }
+            }
+        }
+        if (do_stats) {
+            float mean = K + s1 * (1.f / 64.f), M2 = fmaxf(s2 - s1 * s1 * (1.f / 64.f), 0.f), na = 64.f;
+#pragma unroll
+            for (int sft = 16; sft <= 32; sft <<= 1) {
+                const float om = __shfl_xor(mean, sft), oM2 = __shfl_xor(M2, sft);
+                const float lo_m = (lane & sft) ? om : mean, hi_m = (lane & sft) ? mean : om;
+                const float lo_M = (lane & sft) ? oM2 : M2, hi_M = (lane & sft) ? M2 : oM2;
+                const float dd = hi_m - lo_m;
+                mean = lo_m + dd * 0.5f;
+                M2 = lo_M + hi_M + dd * dd * (na * 0.5f);
+                na *= 2.f;
+            }
+            if (lk == 0) p.stats_out[((int64_t)img * 4 + mb) * p.Cout + ch] = make_float2(mean, M2);
+        }
+    }
+    DLPM_PHASE(p, 10);
+    DLPM_PHASE_FLUSH(p, 8);
 #ifdef DLPM_PHASE_TIMING
     if (p.phase && tid == 0) {
         atomicAdd(p.phase + 11, 1ull);
@@ -873,6 +1176,14 @@ bool wino4_preferred(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
     return mblocks * (c.Cout / f4_nq_of(c.Cout)) >= 256;
 }
 
+// DLPM_WINO4_IMG=0 (A/B runs): the 32-channel 32x32 layers on the 2 + 2-wave 16-tile shape as in round 5 (same bits either way).  A
+// function of the layer's geometry only, like every other kernel choice.
+static bool wino4_whole_image(const ConvLaunch &c) {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DLPM_WINO4_IMG"); v = e ? atoi(e) : 1; }
+    return v != 0 && c.Cout == 32 && !c.ups && c.Hout == 32 && c.Wout == 32 && (c.C0 + c.C1) <= 1024;
+}
+
 int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
     int bh, bw, nimg;
     if (!wino4_geometry(c, &bh, &bw, &nimg)) {
@@ -886,6 +1197,14 @@ int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
     const int nq = f4_nq_of(c.Cout);
     const int64_t tiles = (int64_t)c.B * (c.Hout / 4) * (c.Wout / 4);
     const int64_t mblocks = nimg == 1 ? tiles / F4_TILES : ceil_div(c.B, nimg);
+    if (wino4_whole_image(c)) {   // 32 channels on 32x32 images: one workgroup per image, 8 MFMA waves (round 6)
+        const int r = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_conv3x3_wino4_img), 160 * 1024);
+        if (r != DLPM_OK) return r;
+        const size_t lds = (size_t)(FI_VBUF + FI_RAWBUF + 2 * (c.C0 + c.C1)) * sizeof(float);
+        k_conv3x3_wino4_img<<<(unsigned)c.B, FI_NT, lds, st>>>(c);
+        DLPM_LAUNCH_CHECK();
+        return DLPM_OK;
+    }
     if (nq != F4_NQ) {   // narrow layers: 4 MFMA + 3 helper waves (448 threads: 2 staging items cover 400 halo pixels), or 2 + 2 (256 threads: 4 items)
         KFn fn = nq == 64 ? (c.ups ? &k_conv3x3_wino4<true, 0, 2, 0, 0, 4> : &k_conv3x3_wino4<false, 0, 2, 0, 0, 4>)
                           : (c.ups ? &k_conv3x3_wino4<true, 0, 4, 0, 0, 2> : &k_conv3x3_wino4<false, 0, 4, 0, 0, 2>);

@@ -893,6 +893,63 @@ def test_pipelined_split_gemm_is_bit_identical_to_the_two_barrier_kernel():
     assert len(out['1']) == 64 and out['1'] == out['0'], out
 
 
+_WHOLE_IMAGE_DIGEST_SCRIPT = r"""
+import hashlib, sys, torch
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, sys.argv[1] + '/tests')
+import test_gpu_kernels as T
+import dlpm_amd
+h = hashlib.sha256()
+for name, B, C0, C1, use_coef, use_res in T.WHOLE_IMAGE_CASES:
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    x0 = torch.randn(B, C0, 32, 32, generator=g)
+    x1 = torch.randn(B, C1, 32, 32, generator=g) if C1 else None
+    w = torch.randn(32, C0 + C1, 3, 3, generator=g) / (9 * (C0 + C1)) ** 0.5
+    bias = torch.randn(32, generator=g)
+    coef = (1 + 0.3 * torch.randn(B, C0 + C1, generator=g), 0.3 * torch.randn(B, C0 + C1, generator=g)) if use_coef else None
+    res = torch.randn(B, 32, 32, 32, generator=g) if use_res else None
+    got = T.run_conv(x0, w, bias, x1, 1, 0, coef, use_coef, res, force_direct=8)
+    want = T.ref_conv(x0, w, bias, x1, 1, 0, coef, use_coef, res)
+    assert (got - want).abs().max().item() < 2e-5, name
+    h.update(got.numpy().tobytes())
+# ... and inside the MNIST-sized net, where the kernel also emits the GroupNorm statistics its consumers normalise with
+p = dlpm_amd.load_config('mnist')
+torch.manual_seed(1234)
+net = dlpm_amd.rerandomize_(dlpm_amd.init_model_by_parameter(p), 4321).to('cuda')
+g = torch.Generator().manual_seed(5)
+x = torch.randn(5, 1, 32, 32, generator=g).cuda()
+t = torch.rand(5, generator=g).cuda()
+h.update(net(x, t).cpu().numpy().tobytes())
+print(h.hexdigest())
+"""
+
+WHOLE_IMAGE_CASES = [
+    # name, B, C0, C1, coef + silu, res   -- 32 output channels on 32x32 images: k_conv3x3_wino4_img
+    ('img_32_gn_silu_res', 3, 32, 0, True, True),
+    ('img_32_plain', 1, 32, 0, False, False),
+    ('img_concat_64_32_gn_silu', 2, 64, 32, True, False),
+    ('img_concat_32_32_gn_silu', 2, 32, 32, True, False),
+    ('img_96_gn_silu_res', 1, 96, 0, True, True),
+]
+
+
+def test_conv_winograd_f4_whole_image_is_bit_identical():
+    """Round 6: k_conv3x3_wino4_img (one workgroup per 32x32 image, 8 MFMA waves, phases run one after the other) is a re-scheduling of the
+    2 + 2-wave 16-tile shape's arithmetic -- same staged values, same transform expressions, same k order per accumulator, same epilogue
+    and statistics partials: every case (against fp64 inside the child, 2e-5) and the whole MNIST-sized UNet forward must come out bit
+    for bit the same with DLPM_WINO4_IMG=1 (default) and =0.  Read once per process: two child processes, one digest each."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for img in ('1', '0'):
+        e = dict(os.environ, DLPM_WINO4_IMG=img)
+        r = subprocess.run([sys.executable, '-c', _WHOLE_IMAGE_DIGEST_SCRIPT, root], env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[img] = r.stdout.strip().splitlines()[-1]
+    assert len(out['1']) == 64 and out['1'] == out['0'], out
+
+
 SPLIT3_CASES = [
     # name, B, C0, C1, H, Cout, stride, coef+silu, res
     ('down_16_to_8', 3, 128, 0, 16, 128, 2, False, False),
