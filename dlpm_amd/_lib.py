@@ -134,6 +134,8 @@ SIGNATURES = {
     'dlpm_groupnorm_coeffs_f32': (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i64, i64, vp, vp, vp]),
     'dlpm_attention_f32': (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     'dlpm_resblock_small_f32': (C.c_int, [C.POINTER(ResBlockArgs), vp, i64, vp]),
+    'dlpm_resblock_img_f32': (C.c_int, [C.POINTER(ResBlockArgs), vp, i64, vp]),
+    'dlpm_resblock_img_scratch_floats': (i64, [i64, i32]),
     'dlpm_attnblock_small_f32': (C.c_int, [C.POINTER(AttnBlockArgs), vp, i64, vp]),
     'dlpm_timestep_embedding_f32': (C.c_int, [vp, vp, i64, i32, vp]),
     'dlpm_nchw_to_nhwc_f32': (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),

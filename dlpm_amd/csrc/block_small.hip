@@ -490,6 +490,281 @@ __global__ void __launch_bounds__(RS_NT, 1) k_attnblock_small(AttnSmallLaunch p)
     }   // !QKV_ONLY
 }
 
+// ---- AttentionBlock of a 16x16 image (T = 256) in ONE launch (round 6).  Round 4 stopped at GroupNorm + qkv for this size (qkv of all four
+// heads is 196 KB) and left attention.hip's kernel and the proj launch behind it: 25 + 60 + 14 us per block on the MNIST config, 0.50 of
+// its 2.25 ms step, with qkv (50 MB) and the attention output (17 MB) crossing HBM between them.  Here a workgroup walks the HEADS:
+//   xn  = GN(x) in LDS (70 KB);  per head h:  q | k | v of that head = xn Wqkv[3h .. 3h+2] (53 KB, q and k pre-scaled) -> barrier ->
+//   a_h = softmax(q k^T) v for 16 query tiles (two per wave; the core of k_attnblock_small with 16 key tiles) -> barrier ->
+//   out += a_h Wproj[:, 16h .. 16h+15] -- the proj GEMM accumulates over the heads in REGISTERS (a wave owns 32 pixels x 64 channels:
+//   8 accumulator tiles), in the same channel order as a single K = 64 pass.  Nothing but x and the result touches HBM.
+// (second form: q | k | v of a head in ONE pass over the normalised image -- every A fragment feeds six independent accumulators instead
+//  of being re-read per 16-channel tile; v is kept TRANSPOSED, vT[channel][key], so that the P V products read one 16-byte word per key
+//  tile where the first form read four scalars; S and P V run four independent accumulator chains instead of one: 90 -> see profiles/r06.)
+constexpr int A16_T = 256, A16_QLD = 2 * AB_CH + 4, A16_VLD = A16_T + 4, A16_ALD = AB_CH + 4;
+
+__global__ void __launch_bounds__(RS_NT, 1) k_attnblock16(AttnSmallLaunch p) {
+    constexpr int T = A16_T, MT = T / 16;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *xn = sm;                        // [T][AB_LD]    x, then GN(x) in place
+    float *qh = xn + T * AB_LD;            // [T][A16_QLD]  q | k of the current head (scaled)
+    float *vT = qh + T * A16_QLD;          // [16][A16_VLD] v of the current head, transposed
+    float *ah = vT + AB_CH * A16_VLD;      // [T][A16_ALD]  attention output of the current head
+    float *cf = ah + T * A16_ALD;          // [2][64]
+    float *red = qh;                       // epilogue: [2][8 waves][64] partial statistics (qh is dead by then)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.x;
+    const int c_gn = min(2 * (tid >> 4) + (tid & 15), AB_C - 1);
+    const float pr_gw = p.gn_w[c_gn], pr_gb = p.gn_b[c_gn];
+    float pr_bp[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) pr_bp[nt] = p.bproj[16 * nt + ln];
+    for (int i = tid; i < T * (AB_C / 4); i += RS_NT) {
+        const int pix = i >> 4, c = (i & 15) * 4;
+        *reinterpret_cast<float4 *>(xn + pix * AB_LD + c) = *reinterpret_cast<const float4 *>(p.x + ((int64_t)b * T + pix) * AB_C + c);
+    }
+    __syncthreads();
+    {   // GroupNorm: 32 groups of two channels x 16 threads, two passes over the LDS copy (k_attnblock_small's)
+        const int g = tid >> 4, i = tid & 15;
+        const float inv_n = 1.0f / (float)(2 * T);
+        float s = 0.f;
+        for (int pp = i; pp < T; pp += 16) s += xn[pp * AB_LD + 2 * g] + xn[pp * AB_LD + 2 * g + 1];
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+        const float mean = s * inv_n;
+        float v = 0.f;
+        for (int pp = i; pp < T; pp += 16) {
+            const float d0 = xn[pp * AB_LD + 2 * g] - mean, d1 = xn[pp * AB_LD + 2 * g + 1] - mean;
+            v = fmaf(d0, d0, v);
+            v = fmaf(d1, d1, v);
+        }
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        const float rstd = 1.0f / sqrtf(v * inv_n + 1e-5f);
+        if (i < 2) {
+            const int c = 2 * g + i;
+            const float a = rstd * pr_gw;
+            cf[c] = a;
+            cf[AB_C + c] = pr_gb - mean * a;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < T * (AB_C / 4); i += RS_NT) {
+        const int pix = i >> 4, c = (i & 15) * 4;
+        const float4 x = *reinterpret_cast<const float4 *>(xn + pix * AB_LD + c);
+        const float4 A = *reinterpret_cast<const float4 *>(cf + c), Bc = *reinterpret_cast<const float4 *>(cf + AB_C + c);
+        *reinterpret_cast<float4 *>(xn + pix * AB_LD + c) = make_float4(fmaf(x.x, A.x, Bc.x), fmaf(x.y, A.y, Bc.y), fmaf(x.z, A.z, Bc.z), fmaf(x.w, A.w, Bc.w));
+    }
+    __syncthreads();
+    // this wave's rows of the two GEMMs: pixels 32 wave .. 32 wave + 31 (two pixel tiles)
+    const int row0 = 32 * wave;
+    int abx[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) abx[mt] = (row0 + 16 * mt + ln) * AB_LD + 4 * lq;
+    floatx4 pacc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) pacc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int h = 0; h < AB_HEADS; h++) {
+        // ---- (1) q | k | v of head h for this wave's 32 pixels in one pass (qkv channel order is head-major [head][q | k | v][16]:
+        // output tile nt = 3 h + qi): 12 weight fragments, six accumulator tiles
+        {
+            float4 wq[3][4];
+#pragma unroll
+            for (int qi = 0; qi < 3; qi++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) wq[qi][j] = reinterpret_cast<const float4 *>(p.wqkv)[((int64_t)(3 * h + qi) * 4 + j) * 64 + lane];
+            float bias[3];
+#pragma unroll
+            for (int qi = 0; qi < 3; qi++) bias[qi] = p.bqkv[16 * (3 * h + qi) + ln];
+            floatx4 acc[2][3];
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int qi = 0; qi < 3; qi++) acc[mt][qi] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float4 a[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++) a[mt] = *reinterpret_cast<const float4 *>(xn + abx[mt] + 16 * j);
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int qi = 0; qi < 3; qi++) acc[mt][qi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, wq[qi][j].x, acc[mt][qi], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int qi = 0; qi < 3; qi++) acc[mt][qi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, wq[qi][j].y, acc[mt][qi], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int qi = 0; qi < 3; qi++) acc[mt][qi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, wq[qi][j].z, acc[mt][qi], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int qi = 0; qi < 3; qi++) acc[mt][qi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, wq[qi][j].w, acc[mt][qi], 0, 0, 0);
+            }
+            // q and k carry ch^(-1/4) = 0.5 (ch = 16, exact): rows of qh; v goes to vT[channel ln][pixels 4 lq .. 4 lq + 3 of the tile]
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    qh[(row0 + 16 * mt + 4 * lq + r) * A16_QLD + ln] = (acc[mt][0][r] + bias[0]) * 0.5f;
+                    qh[(row0 + 16 * mt + 4 * lq + r) * A16_QLD + AB_CH + ln] = (acc[mt][1][r] + bias[1]) * 0.5f;
+                }
+                *reinterpret_cast<float4 *>(vT + ln * A16_VLD + row0 + 16 * mt + 4 * lq) =
+                    make_float4(acc[mt][2][0] + bias[2], acc[mt][2][1] + bias[2], acc[mt][2][2] + bias[2], acc[mt][2][3] + bias[2]);
+            }
+        }
+        // the head's slice of the proj weights (fragment j = h of each output tile), requested ahead of the attention
+        float4 wpj[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) wpj[nt] = reinterpret_cast<const float4 *>(p.wproj)[((int64_t)nt * 4 + h) * 64 + lane];
+        __syncthreads();
+        // ---- (2) attention of head h: query tiles wave, wave + 8; a_h -> ah
+#pragma unroll 1
+        for (int u = wave; u < MT; u += 8) {
+            const int t0 = 16 * u;
+            const float *kb = qh + AB_CH;
+            const float4 qv = *reinterpret_cast<const float4 *>(qh + (t0 + ln) * A16_QLD + 4 * lq);
+            floatx4 acc[MT];
+#pragma unroll
+            for (int jg = 0; jg < MT; jg += 4) {      // four key tiles at a time: four independent accumulator chains
+                float4 kv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    acc[jg + j] = floatx4{0.f, 0.f, 0.f, 0.f};
+                    kv[j] = *reinterpret_cast<const float4 *>(kb + (16 * (jg + j) + ln) * A16_QLD + 4 * lq);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[jg + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[j].x, qv.x, acc[jg + j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[jg + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[j].y, qv.y, acc[jg + j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[jg + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[j].z, qv.z, acc[jg + j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[jg + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[j].w, qv.w, acc[jg + j], 0, 0, 0);
+            }
+            // acc[j][r] = S[query t0 + ln][key 16 j + 4 lq + r]: softmax over the keys = registers (j, r) and the four lane groups
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < MT; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) mx = fmaxf(mx, acc[j][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < MT; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    acc[j][r] = __expf(acc[j][r] - mx);
+                    sum += acc[j][r];
+                }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float rsum = 1.0f / sum;
+            // P V: key tile j contributes to chain j & 3 (four independent accumulators, summed pairwise at the end); the B operand of the
+            // four MFMAs of a key tile = v of keys 16 j + 4 lq .. + 3, channel ln = one 16-byte word of vT
+            floatx4 o4[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) o4[c] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jg = 0; jg < MT; jg += 4) {
+                float4 vv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) vv[j] = *reinterpret_cast<const float4 *>(vT + ln * A16_VLD + 16 * (jg + j) + 4 * lq);
+#pragma unroll
+                for (int j = 0; j < 4; j++) o4[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[jg + j][0] * rsum, vv[j].x, o4[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; j++) o4[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[jg + j][1] * rsum, vv[j].y, o4[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; j++) o4[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[jg + j][2] * rsum, vv[j].z, o4[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; j++) o4[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[jg + j][3] * rsum, vv[j].w, o4[j], 0, 0, 0);
+            }
+            // D: row = query 4 lq + r of the tile, column = channel ln of the head
+#pragma unroll
+            for (int r = 0; r < 4; r++) ah[(t0 + 4 * lq + r) * A16_ALD + ln] = (o4[0][r] + o4[1][r]) + (o4[2][r] + o4[3][r]);
+        }
+        __syncthreads();
+        // ---- (3) out += a_h Wproj[:, 16 h ..]: one K = 16 fragment per (pixel tile, output tile)
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+            const float4 a = *reinterpret_cast<const float4 *>(ah + (row0 + 16 * mt + ln) * A16_ALD + 4 * lq);
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                pacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wpj[nt].x, pacc[mt][nt], 0, 0, 0);
+                pacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wpj[nt].y, pacc[mt][nt], 0, 0, 0);
+                pacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wpj[nt].z, pacc[mt][nt], 0, 0, 0);
+                pacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wpj[nt].w, pacc[mt][nt], 0, 0, 0);
+            }
+        }
+        // (the next head's (1) overwrites qh -- every wave is past (2); its (2) overwrites ah behind the barrier that follows (1))
+    }
+    // ---- epilogue: out = x + (proj + bias); x is re-read (L2: this workgroup loaded it at entry)
+    const float *xg = p.x + (int64_t)b * T * AB_C;
+    float *og = p.out + (int64_t)b * T * AB_C;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int pix = row0 + 16 * mt + 4 * lq + r, co = 16 * nt + ln;
+                const float v = xg[pix * AB_C + co] + (pacc[mt][nt][r] + pr_bp[nt]);
+                pacc[mt][nt][r] = v;
+                s[nt] += v;
+                og[pix * AB_C + co] = v;
+            }
+    if (p.stats_out) {   // per-image (mean, centred sum of squares) per channel: the eight waves' partials meet in LDS, fixed order
+        __syncthreads();     // (every wave is done with ah / qh)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            s[nt] += __shfl_xor(s[nt], 16);
+            s[nt] += __shfl_xor(s[nt], 32);
+            if (lq == 0) red[wave * AB_C + 16 * nt + ln] = s[nt];
+        }
+        __syncthreads();
+        float mean[4], m2[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; w++) t += red[w * AB_C + 16 * nt + ln];
+            mean[nt] = t * (1.0f / (float)T);
+            m2[nt] = 0.f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float d = pacc[mt][nt][r] - mean[nt];
+                    m2[nt] = fmaf(d, d, m2[nt]);
+                }
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            m2[nt] += __shfl_xor(m2[nt], 16);
+            m2[nt] += __shfl_xor(m2[nt], 32);
+            if (lq == 0) red[(8 + wave) * AB_C + 16 * nt + ln] = m2[nt];
+        }
+        __syncthreads();
+        if (tid < AB_C) {
+            float t = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                t += red[w * AB_C + tid];
+                q += red[(8 + w) * AB_C + tid];
+            }
+            p.stats_out[(int64_t)b * AB_C + tid] = make_float2(t * (1.0f / (float)T), q);
+        }
+    }
+}
+
 // OIHW (taps = ks * ks) -> Wf[cout / 16][fragment = tap * Cin / 16 + j][lane = lk * 16 + li][e]:
 //   W[cout = 16 w + li][cin = 16 j + 4 lk + e][tap]
 __global__ void k_relayout_weight_small(const float *oihw, float *dst, int Cout, int Cin, int taps) {
@@ -542,6 +817,30 @@ bool res_small_ok(const ResSmallLaunch &r) {
 
 bool attn_small_ok(const AttnSmallLaunch &a) {
     return small_blocks_enabled() && a.wqkv && a.wproj && a.C == AB_C && a.heads == AB_HEADS && a.H == a.W && (a.H == 8 || a.H == 4);
+}
+
+// 16x16 images, round 6: the whole block in one launch, one head at a time (k_attnblock16).  DLPM_ATTN16=0 (A/B runs) restores round 4's
+// GroupNorm + qkv launch followed by attention.hip's kernel and the proj GEMM.
+bool attn16_ok(const AttnSmallLaunch &a) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("DLPM_ATTN16"); on = e ? atoi(e) : 1; }
+    return on && small_blocks_enabled() && a.wqkv && a.wproj && a.C == AB_C && a.heads == AB_HEADS && a.H == 16 && a.W == 16;
+}
+
+int launch_attnblock16(const AttnSmallLaunch &a, hipStream_t st) {
+    if (!attn16_ok(a)) {
+        set_error("launch_attnblock16: unsupported block shape");
+        return DLPM_ERR_UNSUPPORTED;
+    }
+    const int T = A16_T;
+    const double fl = 2.0 * a.B * T * (4.0 * AB_C * AB_C + 2.0 * T * AB_C);
+    ProfScope ps("attnblock16:H16", fl, 4.0 * (2.0 * a.B * T * AB_C + 4.0 * AB_C * AB_C), st);
+    const size_t lds = (size_t)(T * AB_LD + T * A16_QLD + AB_CH * A16_VLD + T * A16_ALD + 2 * AB_C) * sizeof(float);
+    int e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_attnblock16), 160 * 1024);
+    if (e != DLPM_OK) return e;
+    k_attnblock16<<<(unsigned)a.B, RS_NT, lds, st>>>(a);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
 }
 
 // 16x16 images: GroupNorm + qkv in one launch per image (a.out = qkv [B][256][192]); attention and proj_out stay separate launches

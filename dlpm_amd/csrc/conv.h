@@ -98,6 +98,33 @@ bool wino4_preferred(const ConvLaunch &c, int *bh, int *bw, int *nimg);   // geo
 int launch_conv_wino4(const ConvLaunch &c, hipStream_t st);
 int64_t wino4_weight_floats(int Cout, int Cin);
 int relayout_weight_wino4(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st);
+// A WHOLE ResBlock with 32 output channels on 32x32 images in one launch (round 6, conv_wino4.hip: k_resblock_wino4_img): GroupNorm-1
+// coefficients from the producers' statistics (or given), conv1 as F(4x4,3x3), GroupNorm-2 with scale-shift inside the workgroup (an image
+// is one workgroup), conv2 over the activated intermediate (which makes one trip through L2, never a second launch), skip, output
+// statistics.  The 1x1 skip convolution of the concat blocks stays a launch of its own (its result arrives as `res`).
+struct ResImgLaunch {
+    const float *x0 = nullptr, *x1 = nullptr;        // NHWC input, virtual concat [x0 | x1]
+    int C0 = 0, C1 = 0, B = 0;
+    const float2 *st0 = nullptr, *st1 = nullptr;     // producers' statistics ([B][nt][C] float2) -> GroupNorm-1 inside the kernel, or
+    int nt0 = 1, nt1 = 1;
+    const float *coefA1 = nullptr, *coefB1 = nullptr;   // ... its coefficients [B][Cin] computed by a launch in front (sources without statistics)
+    const float *gn1_w = nullptr, *gn1_b = nullptr, *gn2_w = nullptr, *gn2_b = nullptr;
+    const float *w1 = nullptr, *b1 = nullptr;        // in_layers.2 (3x3, Cin -> 32): F(4x4) fragment stream (relayout_weight_wino4)
+    const float *w2 = nullptr, *b2 = nullptr;        // out_layers.3 (3x3, 32 -> 32)
+    const float *emb = nullptr;                      // emb_layers output rows: scale at [emb_off + c], shift at [emb_off + 32 + c]
+    int64_t emb_stride = 0;
+    int emb_off = 0;
+    const float *res = nullptr;                      // [B][1024][32]: x itself (identity skip) or the 1x1 skip convolution's output
+    float *hbuf = nullptr;                           // [B][1024][32] scratch: silu(GN2(conv1(..)) (1 + scale) + shift)
+    float *out = nullptr;                            // [B][1024][32]
+    float2 *stats_out = nullptr;                     // optional [B][4][32]: (mean, M2) per 256-pixel quadrant, as the convolution kernels emit
+#ifdef DLPM_PHASE_TIMING
+    unsigned long long *phase = nullptr;
+#endif
+};
+bool res_img_ok(const ResImgLaunch &r);
+int launch_resblock_img(const ResImgLaunch &r, hipStream_t st);
+
 // 1x1 convolutions, and 3x3 ones as an implicit GEMM, on the bf16 matrix pipe with fp32 operands split exactly into three
 // bf16 planes (conv_split.hip); taps = 1 or 9
 bool conv_split_ok(const ConvLaunch &c);
@@ -156,6 +183,8 @@ struct AttnSmallLaunch {                         // AttentionBlock, 64 channels,
 };
 bool attn_small_ok(const AttnSmallLaunch &a);
 int launch_attnblock_small(const AttnSmallLaunch &a, hipStream_t st);
+bool attn16_ok(const AttnSmallLaunch &a);        // 16x16 images (round 6): the whole block, one head at a time
+int launch_attnblock16(const AttnSmallLaunch &a, hipStream_t st);
 bool gnqkv_small_ok(const AttnSmallLaunch &a);   // 16x16 images: GroupNorm + qkv only, out = qkv [B][256][192]
 int launch_gnqkv_small(const AttnSmallLaunch &a, hipStream_t st);
 bool small_blocks_enabled();                     // DLPM_NO_FUSED_BLOCKS

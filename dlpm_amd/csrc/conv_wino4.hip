@@ -35,6 +35,7 @@
 #include <type_traits>
 
 #include "conv.h"
+#include "gn_stats.h"
 
 namespace dlpm {
 namespace {
@@ -1065,6 +1066,325 @@ __global__ void __launch_bounds__(FI_NT, 1) k_conv3x3_wino4_img(ConvLaunch p) {
 #endif
 }
 
+// =====================================================================================================================================
+// Round 6 -- a WHOLE ResBlock (dlpm/models/unet.py:105-196, use_scale_shift_norm) with 32 output channels on 32x32 images in ONE launch:
+//     h = conv3x3(silu(GN1(x)));   a = silu(GN2(h) (1 + scale) + shift);   out = conv3x3(a) + skip
+// Two passes of k_conv3x3_wino4_img's chunk loop in one workgroup per image.  Between them the workgroup -- which holds the whole image --
+// does what the launches in between did: the four waves of a channel half leave their 256-pixel (mean, M2) partials in LDS, the
+// coefficient arithmetic of k_gn_coeffs_stats runs on them (gn_stats.h: the same function), every lane activates its 64 values of h in
+// registers and writes them ONCE, activated, to a scratch image that the second pass stages like any input (no coefficients, no SiLU
+// there: a plain copy with zero padding).  That image is 128 KB per workgroup and is read back by the CU that wrote it: an L2 round
+// trip.  GroupNorm-1's coefficients come from the producers' statistics inside the prologue (same function) when they exist.
+// Every value is computed by the expressions of the separate launches (conv -> k_gn_coeffs_stats -> conv), so the block's output
+// and its statistics partials are bit-identical to that path (tests/test_gpu_kernels.py::test_resblock_whole_image_*).
+__global__ void __launch_bounds__(FI_NT, 1) k_resblock_wino4_img(ResImgLaunch p) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float *V = wsm;                      // [18 position pairs][4 channel pairs][64 tiles][2 pos x 2 ch]
+    float *raw = V + FI_VBUF;            // [34 x 34][F4_PRLD] (+ skew)
+    float *Cf = raw + FI_RAWBUF;         // [A | B][Cin <= 128]
+    float *gsh = Cf + 256;               // GroupNorm scratch: 2 C + 2 G floats
+    float2 *part = reinterpret_cast<float2 *>(gsh + 512);   // [4 quadrants][32]: conv1's statistics partials
+    int *itmL = reinterpret_cast<int *>(gsh + 768);         // [5][512] staging items (in registers they were scratch memory beside 36 accumulators)
+    DLPM_PHASE_DECL;
+    constexpr int H = 32, W = 32, CO = 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int mb = wave >> 1, nw = wave & 1;
+    const int img = blockIdx.x;
+    const int ch = 16 * nw + li;
+
+    const int squad = tid & 1;
+#pragma unroll
+    for (int it = 0; it < FI_QN; it++) {
+        const int pix = it * (FI_NT / 2) + (tid >> 1);
+        const int ry = pix / FI_RW, rx = pix - ry * FI_RW;
+        const int iy = ry - 1, ix = rx - 1;
+        const bool pad = iy < 0 || iy >= H || ix < 0 || ix >= W;
+        const int lo = pix * F4_PRLD + squad * 4 + 4 * (ry >> 2);
+        itmL[it * FI_NT + tid] = pix >= FI_NPIX ? (1 << 25) : (lo | (pad ? (1 << 24) : ((iy * W + ix) << 14)));   // (read back by this thread only)
+    }
+    // ---- the source of the pass in flight (pass 1: x0 | x1 with GroupNorm-1 + SiLU; pass 2: the activated scratch image, plain)
+    const float *s0 = p.x0, *s1 = p.x1;
+    int c0 = p.C0, c1 = p.C1;
+    float4 xr[FI_QN];
+    auto load_raw = [&](int chunk) {
+        const int c = chunk * F4_KC + squad * 4;
+        const bool first = c < c0;
+        const int ld = first ? c0 : c1;
+        const float *sb = (first ? s0 + c : s1 + (c - c0)) + (int64_t)img * (H * W) * ld;
+#pragma unroll
+        for (int it = 0; it < FI_QN; it++) xr[it] = *reinterpret_cast<const float4 *>(sb + ((itmL[it * FI_NT + tid] >> 14) & 1023) * ld);
+    };
+    auto store_raw = [&](int chunk, auto act_c) {
+        constexpr bool ACT = decltype(act_c)::value;      // pass 1: x A + B, SiLU; pass 2: plain copy
+        const int c = chunk * F4_KC + squad * 4;
+        float4 ca = make_float4(1.f, 1.f, 1.f, 1.f), cb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ACT) {
+            ca = *reinterpret_cast<const float4 *>(Cf + c);
+            cb = *reinterpret_cast<const float4 *>(Cf + 128 + c);
+        }
+#pragma unroll
+        for (int it = 0; it < FI_QN; it++) {
+            const int iv = itmL[it * FI_NT + tid];
+            if (iv & (1 << 25)) continue;
+            float4 x = xr[it];
+            if (ACT) {
+                x.x = silu_f(fmaf(x.x, ca.x, cb.x));
+                x.y = silu_f(fmaf(x.y, ca.y, cb.y));
+                x.z = silu_f(fmaf(x.z, ca.z, cb.z));
+                x.w = silu_f(fmaf(x.w, ca.w, cb.w));
+            }
+            if (iv & (1 << 24)) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(raw + (iv & 16383)) = x;
+        }
+    };
+    int rbase, vofs;
+    {
+        const int tg = wave & 3, tile = lane & 15, pair = lane >> 4;
+        const int ty = 4 * (tg >> 1) + (tile >> 2), tx = 4 * (tg & 1) + (tile & 3);
+        rbase = (4 * ty * FI_RW + 4 * tx) * F4_PRLD + pair * 2 + 4 * ty;
+        vofs = (pair * FI_TILES + 16 * tg + tile) * 4;
+    }
+    const int th = wave >> 2;
+    auto transform = [&]() {
+        const float *rb = raw + rbase;
+        float *vb = V + vofs;
+        auto d = [&](int i, int c) {
+            return *reinterpret_cast<const float2 *>(rb + (i * FI_RW + c) * F4_PRLD + (i >= 4 ? 4 : 0));
+        };
+        auto row_out = [&](const float2 (&T)[6], int a) {
+            float *vr = vb + a * 3 * FI_VPP;
+            const float2 e1 = f2fma(-PB2, T[2], T[4]), o1 = f2fma(-PB2, T[1], T[3]);
+            const float2 e2 = f2fma(-PA2, T[2], T[4]), o2 = f2fma(-PA2, T[1], T[3]);
+            const float2 v0 = f2fma(PP2, T[0], f2fma(-PS2, T[2], T[4])), v1 = f2fma(PA, o1, e1), v2 = f2fma(-PA, o1, e1);
+            const float2 v3 = f2fma(PB, o2, e2), v4 = f2fma(-PB, o2, e2), v5 = f2fma(PP2, T[1], f2fma(-PS2, T[3], T[5]));
+            *reinterpret_cast<float4 *>(vr + 0 * FI_VPP) = make_float4(v0.x, v0.y, v1.x, v1.y);
+            *reinterpret_cast<float4 *>(vr + 1 * FI_VPP) = make_float4(v2.x, v2.y, v3.x, v3.y);
+            *reinterpret_cast<float4 *>(vr + 2 * FI_VPP) = make_float4(v4.x, v4.y, v5.x, v5.y);
+        };
+        float2 Ta[6], Tb[6];
+        if (th == 0) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const float2 e = f2fma(-PB2, d(2, c), d(4, c)), o = f2fma(-PB2, d(1, c), d(3, c));
+                Ta[c] = f2fma(PA, o, e);
+                Tb[c] = f2fma(-PA, o, e);
+            }
+            row_out(Ta, 1);
+            row_out(Tb, 2);
+#pragma unroll
+            for (int c = 0; c < 6; c++) Ta[c] = f2fma(PP2, d(0, c), f2fma(-PS2, d(2, c), d(4, c)));
+            row_out(Ta, 0);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const float2 e = f2fma(-PA2, d(2, c), d(4, c)), o = f2fma(-PA2, d(1, c), d(3, c));
+                Ta[c] = f2fma(PB, o, e);
+                Tb[c] = f2fma(-PB, o, e);
+            }
+            row_out(Ta, 3);
+            row_out(Tb, 4);
+#pragma unroll
+            for (int c = 0; c < 6; c++) Tb[c] = f2fma(PP2, d(1, c), f2fma(-PS2, d(3, c), d(5, c)));
+            row_out(Tb, 5);
+        }
+    };
+    constexpr int AHEAD = F4_RING - 1;
+    const float *asrc = V + (lk * FI_TILES + 16 * mb + li) * 4;
+    floatx4 acc[36];
+    // one convolution: chunk 0 is in xr on entry (load_raw(0) issued by the caller); acc is zeroed here
+    auto conv_pass = [&](const float *wfrag, int nch, auto act_c) {
+        const int last = nch - 1;
+        const float4 *__restrict__ wp = reinterpret_cast<const float4 *>(wfrag) + (int64_t)nw * nch * 18 * 64;
+        float4 bq[F4_RING];
+#pragma unroll
+        for (int q = 0; q < 36; q++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[q][r] = 0.f;
+        store_raw(0, act_c);
+        F4_LDS_BARRIER();
+#pragma unroll 1
+        for (int chunk = 0; chunk < nch; chunk++) {
+            transform();
+#pragma unroll
+            for (int a = 0; a < AHEAD; a++) bq[a] = wp[a * 64 + lane];
+            load_raw(min(chunk + 1, last));
+            F4_LDS_BARRIER();
+            float4 aq[2];
+            aq[0] = *reinterpret_cast<const float4 *>(asrc);
+#pragma unroll
+            for (int pp = 0; pp < 18; pp++) {
+                if (pp + AHEAD < 18) bq[(pp + AHEAD) % F4_RING] = wp[(pp + AHEAD) * 64 + lane];
+                if (pp + 1 < 18) aq[(pp + 1) & 1] = *reinterpret_cast<const float4 *>(asrc + (pp + 1) * FI_VPP);
+                const float4 aa = aq[pp & 1];
+                const float4 b = bq[pp % F4_RING];
+                acc[2 * pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.x, b.x, acc[2 * pp], 0, 0, 0);
+                acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.z, b.z, acc[2 * pp + 1], 0, 0, 0);
+                acc[2 * pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.y, b.y, acc[2 * pp], 0, 0, 0);
+                acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.w, b.w, acc[2 * pp + 1], 0, 0, 0);
+            }
+            wp += 18 * 64;
+            if (chunk < last) store_raw(chunk + 1, act_c);
+            F4_LDS_BARRIER();
+        }
+    };
+    // Y = A^T M A of tile r of this lane (the 2 + 2-wave shape's expressions)
+    auto out_tile = [&](int r, float (&Yt)[16]) {
+        float Z[4][6];
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+            const float m0 = acc[0 * 6 + b][r], m1 = acc[1 * 6 + b][r], m2 = acc[2 * 6 + b][r];
+            const float m3 = acc[3 * 6 + b][r], m4 = acc[4 * 6 + b][r], m5 = acc[5 * 6 + b][r];
+            const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+            Z[0][b] = m0 + s12 + s34;
+            Z[1][b] = fmaf(PB, d34, PA * d12);
+            Z[2][b] = fmaf(PB2, s34, PA2 * s12);
+            Z[3][b] = fmaf(PB3, d34, PA3 * d12) + m5;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float s12 = Z[i][1] + Z[i][2], d12 = Z[i][1] - Z[i][2], s34 = Z[i][3] + Z[i][4], d34 = Z[i][3] - Z[i][4];
+            Yt[i * 4 + 0] = Z[i][0] + s12 + s34;
+            Yt[i * 4 + 1] = fmaf(PB, d34, PA * d12);
+            Yt[i * 4 + 2] = fmaf(PB2, s34, PA2 * s12);
+            Yt[i * 4 + 3] = fmaf(PB3, d34, PA3 * d12) + Z[i][5];
+        }
+    };
+    // the quadrant's statistics partial from the per-lane shifted sums (the convolution kernels' epilogue): lanes lk == 0 hold it
+    auto quadrant_stats = [&](float K, float s1, float s2, float &mean, float &M2) {
+        mean = K + s1 * (1.f / 64.f);
+        M2 = fmaxf(s2 - s1 * s1 * (1.f / 64.f), 0.f);
+        float na = 64.f;
+#pragma unroll
+        for (int sft = 16; sft <= 32; sft <<= 1) {
+            const float om = __shfl_xor(mean, sft), oM2 = __shfl_xor(M2, sft);
+            const float lo_m = (lane & sft) ? om : mean, hi_m = (lane & sft) ? mean : om;
+            const float lo_M = (lane & sft) ? oM2 : M2, hi_M = (lane & sft) ? M2 : oM2;
+            const float dd = hi_m - lo_m;
+            mean = lo_m + dd * 0.5f;
+            M2 = lo_M + hi_M + dd * dd * (na * 0.5f);
+            na *= 2.f;
+        }
+    };
+    const int ty0 = 4 * (mb >> 1), tx0 = 4 * (mb & 1);
+    const int64_t pix0 = ((int64_t)img * H + 4 * ty0) * W + 4 * tx0;      // wave-uniform: this quadrant's first pixel
+
+    // ================= pass 1: h = conv1(silu(GN1(x)))
+    const int Cin = p.C0 + p.C1;
+    load_raw(0);
+    if (p.st0) {
+        gn_coeffs_from_stats_image(p.st0 + (int64_t)img * p.nt0 * p.C0, p.st1 ? p.st1 + (int64_t)img * p.nt1 * p.C1 : nullptr, p.C0, p.C1, p.nt0,
+                                   p.nt1, H * W, Cin < 32 ? Cin : 32, p.gn1_w, p.gn1_b, nullptr, gsh, Cf, Cf + 128, 1e-5f, tid, FI_NT,
+                                   [] { F4_LDS_BARRIER(); });
+    } else {
+        for (int i = tid; i < 2 * Cin; i += FI_NT) {
+            if (i < Cin) Cf[i] = p.coefA1[(int64_t)img * Cin + i];
+            else Cf[128 + (i - Cin)] = p.coefB1[(int64_t)img * Cin + (i - Cin)];
+        }
+    }
+    F4_LDS_BARRIER();
+    conv_pass(p.w1, Cin / F4_KC, std::integral_constant<bool, true>());
+    DLPM_PHASE(p, 8);
+
+    // ================= between: h + bias (registers), its statistics, GroupNorm-2 with scale-shift, a = silu(..) -> scratch image
+    {
+        int chv = ch;
+        asm volatile("" : "+v"(chv));      // (opaque: the section's addresses must not be formed -- and kept -- in front of the chunk loop)
+        const float bias_v = p.b1[chv];
+        float hv[4][16];
+        float K = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float Yt[16];
+            out_tile(r, Yt);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const float v = Yt[k] + bias_v;
+                if (r == 0 && k == 0) K = v;
+                const float dd = v - K;
+                s1 += dd;
+                s2 = fmaf(dd, dd, s2);
+                hv[r][k] = v;
+            }
+        }
+        float mean, M2;
+        quadrant_stats(K, s1, s2, mean, M2);
+        if (lk == 0) part[mb * CO + chv] = make_float2(mean, M2);
+        F4_LDS_BARRIER();
+        gn_coeffs_from_stats_image(part, nullptr, CO, 0, 4, 1, H * W, 32, p.gn2_w, p.gn2_b, p.emb + (int64_t)img * p.emb_stride + p.emb_off, gsh, Cf,
+                                   Cf + 128, 1e-5f, tid, FI_NT, [] { F4_LDS_BARRIER(); });
+        F4_LDS_BARRIER();
+        const float a2 = Cf[chv], b2 = Cf[128 + chv];
+        float *hb = p.hbuf + pix0 * CO;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int tile = 4 * lk + r;
+            const int tpix = (4 * (tile >> 2)) * W + 4 * (tile & 3);
+#pragma unroll
+            for (int k = 0; k < 16; k++) hb[(tpix + (k >> 2) * W + (k & 3)) * CO + chv] = silu_f(fmaf(hv[r][k], a2, b2));
+        }
+    }
+    // the scratch image is read back by other waves of THIS workgroup only: __syncthreads() is a workgroup-scope release / acquire over global
+    // memory as well (s_waitcnt vmcnt(0) + barrier; the CU's L1 is write-through and shared by the workgroup).  An agent-scope
+    // __threadfence() here writes the XCD's whole dirty L2 back, with 256 workgroups doing so at once: 190 us per launch instead of 70.
+    __syncthreads();
+
+    // ================= pass 2: out = conv2(a) + bias + skip
+    s0 = p.hbuf; s1 = nullptr; c0 = CO; c1 = 0;
+    load_raw(0);
+    conv_pass(p.w2, CO / F4_KC, std::integral_constant<bool, false>());
+    DLPM_PHASE(p, 9);
+    {
+        int chv = ch, lkv = lk;
+        asm volatile("" : "+v"(chv), "+v"(lkv));      // (opaque: else the 64 pixel offsets of the section above stay live -- in scratch -- across pass 2)
+        const float bias_v = p.b2[chv];
+        float *__restrict__ out_blk = p.out + pix0 * CO;
+        const float *__restrict__ res_blk = p.res + pix0 * CO;
+        const bool do_stats = p.stats_out != nullptr;
+        float K = 0.f, s1 = 0.f, s2 = 0.f;
+        // the residual of tile r + 1 is requested before tile r's output transform (all four at once, as the convolution kernels
+        // do, is 64 registers beside the 36 accumulators: scratch memory here)
+        float rs[2][16];
+        auto load_res = [&](int rr, float (&dst)[16]) {
+            const int t2 = 4 * lkv + rr;
+            const int tp2 = (4 * (t2 >> 2)) * W + 4 * (t2 & 3);
+#pragma unroll
+            for (int k = 0; k < 16; k++) dst[k] = res_blk[(tp2 + (k >> 2) * W + (k & 3)) * CO + chv];
+        };
+        load_res(0, rs[0]);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int tile = 4 * lkv + r;
+            const int tpix = (4 * (tile >> 2)) * W + 4 * (tile & 3);
+            if (r + 1 < 4) load_res(r + 1, rs[(r + 1) & 1]);
+            float Yt[16];
+            out_tile(r, Yt);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                float v = Yt[k] + bias_v;
+                v += rs[r & 1][k];
+                if (do_stats) {
+                    if (r == 0 && k == 0) K = v;
+                    const float dd = v - K;
+                    s1 += dd;
+                    s2 = fmaf(dd, dd, s2);
+                }
+                out_blk[(tpix + (k >> 2) * W + (k & 3)) * CO + chv] = v;
+            }
+        }
+        if (do_stats) {
+            float mean, M2;
+            quadrant_stats(K, s1, s2, mean, M2);
+            if (lkv == 0) p.stats_out[((int64_t)img * 4 + mb) * CO + chv] = make_float2(mean, M2);
+        }
+    }
+    DLPM_PHASE(p, 10);
+    DLPM_PHASE_FLUSH(p, 8);
+#ifdef DLPM_PHASE_TIMING
+    if (p.phase && tid == 0) atomicAdd(p.phase + 11, 1ull);
+#endif
+}
+
 // OIHW (3x3) -> U = G g G^T (6x6 per filter) in the kernel's fragment order Wf[ntile][wave][phase][18][lane][4]:
 // lane = lk*16 + li holds, for position pair pp and e = 0..3, U_pos[cin = phase*8 + 2 lk + (e & 1)][cout = ntile*128 + wave*16 + li]
 // with pos = 2 pp + (e >> 1).  Computed in double, rounded once.
@@ -1253,6 +1573,34 @@ int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
     size_t loop_b = (size_t)(2 * F4_VBUF + 2 * F4_RAWBUF + 2 * F4_CFS) * sizeof(float);
     if (wino4_vsplit() && loop_b < (size_t)8 * 4 * 16 * 64 * sizeof(float)) loop_b = (size_t)8 * 4 * 16 * 64 * sizeof(float);   // the epilogue's exchange buffer
     fn<<<(unsigned)(mblocks * (c.Cout / F4_NQ)), F4_NT, loop_b, st>>>(c, bh, bw, nimg);
+    DLPM_LAUNCH_CHECK();
+    return DLPM_OK;
+}
+
+// DLPM_RES_IMG=0 (A/B runs): the 32-channel 32x32 ResBlocks as separate launches (conv, GroupNorm coefficients, conv) as before -- same bits
+bool res_img_ok(const ResImgLaunch &r) {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DLPM_RES_IMG"); v = e ? atoi(e) : 1; }
+    const int Cin = r.C0 + r.C1;
+    return v != 0 && wino4_enabled() && r.w1 && r.w2 && r.res && r.hbuf && Cin % F4_KC == 0 && r.C0 % F4_KC == 0 && Cin <= 128 && Cin >= 32 &&
+           (r.st0 ? (r.C1 == 0 || r.st1 != nullptr) : (r.coefA1 && r.coefB1));
+}
+
+int launch_resblock_img(const ResImgLaunch &r, hipStream_t st) {
+    if (!res_img_ok(r)) {
+        set_error("launch_resblock_img: unsupported block");
+        return DLPM_ERR_UNSUPPORTED;
+    }
+    const int Cin = r.C0 + r.C1;
+    const double M = (double)r.B * 1024;
+    ProfScope ps("resblock_img:H32", 2.0 * M * 32 * 9.0 * (Cin + 32), 4.0 * (M * (Cin + 32 + 32) + 32 * 9.0 * (Cin + 32)), st);
+#ifdef DLPM_PHASE_TIMING
+    const_cast<ResImgLaunch &>(r).phase = phase_buffer();
+#endif
+    const int e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_resblock_wino4_img), 160 * 1024);
+    if (e != DLPM_OK) return e;
+    const size_t lds = (size_t)(FI_VBUF + FI_RAWBUF + 256 + 512 + 256 + FI_QN * FI_NT) * sizeof(float);
+    k_resblock_wino4_img<<<(unsigned)r.B, FI_NT, lds, st>>>(r);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }

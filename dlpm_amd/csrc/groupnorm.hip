@@ -11,6 +11,7 @@
 // slices: a one-pass shifted-data kernel for channel counts divisible by 4 (every shipped config),
 // a two-pass scalar kernel otherwise.
 #include "conv.h"
+#include "gn_stats.h"
 
 namespace dlpm {
 namespace {
@@ -182,53 +183,12 @@ __global__ void __launch_bounds__(256) k_gn_coeffs_stats(const float2 *__restric
                                                          int64_t ss_stride, int64_t ss_offset, float *__restrict__ coefA,
                                                          float *__restrict__ coefB, float eps) {
     extern __shared__ float sh[];
-    const int C = C0 + C1, cg = C / G;
-    float *cmean = sh, *cm2 = sh + C, *mean = cm2 + C, *rstd = mean + G;
-    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-    for (int c = tid; c < C; c += nthr) {
-        const int nt = (c < C0) ? nt0 : nt1;
-        const float npt = (float)(HW / nt);  // pixels per tile
-        const float2 *sp = (c < C0) ? st0 + (int64_t)b * nt * C0 + c : st1 + (int64_t)b * nt * C1 + (c - C0);
-        const int ld = (c < C0) ? C0 : C1;
-        float m = sp[0].x, M2 = sp[0].y, na = npt;
-        for (int k = 1; k < nt; k++) {
-            const float2 q = sp[(int64_t)k * ld];
-            const float d = q.x - m, N = na + npt;
-            m += d * (npt / N);
-            M2 += q.y + d * d * (na * npt / N);
-            na = N;
-        }
-        cmean[c] = m;
-        cm2[c] = M2;
-    }
-    __syncthreads();
-    const float fn = (float)HW;
-    for (int g = tid; g < G; g += nthr) {
-        float m = 0.f;
-        for (int c = g * cg; c < (g + 1) * cg; c++) m += cmean[c];
-        m /= (float)cg;
-        float M2 = 0.f;
-        for (int c = g * cg; c < (g + 1) * cg; c++) {
-            const float d = cmean[c] - m;
-            M2 += cm2[c] + fn * d * d;
-        }
-        mean[g] = m;
-        rstd[g] = 1.0f / sqrtf(M2 / (fn * (float)cg) + eps);
-    }
-    __syncthreads();
-    for (int c = tid; c < C; c += nthr) {
-        const int g = c / cg;
-        float a = rstd[g] * gamma[c];
-        float bb = beta[c] - mean[g] * a;
-        if (ss) {
-            const float sc = 1.0f + ss[(int64_t)b * ss_stride + ss_offset + c];
-            const float sft = ss[(int64_t)b * ss_stride + ss_offset + C + c];
-            a = a * sc;
-            bb = fmaf(bb, sc, sft);
-        }
-        coefA[(int64_t)b * C + c] = a;
-        coefB[(int64_t)b * C + c] = bb;
-    }
+    const int C = C0 + C1;
+    const int b = blockIdx.x;
+    // (the arithmetic lives in gn_stats.h: the whole-image ResBlock kernel runs the same function inside its workgroups)
+    gn_coeffs_from_stats_image(st0 + (int64_t)b * nt0 * C0, st1 ? st1 + (int64_t)b * nt1 * C1 : nullptr, C0, C1, nt0, nt1, HW, G, gamma, beta,
+                               ss ? ss + (int64_t)b * ss_stride + ss_offset : nullptr, sh, coefA + (int64_t)b * C, coefB + (int64_t)b * C, eps,
+                               (int)threadIdx.x, (int)blockDim.x, [] { __syncthreads(); });
 }
 
 }  // namespace

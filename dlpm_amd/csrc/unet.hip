@@ -452,6 +452,49 @@ int run_res(Ctx &cx, const Layer &L, Tensor4 x0, Tensor4 x1, Tensor4 *out) {
             return launch_resblock_small(r, cx.st);
         }
     }
+    if (u->gen == DLPM_CONV_AUTO && Co == 32 && H == 32 && W == 32 && L.c1.w_wino4 && L.c2.w_wino4) {
+        // 32 channels on 32x32 images: the whole block in ONE launch, one workgroup per image (conv_wino4.hip: k_resblock_wino4_img) -- the
+        // bits of the separate launches below (a function of the layer and the policy only).  GroupNorm-1 runs inside the kernel when both
+        // sources carry statistics; the 1x1 skip convolution of the concat blocks stays a launch of its own.
+        ResImgLaunch r;
+        r.x0 = x0.p; r.x1 = x1.p; r.C0 = C0; r.C1 = C1; r.B = B;
+        const bool from_stats = x0.stats && (C1 == 0 || x1.stats);
+        r.w1 = L.c1.w_wino4; r.w2 = L.c2.w_wino4;
+        float *cA1 = from_stats ? nullptr : cx.ws.alloc((int64_t)B * Cin), *cB1 = from_stats ? nullptr : cx.ws.alloc((int64_t)B * Cin);
+        float *sk = L.has_skip ? cx.ws.alloc((int64_t)B * HW * Co) : nullptr;
+        float *hb = cx.ws.alloc((int64_t)B * HW * Co);
+        float *o = cx.ws.alloc((int64_t)B * HW * Co);
+        r.hbuf = hb; r.res = L.has_skip ? sk : x0.p;
+        if (from_stats) {
+            r.st0 = x0.stats; r.nt0 = HW / x0.stats_px;
+            if (C1) { r.st1 = x1.stats; r.nt1 = HW / x1.stats_px; }
+        } else {
+            r.coefA1 = cA1; r.coefB1 = cB1;
+        }
+        if ((L.has_skip || C1 == 0) && res_img_ok(r)) {
+            out->p = o; out->C = Co; out->H = H; out->W = W;
+            plan_stats(cx.u, cx.ws, *out, L.c2, B, Co, 1, 0);
+            auto done = [&]() { cx.ws.release(cA1); cx.ws.release(cB1); cx.ws.release(sk); cx.ws.release(hb); };
+            if (cx.dry()) { done(); return DLPM_OK; }
+            if (!from_stats)
+                TRY(gn_any(x0, x1, B, Cin < 32 ? Cin : 32, u->params[L.p_gn1_w].dev, u->params[L.p_gn1_b].dev, nullptr, 0, 0, cA1, cB1, cx.st));
+            if (L.has_skip) {
+                ConvLaunch s;
+                s.src0 = x0.p; s.src1 = x1.p; s.C0 = C0; s.C1 = C1; s.B = B; s.Hin = s.Hout = H; s.Win = s.Wout = W;
+                s.bias = u->params[L.skip.p_b].dev; s.out = sk;
+                TRY(run_conv(u, L.skip, s, cx.st));
+            }
+            r.gn1_w = u->params[L.p_gn1_w].dev; r.gn1_b = u->params[L.p_gn1_b].dev;
+            r.gn2_w = u->params[L.p_gn2_w].dev; r.gn2_b = u->params[L.p_gn2_b].dev;
+            r.b1 = u->params[L.c1.p_b].dev; r.b2 = u->params[L.c2.p_b].dev;
+            r.emb = cx.embout; r.emb_stride = cx.uniform_t ? 0 : u->emb_total; r.emb_off = L.emb_off;
+            r.out = o; r.stats_out = out->stats;
+            TRY(launch_resblock_img(r, cx.st));
+            done();
+            return DLPM_OK;
+        }
+        cx.ws.release(cA1); cx.ws.release(cB1); cx.ws.release(sk); cx.ws.release(hb); cx.ws.release(o);
+    }
     float *cA1 = cx.ws.alloc((int64_t)B * Cin), *cB1 = cx.ws.alloc((int64_t)B * Cin);
     Tensor4 h1;
     h1.C = Co; h1.H = H; h1.W = W;
@@ -499,7 +542,8 @@ int run_attn(Ctx &cx, const Layer &L, Tensor4 x, Tensor4 *out) {
         AttnSmallLaunch a;
         a.x = x.p; a.C = C; a.heads = u->cfg.num_heads; a.B = B; a.H = x.H; a.W = x.W;
         a.wqkv = L.c1.w_rs; a.wproj = L.c2.w_rs;
-        if (u->gen == DLPM_CONV_AUTO && attn_small_ok(a)) {
+        const bool whole16 = attn16_ok(a);
+        if (u->gen == DLPM_CONV_AUTO && (attn_small_ok(a) || whole16)) {
             *out = x;
             out->p = cx.ws.alloc((int64_t)B * T * C);
             out->stats = reinterpret_cast<float2 *>(cx.ws.alloc((int64_t)2 * B * C));
@@ -508,7 +552,7 @@ int run_attn(Ctx &cx, const Layer &L, Tensor4 x, Tensor4 *out) {
             a.gn_w = u->params[L.p_gn1_w].dev; a.gn_b = u->params[L.p_gn1_b].dev;
             a.bqkv = u->params[L.c1.p_b].dev; a.bproj = u->params[L.c2.p_b].dev;
             a.out = out->p; a.stats_out = out->stats;
-            return launch_attnblock_small(a, cx.st);
+            return whole16 ? launch_attnblock16(a, cx.st) : launch_attnblock_small(a, cx.st);
         }
     }
     float *cA = cx.ws.alloc((int64_t)B * C), *cB = cx.ws.alloc((int64_t)B * C);
@@ -1221,10 +1265,56 @@ extern "C" int dlpm_resblock_small_f32(const dlpm_resblock_args *a, float *scrat
     return launch_resblock_small(r, st);
 }
 
+extern "C" int64_t dlpm_resblock_img_scratch_floats(int64_t B, int32_t Cin) {
+    if (B <= 0 || Cin <= 0) return -1;
+    return wino4_weight_floats(32, Cin) + wino4_weight_floats(32, 32) + 2 * B * Cin + 2 * B * 1024 * 32 + 64;
+}
+
+extern "C" int dlpm_resblock_img_f32(const dlpm_resblock_args *a, float *scratch_dev, int64_t scratch_floats, dlpm_stream_t stream) {
+    DLPM_CHECK_ARG(a && a->x0 && a->conv1_w && a->conv2_w && a->ss && a->out && scratch_dev, "dlpm_resblock_img_f32: null argument");
+    DLPM_CHECK_ARG(a->gn1_w && a->gn1_b && a->gn2_w && a->gn2_b && a->conv1_b && a->conv2_b, "dlpm_resblock_img_f32: null GroupNorm / bias parameter");
+    DLPM_CHECK_ARG(a->B > 0 && a->H == 32 && a->W == 32, "dlpm_resblock_img_f32: B %d, %d x %d images (32x32)", a->B, a->H, a->W);
+    DLPM_CHECK_ARG((a->C1 == 0) == (a->x1 == nullptr), "dlpm_resblock_img_f32: x1/C1 mismatch");
+    const int Cin = a->C0 + a->C1;
+    DLPM_CHECK_ARG(Cin >= 32 && Cin <= 128 && Cin % 8 == 0 && a->C0 % 8 == 0, "dlpm_resblock_img_f32: %d + %d input channels", a->C0, a->C1);
+    DLPM_CHECK_ARG((Cin == 32) == (a->skip_w == nullptr) && (!a->skip_w || a->skip_b), "dlpm_resblock_img_f32: skip_w / skip_b (required unless C0 + C1 = 32)");
+    DLPM_CHECK_ARG(scratch_floats >= dlpm_resblock_img_scratch_floats(a->B, Cin), "dlpm_resblock_img_f32: scratch of %lld floats, need %lld",
+                   (long long)scratch_floats, (long long)dlpm_resblock_img_scratch_floats(a->B, Cin));
+    hipStream_t st = as_stream(stream);
+    float *w1 = scratch_dev, *w2 = w1 + wino4_weight_floats(32, Cin), *cA = w2 + wino4_weight_floats(32, 32), *cB = cA + (int64_t)a->B * Cin;
+    float *hb = cB + (int64_t)a->B * Cin, *sk = hb + (int64_t)a->B * 1024 * 32;
+    hb += (64 - ((hb - scratch_dev) & 63)) & 63;          // (16-byte rows: float4 staging loads)
+    sk = hb + (int64_t)a->B * 1024 * 32;
+    TRY(relayout_weight_wino4(a->conv1_w, w1, 32, Cin, st));
+    TRY(relayout_weight_wino4(a->conv2_w, w2, 32, 32, st));
+    TRY(launch_gn_coeffs(a->x0, a->x1, a->C0, a->C1, a->B, 1024, 32, a->gn1_w, a->gn1_b, nullptr, 0, 0, cA, cB, st));
+    ResImgLaunch r;
+    r.x0 = a->x0; r.x1 = a->x1; r.C0 = a->C0; r.C1 = a->C1; r.B = a->B;
+    r.coefA1 = cA; r.coefB1 = cB;
+    r.gn1_w = a->gn1_w; r.gn1_b = a->gn1_b; r.gn2_w = a->gn2_w; r.gn2_b = a->gn2_b;
+    r.w1 = w1; r.b1 = a->conv1_b; r.w2 = w2; r.b2 = a->conv2_b;
+    r.emb = a->ss; r.emb_stride = a->ss_stride; r.emb_off = 0;
+    r.hbuf = hb; r.out = a->out; r.stats_out = reinterpret_cast<float2 *>(a->stats_out);
+    if (a->skip_w) {
+        ConvLaunch s;
+        s.src0 = a->x0; s.src1 = a->x1; s.C0 = a->C0; s.C1 = a->C1; s.B = a->B; s.Hin = s.Hout = 32; s.Win = s.Wout = 32;
+        s.ks = 1; s.Cout = 32; s.w = a->skip_w; s.bias = a->skip_b; s.out = sk; s.gemm = DLPM_GEMM_F32;
+        TRY(launch_conv_igemm(s, st));
+        r.res = sk;
+    } else {
+        r.res = a->x0;
+    }
+    if (!res_img_ok(r)) {
+        set_error("dlpm_resblock_img_f32: the whole-image ResBlock kernel is switched off (DLPM_RES_IMG=0 / DLPM_WINO_F4=0)");
+        return DLPM_ERR_UNSUPPORTED;
+    }
+    return launch_resblock_img(r, st);
+}
+
 extern "C" int dlpm_attnblock_small_f32(const dlpm_attnblock_args *a, float *scratch_dev, int64_t scratch_floats, dlpm_stream_t stream) {
     DLPM_CHECK_ARG(a && a->x && a->qkv_w && a->proj_w && a->out && scratch_dev, "dlpm_attnblock_small_f32: null argument");
     DLPM_CHECK_ARG(a->gn_w && a->gn_b && a->qkv_b && a->proj_b, "dlpm_attnblock_small_f32: null GroupNorm / bias parameter");
-    DLPM_CHECK_ARG(a->B > 0 && a->H == a->W && (a->H == 8 || a->H == 4), "dlpm_attnblock_small_f32: B %d, %d x %d images (8x8 or 4x4)", a->B, a->H, a->W);
+    DLPM_CHECK_ARG(a->B > 0 && a->H == a->W && (a->H == 16 || a->H == 8 || a->H == 4), "dlpm_attnblock_small_f32: B %d, %d x %d images (16x16, 8x8 or 4x4)", a->B, a->H, a->W);
     DLPM_CHECK_ARG(a->C == 64 && a->heads == 4, "dlpm_attnblock_small_f32: 64 channels, 4 heads (got %d, %d)", a->C, a->heads);
     const int64_t nq = (int64_t)192 * 64, np = (int64_t)64 * 64;
     DLPM_CHECK_ARG(scratch_floats >= nq + np, "dlpm_attnblock_small_f32: scratch of %lld floats, need %lld", (long long)scratch_floats,
@@ -1236,7 +1326,7 @@ extern "C" int dlpm_attnblock_small_f32(const dlpm_attnblock_args *a, float *scr
     l.x = a->x; l.C = a->C; l.heads = a->heads; l.B = a->B; l.H = a->H; l.W = a->W;
     l.gn_w = a->gn_w; l.gn_b = a->gn_b; l.wqkv = scratch_dev; l.bqkv = a->qkv_b; l.wproj = scratch_dev + nq; l.bproj = a->proj_b;
     l.out = a->out; l.stats_out = reinterpret_cast<float2 *>(a->stats_out);
-    return launch_attnblock_small(l, st);
+    return a->H == 16 ? launch_attnblock16(l, st) : launch_attnblock_small(l, st);
 }
 
 extern "C" int dlpm_timestep_embedding_f32(const float *t, float *emb, int64_t B, int32_t dim, dlpm_stream_t stream) {

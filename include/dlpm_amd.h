@@ -463,9 +463,18 @@ typedef struct dlpm_resblock_args {
  * scratch_floats >= 64 (C0+C1) 9 + 64 64 9 + 64 (C0+C1). */
 int dlpm_resblock_small_f32(const dlpm_resblock_args *args, float *scratch_dev, int64_t scratch_floats, dlpm_stream_t stream);
 
+/* Round 6: the same block with 32 output channels on 32x32 images (the first level of the MNIST-sized nets) in ONE launch, Winograd F(4x4,3x3)
+ * inside (conv_wino4.hip: k_resblock_wino4_img).  Same argument struct: C0 + C1 in {32, 64, 96} (multiples of 8), H = W = 32, conv1_w [32][C0+C1][3][3],
+ * conv2_w [32][32][3][3], ss rows scale (32) | shift (32), skip_w [32][C0+C1][1][1] required unless C0 + C1 = 32, out NHWC [B,32,32,32],
+ * stats_out optional [B][4][32][2]: (mean, centred sum of squares) per 256-pixel quadrant and channel, the layout the convolution kernels emit.
+ * GroupNorm-1's coefficients are computed from the activations by a launch in front (the UNet plan hands the kernel its producers' statistics instead).
+ * scratch_floats >= dlpm_resblock_img_scratch_floats(B, C0 + C1).  Bit-identical to the separate launches (convolution, coefficients, convolution). */
+int64_t dlpm_resblock_img_scratch_floats(int64_t B, int32_t Cin);
+int dlpm_resblock_img_f32(const dlpm_resblock_args *args, float *scratch_dev, int64_t scratch_floats, dlpm_stream_t stream);
+
 typedef struct dlpm_attnblock_args {
     const float *x;              /* NHWC [B,H,W,64] */
-    int32_t C, heads, B, H, W;   /* C = 64, heads = 4, H = W = 8 or 4 */
+    int32_t C, heads, B, H, W;   /* C = 64, heads = 4, H = W = 16 (round 6: k_attnblock16, one head at a time), 8 or 4 */
     const float *gn_w, *gn_b;    /* norm */
     const float *qkv_w, *qkv_b;  /* qkv: [192][64][1], [192] (head-major channel order, unet.py:224,243-244) */
     const float *proj_w, *proj_b;/* proj_out: [64][64][1], [64] */

@@ -22,6 +22,10 @@ def _shapes_res(cin, emb=128, cout=64):
     return s
 
 
+def _shapes_res_o(cin, cout):
+    return _shapes_res(cin, 128, cout)
+
+
 def _shapes_attn(c=64):
     return {'norm.weight': (c,), 'norm.bias': (c,), 'qkv.weight': (3 * c, c, 1), 'qkv.bias': (3 * c,), 'proj_out.weight': (c, c, 1),
             'proj_out.bias': (c,)}
@@ -46,6 +50,34 @@ def res_state(cin, hs):
 
 def attn_state(hs):
     return _draw(_shapes_attn(), ATTN_KEYS, 500 + hs)
+
+
+# F14 (tests/golden/f14_blocks16.npz): the blocks of the MNIST-sized net's 16x16 / 32x32 levels; inputs from seeds as well
+def attn16_state():
+    return _draw(_shapes_attn(), ATTN_KEYS, 516)
+
+
+def res_fine_state(cin, cout, hs):
+    return _draw(_shapes_res_o(cin, cout), RES_KEYS, 7000 + cin + hs)
+
+
+def seeded_input(shape, seed):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * 1.5 + 0.3
+
+
+def attn16_input():
+    return seeded_input((2, 64, 16, 16), 1416)
+
+
+def res_fine_input(cin, hs, B):
+    return seeded_input((B, cin, hs, hs), 1400 + cin + hs), torch.randn(B, 128, generator=torch.Generator().manual_seed(1500 + cin + hs))
+
+
+def input_digest(*ts):
+    h = hashlib.sha256()
+    for t in ts:
+        h.update(t.numpy().tobytes())
+    return h.digest().hex()
 
 
 def digest(sd):

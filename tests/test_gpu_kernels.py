@@ -950,6 +950,41 @@ def test_conv_winograd_f4_whole_image_is_bit_identical():
     assert len(out['1']) == 64 and out['1'] == out['0'], out
 
 
+_MNIST_NET_DIGEST_SCRIPT = r"""
+import hashlib, sys, torch
+sys.path.insert(0, sys.argv[1])
+import dlpm_amd
+p = dlpm_amd.load_config('mnist')
+torch.manual_seed(1234)
+net = dlpm_amd.rerandomize_(dlpm_amd.init_model_by_parameter(p), 4321).to('cuda')
+g = torch.Generator().manual_seed(5)
+x = torch.randn(5, 1, 32, 32, generator=g).cuda()
+t = torch.rand(5, generator=g).cuda()
+h = hashlib.sha256()
+h.update(net(x, t).cpu().numpy().tobytes())
+h.update(net(x[1:3], t[1:3]).cpu().numpy().tobytes())
+print(h.hexdigest())
+"""
+
+
+def test_resblock_whole_image_is_bit_identical_to_the_separate_launches():
+    """Round 6: k_resblock_wino4_img (a whole 32-channel ResBlock of a 32x32 image in one launch: GroupNorm-1 from the producers'
+    statistics, conv1, GroupNorm-2 with scale-shift inside the workgroup, conv2 over the activated intermediate, skip, statistics)
+    evaluates the expressions of the launches it replaces (conv -> k_gn_coeffs_stats -> conv; gn_stats.h is shared): the whole
+    MNIST-sized UNet forward -- five such blocks, identity and 1x1-convolution skips, concat inputs, sources with 1 and 4 statistics
+    partials -- must come out bit for bit the same with DLPM_RES_IMG=1 (default) and =0.  Two child processes, one digest each."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for v in ('1', '0'):
+        e = dict(os.environ, DLPM_RES_IMG=v)
+        r = subprocess.run([sys.executable, '-c', _MNIST_NET_DIGEST_SCRIPT, root], env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[v] = r.stdout.strip().splitlines()[-1]
+    assert len(out['1']) == 64 and out['1'] == out['0'], out
+
+
 SPLIT3_CASES = [
     # name, B, C0, C1, H, Cout, stride, coef+silu, res
     ('down_16_to_8', 3, 128, 0, 16, 128, 2, False, False),
@@ -1058,6 +1093,115 @@ def test_fused_small_resblock_vs_reference(cin, hs):
     big = torch.cat([x[2:3], x, x[0:1]])
     gb, _ = run(big, torch.cat([ss[2:3], ss, ss[0:1]]))
     assert torch.equal(gb[1:4], got) and torch.equal(gb[0], got[2]) and torch.equal(gb[4], got[0])
+
+
+@pytest.mark.parametrize('cin', [32, 64, 96])
+def test_whole_image_resblock_vs_reference(cin):
+    """Round 6: k_resblock_wino4_img (a whole 32-channel ResBlock of a 32x32 image in one launch, Winograd F(4x4,3x3) inside) against the
+    reference's ResBlock (unet.py:105-196) on the F14 fixtures -- 32 -> 32 with the identity skip, 64 (= concat 32 | 32) and 96 (= 64 | 32)
+    -> 32 with the 1x1 skip convolution -- the quadrant statistics it emits, and bit-independence of the batch."""
+    import ctypes as C
+    import small_block_weights as sbw
+    from oracle import nets
+    f = golden('f14_blocks16')
+    tag = 'res_c%d_o32_h32_' % cin
+    sd = sbw.res_fine_state(cin, 32, 32)
+    assert sbw.digest(sd) == bytes(f[tag + 'digest']).hex()
+    x, emb = sbw.res_fine_input(cin, 32, 1)
+    assert sbw.input_digest(x, emb) == bytes(f[tag + 'xdigest']).hex()
+    want = f[tag + 'y']
+    ss = torch.nn.functional.linear(nets.silu(emb), sd['emb_layers.1.weight'], sd['emb_layers.1.bias'])   # the block's emb_layers (host)
+    L, st = _lib.lib(), _lib.stream_ptr()
+    c0 = {32: 32, 64: 32, 96: 64}[cin]
+
+    def run(xb, ssb):
+        B = xb.shape[0]
+        xh = _dev(nhwc(xb))
+        keep = [xh]
+        a = _lib.ResBlockArgs()
+        if cin > 32:       # the output blocks' virtual concat
+            x0, x1 = _dev(xh[..., :c0]), _dev(xh[..., c0:])
+            keep += [x0, x1]
+            a.x0, a.x1, a.C0, a.C1 = x0.data_ptr(), x1.data_ptr(), c0, cin - c0
+        else:
+            a.x0, a.x1, a.C0, a.C1 = xh.data_ptr(), None, 32, 0
+        a.B, a.H, a.W = B, 32, 32
+        w = {k: _dev(v) for k, v in sd.items()}
+        a.gn1_w, a.gn1_b = w['in_layers.0.weight'].data_ptr(), w['in_layers.0.bias'].data_ptr()
+        a.conv1_w, a.conv1_b = w['in_layers.2.weight'].data_ptr(), w['in_layers.2.bias'].data_ptr()
+        ssd = _dev(ssb)
+        a.ss, a.ss_stride = ssd.data_ptr(), 64
+        a.gn2_w, a.gn2_b = w['out_layers.0.weight'].data_ptr(), w['out_layers.0.bias'].data_ptr()
+        a.conv2_w, a.conv2_b = w['out_layers.3.weight'].data_ptr(), w['out_layers.3.bias'].data_ptr()
+        if cin > 32:
+            a.skip_w, a.skip_b = w['skip_connection.weight'].data_ptr(), w['skip_connection.bias'].data_ptr()
+        out = torch.empty(B, 32, 32, 32, device=DEV)
+        stats = torch.empty(B, 4, 32, 2, device=DEV)
+        a.out, a.stats_out = out.data_ptr(), stats.data_ptr()
+        n = L.dlpm_resblock_img_scratch_floats(B, cin)
+        scratch = torch.empty(n, device=DEV)
+        _lib.check(L.dlpm_resblock_img_f32(C.byref(a), scratch.data_ptr(), n, st))
+        torch.cuda.synchronize()
+        return nchw(out).cpu(), stats.cpu()
+
+    got, stats = run(x, ss)
+    err = np.abs(got.numpy() - want).max()
+    print('whole-image ResBlock %d -> 32 at 32x32: max |hip - reference| = %.3g (|y| max %.3g)' % (cin, err, np.abs(want).max()))
+    assert err < 2e-5 * max(1.0, np.abs(want).max())
+    # statistics partials: (mean, centred sum of squares) of each 16x16 quadrant (row-major) per channel
+    g64 = got.double()
+    for q in range(4):
+        blk = g64[:, :, 16 * (q // 2):16 * (q // 2) + 16, 16 * (q % 2):16 * (q % 2) + 16]
+        assert (stats[:, q, :, 0].double() - blk.mean(dim=(2, 3))).abs().max() < 1e-5
+        m2 = ((blk - blk.mean(dim=(2, 3), keepdim=True)) ** 2).sum(dim=(2, 3))
+        assert ((stats[:, q, :, 1].double() - m2).abs() / (1 + m2)).max() < 1e-5
+    # a sample's bits do not depend on the batch it travels in (other images: the same one scaled, with its own emb row)
+    big = torch.cat([0.5 * x, x, 2.0 * x])
+    gb, _ = run(big, torch.cat([ss + 0.1, ss, ss - 0.1]))
+    assert torch.equal(gb[1:2], got)
+
+
+def test_fused_attention_block_16x16_vs_reference():
+    """Round 6: k_attnblock16 (GroupNorm -> per head: qkv, softmax(q k^T) v, proj accumulated in registers -> + x, ONE launch per 16x16
+    image) against the reference's AttentionBlock (unet.py:199-250) at T = 256 (tests/golden/f14_blocks16.npz), its per-image output
+    statistics, and bit-independence of the batch."""
+    import ctypes as C
+    import small_block_weights as sbw
+    f = golden('f14_blocks16')
+    sd = sbw.attn16_state()
+    assert sbw.digest(sd) == bytes(f['attn_h16_digest']).hex()
+    x, want = sbw.attn16_input(), f['attn_h16_y']
+    assert sbw.input_digest(x) == bytes(f['attn_h16_xdigest']).hex()
+    L, st = _lib.lib(), _lib.stream_ptr()
+
+    def run(xb, with_stats=True):
+        B = xb.shape[0]
+        xh = _dev(nhwc(xb))
+        w = {k: _dev(v) for k, v in sd.items()}
+        a = _lib.AttnBlockArgs()
+        a.x, a.C, a.heads, a.B, a.H, a.W = xh.data_ptr(), 64, 4, B, 16, 16
+        a.gn_w, a.gn_b = w['norm.weight'].data_ptr(), w['norm.bias'].data_ptr()
+        a.qkv_w, a.qkv_b = w['qkv.weight'].data_ptr(), w['qkv.bias'].data_ptr()
+        a.proj_w, a.proj_b = w['proj_out.weight'].data_ptr(), w['proj_out.bias'].data_ptr()
+        out = torch.empty(B, 16, 16, 64, device=DEV)
+        stats = torch.zeros(B, 64, 2, device=DEV)
+        a.out, a.stats_out = out.data_ptr(), stats.data_ptr() if with_stats else None
+        n = 192 * 64 + 64 * 64
+        scratch = torch.empty(n, device=DEV)
+        _lib.check(L.dlpm_attnblock_small_f32(C.byref(a), scratch.data_ptr(), n, st))
+        torch.cuda.synchronize()
+        return nchw(out).cpu(), stats.cpu()
+
+    got, stats = run(x)
+    err = np.abs(got.numpy() - want).max()
+    print('fused AttentionBlock at 16x16: max |hip - reference| = %.3g (|y| max %.3g)' % (err, np.abs(want).max()))
+    assert err < 2e-5 * max(1.0, np.abs(want).max())
+    g64 = got.double()
+    assert (stats[..., 0].double() - g64.mean(dim=(2, 3))).abs().max() < 1e-5
+    m2 = ((g64 - g64.mean(dim=(2, 3), keepdim=True)) ** 2).sum(dim=(2, 3))
+    assert ((stats[..., 1].double() - m2).abs() / (1 + m2)).max() < 1e-5
+    gb, _ = run(torch.cat([x[1:2], x, x[0:1]]), with_stats=False)
+    assert torch.equal(gb[1:3], got) and torch.equal(gb[0], got[1]) and torch.equal(gb[3], got[0])
 
 
 @pytest.mark.parametrize('hs', [8, 4])

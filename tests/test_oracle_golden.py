@@ -433,3 +433,30 @@ def test_small_attention_block_oracle_vs_reference(hs):
     with torch.no_grad():
         y = nets.attention_block(sd, '', T_(f[tag + 'x']), 4)
     assert np.abs(y.numpy() - f[tag + 'y']).max() < 2e-5 * max(1.0, np.abs(f[tag + 'y']).max())
+
+
+# ---------------------------------------------------------------- F14: the blocks of the 16x16 / 32x32 levels (round 6's fused kernels)
+def test_attention_block_16x16_oracle_vs_reference():
+    import small_block_weights as sbw
+    f = golden('f14_blocks16')
+    sd = sbw.attn16_state()
+    assert sbw.digest(sd) == bytes(f['attn_h16_digest']).hex()
+    x = sbw.attn16_input()
+    assert sbw.input_digest(x) == bytes(f['attn_h16_xdigest']).hex()
+    with torch.no_grad():
+        y = nets.attention_block(sd, '', x, 4)
+    assert np.abs(y.numpy() - f['attn_h16_y']).max() < 2e-5 * max(1.0, np.abs(f['attn_h16_y']).max())
+
+
+@pytest.mark.parametrize('cin,cout,hs,B', [(64, 64, 16, 2), (128, 64, 16, 2), (96, 64, 16, 2), (32, 32, 32, 1), (64, 32, 32, 1), (96, 32, 32, 1)])
+def test_fine_level_resblock_oracle_vs_reference(cin, cout, hs, B):
+    import small_block_weights as sbw
+    f = golden('f14_blocks16')
+    tag = 'res_c%d_o%d_h%d_' % (cin, cout, hs)
+    sd = sbw.res_fine_state(cin, cout, hs)
+    assert sbw.digest(sd) == bytes(f[tag + 'digest']).hex()
+    x, emb = sbw.res_fine_input(cin, hs, B)
+    assert sbw.input_digest(x, emb) == bytes(f[tag + 'xdigest']).hex()
+    with torch.no_grad():
+        y = nets.res_block(sd, '', x, emb)
+    assert np.abs(y.numpy() - f[tag + 'y']).max() < 2e-5 * max(1.0, np.abs(f[tag + 'y']).max())

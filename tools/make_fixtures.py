@@ -19,6 +19,7 @@ Fixture families:
   F8 generation manager  clamp + inverse affine                   bem/GenerationManager.py:29-63
   F10 LIM sampler        VPSDE, LIM_sampler sde/ode updates        dlpm/methods/LIM/functions/{sde,sampler}.py
   F13 small blocks       ResBlock / AttentionBlock at the fused kernels' shapes     dlpm/models/unet.py:105-250
+  F14 16x16 / 32x32 blocks  AttentionBlock at T = 256, ResBlocks of the MNIST-sized net's fine levels   dlpm/models/unet.py:105-250
   F12 mean types         p_mean_variance: START_X / Z / PREVIOUS_X, denoised_fn, model_kwargs   GenerativeLevyProcess.py:154-219
   F11 image quantisation PIL's float -> 8-bit path (torchvision absent)  bem/evaluate/EvaluationManager.py:188-190
   F9 checkpoints         TrainingManager.save/load, EMAHelper,    bem/TrainingManager.py:240-285, bem/utils_ema.py,
@@ -776,6 +777,40 @@ def f13_small_blocks():
     save('f13_small_blocks', **arrs)
 
 
+def f14_blocks16():
+    """Round 6: the reference's AttentionBlock (unet.py:199-250) and ResBlock (:105-196, use_scale_shift_norm) at the shapes of the
+    MNIST-sized net's two FINE levels, where round 6 fuses whole blocks: AttentionBlock(64, 4 heads) on 16x16 images (T = 256),
+    ResBlock -> 64 channels on 16x16 (64, 128 = 64 | 64 and 96 = 64 | 32 input channels), ResBlock -> 32 channels on 32x32 (32, 64 = 32 | 32
+    and 96 = 64 | 32).  Inputs come from a seeded generator the tests repeat (the fixture holds their SHA-256, not the arrays);
+    weights from seeded_state (digest stored)."""
+    arrs = {}
+
+    def seeded_input(shape, seed):
+        return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * 1.5 + 0.3
+
+    def xdigest(*ts):
+        h = hashlib.sha256()
+        for t in ts:
+            h.update(t.numpy().tobytes())
+        return np.frombuffer(h.digest(), dtype=np.uint8)
+
+    ab = seeded_state(ref_unet.AttentionBlock(64, num_heads=4).eval(), 516)
+    x = seeded_input((2, 64, 16, 16), 1416)
+    arrs['attn_h16_y'], arrs['attn_h16_xdigest'] = ab(x), xdigest(x)
+    arrs['attn_h16_digest'] = np.frombuffer(bytes.fromhex(weight_digest(ab)), dtype=np.uint8)
+    for cout, hs, cins, B in ((64, 16, (64, 128, 96), 2), (32, 32, (32, 64, 96), 1)):
+        for cin in cins:
+            rb = seeded_state(ref_unet.ResBlock(cin, 128, 0.0, out_channels=cout, dims=2, use_scale_shift_norm=True).eval(), 7000 + cin + hs)
+            x = seeded_input((B, cin, hs, hs), 1400 + cin + hs)
+            emb = torch.randn(B, 128, generator=torch.Generator().manual_seed(1500 + cin + hs))
+            tag = 'res_c%d_o%d_h%d_' % (cin, cout, hs)
+            arrs[tag + 'y'], arrs[tag + 'xdigest'] = rb(x, emb), xdigest(x, emb)
+            arrs[tag + 'digest'] = np.frombuffer(bytes.fromhex(weight_digest(rb)), dtype=np.uint8)
+    with torch.no_grad():
+        arrs = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in arrs.items()}
+    save('f14_blocks16', **arrs)
+
+
 def f8_generation_manager():
     class FakeMethod:
         device = 'cpu'
@@ -965,9 +1000,9 @@ def f10_lim():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f11', 'f1', 'f2', 'f3', 'f4', 'f5', 'f5u', 'f5w', 'f5k', 'f5b', 'f5c', 'f6', 'f7', 'f8', 'f9', 'f10', 'f12', 'f13']
+    which = sys.argv[1:] or ['f11', 'f1', 'f2', 'f3', 'f4', 'f5', 'f5u', 'f5w', 'f5k', 'f5b', 'f5c', 'f6', 'f7', 'f8', 'f9', 'f10', 'f12', 'f13', 'f14']
     table = dict(f12=f12_mean_types, f11=f11_image_quantise, f10=f10_lim, f1=f1_schedule, f2=f2_noise, f3=f3_tables, f4=f4_single_step, f5=f5_trajectories, f5u=f5_unet_trajectory, f5w=f5_wide_unet_trajectory, f5k=f5_unet_trajectories_T1000, f5b=f5_bounded_unet_trajectories, f5c=f5_cifar_teacher_forced,
-                 f6=f6_models, f7=f7_layers, f13=f13_small_blocks, f8=f8_generation_manager, f9=f9_checkpoints)
+                 f6=f6_models, f7=f7_layers, f13=f13_small_blocks, f14=f14_blocks16, f8=f8_generation_manager, f9=f9_checkpoints)
     with torch.no_grad():
         for w in which:
             table[w]()

@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 6, GPU call: the whole-image ResBlock kernel -- parity, A/B on the MNIST step
+O=gpurun_out/r06_run4
+mkdir -p $O
+python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -s -k "whole_image" > $O/pytest_img.log 2>&1; tail -8 $O/pytest_img.log
+python -m pytest tests/test_gpu_models.py -m gpu -x -q > $O/pytest_models.log 2>&1; tail -3 $O/pytest_models.log
+python -m pytest tests/test_gpu_sampler.py -m gpu -x -q -k "mnist or C2" > $O/pytest_sampler_mnist.log 2>&1; tail -3 $O/pytest_sampler_mnist.log
+for i in 1 2; do
+for v in 1 0; do
+DLPM_RES_IMG=$v python bench.py --workload mnist_unet_b256_T1000 --no-cpu-baseline --no-full-trajectory --no-board-sampler --steps 300 > $O/bench_mnist_res${v}_$i.json 2> $O/bench_mnist_res${v}_$i.err
+done; done
+python tools/prof_layers.py --workload mnist --batch 256 > $O/layers_mnist_b256.txt 2>&1
+head -16 $O/layers_mnist_b256.txt; tail -1 $O/layers_mnist_b256.txt
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r06_run4/bench_*.json')):
+    try:
+        j=json.loads([l for l in open(f) if l.startswith('{')][-1])
+        print(f.split('/')[-1], j['ms_per_step'], j['value'])
+    except Exception as e: print(f, 'ERR', e, open(f.replace('.json','.err')).read()[-800:])
+PY
