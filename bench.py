@@ -422,7 +422,7 @@ class NativeRunner:
         self.net = dlpm_amd.rerandomize_(dlpm_amd.init_model_by_parameter(p), 4321)
         # the per-GPU batch of the BASELINE configuration is a declared property of the workload (the same on every rank and
         # for every chunk), so the dispatch policy may weigh grid occupancy for it (dlpm_unet_set_conv_policy)
-        self.net.set_conv_policy(args.conv, args.dispatch_batch if args.dispatch_batch >= 0 else WORKLOADS[args.workload][1])
+        self.net.set_conv_policy(args.conv, args.dispatch_batch if args.dispatch_batch >= 0 else (args.batch or WORKLOADS[args.workload][1]))
         self.net.set_gemm_policy(args.gemm)
         self.shape = [B, p['data']['channels'], p['data']['image_size'], p['data']['image_size']]
         ev = p['eval']['dlpm']
@@ -544,7 +544,7 @@ def main():
                          'exactly into three bf16 planes, six partial products, fp32 accumulate (default where the shape admits it); '
                          'f32 = the fp32 MFMA everywhere (A/B runs)')
     ap.add_argument('--dispatch-batch', type=int, default=-1,
-                    help='dlpm_unet_set_conv_policy dispatch batch (default: the per-GPU batch of the workload\'s BASELINE config; 0: geometry only)')
+                    help='dlpm_unet_set_conv_policy dispatch batch (default: --batch if given, else the per-GPU batch of the workload\'s BASELINE config; 0: geometry only)')
     ap.add_argument('--non-iso', action='store_true',
                     help='non-isotropic noise variant (--non_iso of the reference): [T,B,D] tables; not the headline config')
     ap.add_argument('--rank-timeout', type=float, default=7200.0,
@@ -824,7 +824,7 @@ def main():
                        'net': 'reference cifar10.yml UNet (mc=128, 39.6M params), random init + re-drawn zero tensors'
                        if cfg_name == 'cifar10' else cfg_name,
                        'rng': 'philox (device, keyed by global sample index)', 'hip_graph': not args.no_graph,
-                       'conv_generation': args.conv, 'gemm_1x1_and_downsample': args.gemm + (' (= bf16x3: fp32 operands split exactly into 3 bf16 planes, 6 partial products per multiply, fp32 accumulate; fp32-grade error, tests/test_gpu_kernels.py)' if args.gemm == 'auto' else ''), 'conv_dispatch_batch': args.dispatch_batch if args.dispatch_batch >= 0 else WORKLOADS[args.workload][1],
+                       'conv_generation': args.conv, 'gemm_1x1_and_downsample': args.gemm + (' (= bf16x3: fp32 operands split exactly into 3 bf16 planes, 6 partial products per multiply, fp32 accumulate; fp32-grade error, tests/test_gpu_kernels.py)' if args.gemm == 'auto' else ''), 'conv_dispatch_batch': args.dispatch_batch if args.dispatch_batch >= 0 else (args.batch or WORKLOADS[args.workload][1]),
                        'parallelism': ('batch-sharded x%d, one RCCL all-gather at the end' % world) if world > 1 else 'single GPU (no collective)'},
             'value_source': value_source,
             'full_trajectory_s': None if full_s is None else round(full_s, 4),

@@ -16,6 +16,8 @@ struct ConvLaunch {
     const float *w_wino = nullptr; // optional, 3x3 s1 only: Winograd-domain weights U = G g G^T in fragment order
                                    // (see conv_wino.hip); when the shape qualifies the F(2x2,3x3) kernel runs
     const float *w_wino4 = nullptr;// optional, 3x3 s1 only: F(4x4,3x3) Winograd-domain weights (conv_wino4.hip); preferred over w_wino
+    const float *w_wino4_n64 = nullptr, *w_wino4_n32 = nullptr;   // optional, Cout % 128 == 0 only: the same weights in the fragment order of 64- / 32-channel
+                                   // n-tiles (round 6: at a small DECLARED batch the narrow shapes give 2-4x as many workgroups; same bits)
     const void *w_split = nullptr; // optional: the weights as three bf16 planes in stage-tile order (conv_split.hip); a 3x3 launch
                                    // that carries it is a stride-2 downsampling convolution, or a test forcing the path
     const float *w_small = nullptr;// optional, 3x3 with Cout <= 4 (the head): [tap][Cin][4] for k_conv3x3_head
@@ -97,7 +99,7 @@ bool wino4_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg);
 bool wino4_preferred(const ConvLaunch &c, int *bh, int *bw, int *nimg);   // geometry + dispatch policy
 int launch_conv_wino4(const ConvLaunch &c, hipStream_t st);
 int64_t wino4_weight_floats(int Cout, int Cin);
-int relayout_weight_wino4(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st);
+int relayout_weight_wino4(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st, int nq = 0);   // nq: n-tile width (0: the layer's own)
 // A WHOLE ResBlock with 32 output channels on 32x32 images in one launch (round 6, conv_wino4.hip: k_resblock_wino4_img): GroupNorm-1
 // coefficients from the producers' statistics (or given), conv1 as F(4x4,3x3), GroupNorm-2 with scale-shift inside the workgroup (an image
 // is one workgroup), conv2 over the activated intermediate (which makes one trip through L2, never a second launch), skip, output
@@ -105,6 +107,8 @@ int relayout_weight_wino4(const float *oihw_dev, float *dst_dev, int Cout, int C
 struct ResImgLaunch {
     const float *x0 = nullptr, *x1 = nullptr;        // NHWC input, virtual concat [x0 | x1]
     int C0 = 0, C1 = 0, B = 0;
+    int H = 32;                                      // 32: 32 output channels on 32x32 images (k_resblock_wino4_img); 16: 64 output channels on 16x16
+                                                     // images (k_resblock_wino4_img16: the intermediate stays in LDS, hbuf unused, stats_out = [B][64])
     const float2 *st0 = nullptr, *st1 = nullptr;     // producers' statistics ([B][nt][C] float2) -> GroupNorm-1 inside the kernel, or
     int nt0 = 1, nt1 = 1;
     const float *coefA1 = nullptr, *coefB1 = nullptr;   // ... its coefficients [B][Cin] computed by a launch in front (sources without statistics)

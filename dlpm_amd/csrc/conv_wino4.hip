@@ -1385,6 +1385,372 @@ __global__ void __launch_bounds__(FI_NT, 1) k_resblock_wino4_img(ResImgLaunch p)
 #endif
 }
 
+// =====================================================================================================================================
+// Round 6 -- the same for 64 output channels on 16x16 images (the MNIST-sized nets' second level: five ResBlocks per step, each two
+// 34-us launches of the 4 + 3-wave shape + two coefficient launches).  An image is ONE 16-tile M-block, so the matrix work has four
+// 16-channel roles; the eight waves are those four x two K HALVES: wave (nw, kh) runs the MFMAs of the 8-channel phases 2 c + kh of
+// every 16-channel chunk c on a full set of 36 accumulators, and at the end of a pass the halves meet through LDS -- each wave hands its
+// partner the two tiles the partner finalises and keeps the other two, so the output transform, the GroupNorm statistics and the
+// epilogue run on all eight waves.  Per chunk: waves 0..3 transform (two row groups x two channel-pair groups), barrier, every wave
+// its 72 MFMAs with the next chunk's loads in flight, staging, barrier.  The intermediate h never leaves the CU: activated, it goes
+// to an LDS image [256][68] from which pass 2 stages its chunks (LDS -> LDS, zero padding applied there).  The sums of the two K halves
+// are added once per output, so this kernel rounds differently from the 4 + 3-wave launches it replaces (5e-6 of the reference's
+// ResBlock, tests/golden/f14_blocks16.npz; bits independent of the batch: an image is a workgroup).
+constexpr int F6_TILES = 16, F6_RW = 18, F6_NPIX = F6_RW * F6_RW, F6_KC = 16, F6_PRLD = F6_KC + 4;
+constexpr int F6_QN = (F6_NPIX * 4 + FI_NT - 1) / FI_NT;        // staging items (pixel, channel quad of the chunk) per thread: 3
+constexpr int F6_RAWBUF = F6_NPIX * F6_PRLD + 32;
+constexpr int F6_VPP = 8 * F6_TILES * 4;                         // floats per position pair: [8 channel pairs][16 tiles][4]
+constexpr int F6_VBUF = 18 * F6_VPP;
+constexpr int F6_HLD = 64 + 4, F6_HBUF = 256 * F6_HLD;
+constexpr int F6_XCH = 8 * 36 * 64;                              // floats of the K-half exchange buffer (one round: 18 accumulator tiles x 2 components per wave)
+static_assert(F6_XCH <= F6_VBUF + F6_RAWBUF + F6_HBUF, "the exchange buffer aliases V, raw and the (then dead) intermediate image");
+
+__global__ void __launch_bounds__(FI_NT, 1) k_resblock_wino4_img16(ResImgLaunch p) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float *V = wsm;                      // [18 position pairs][8 channel pairs][16 tiles][2 pos x 2 ch]
+    float *raw = V + F6_VBUF;            // [18 x 18][F6_PRLD] (+ skew)
+    float *hL = raw + F6_RAWBUF;         // [256][F6_HLD] silu(GN2(h) (1 + scale) + shift)
+    float *Cf = hL + F6_HBUF;            // [A | B][Cin <= 128]
+    float *gsh = Cf + 256;               // GroupNorm scratch (2 C + 2 G floats)
+    float2 *part = reinterpret_cast<float2 *>(gsh + 512);   // [2 K halves][64]: statistics partials (128 pixels each)
+    int *itmL = reinterpret_cast<int *>(gsh + 768);         // [3][512] staging items
+    float *xb = wsm;                     // exchange buffer (aliases V / raw / hL between the passes' loops and their register sections)
+    DLPM_PHASE_DECL;
+    constexpr int H = 16, W = 16, CO = 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int nw = wave & 3, kh = wave >> 2;         // MFMA role: 16-channel output tile, K half
+    const int img = blockIdx.x;
+    const int ch = 16 * nw + li;
+
+    // staging item e = it * 512 + tid: (halo pixel e >> 2, channel quad e & 3 of the 16-channel chunk)
+#pragma unroll
+    for (int it = 0; it < F6_QN; it++) {
+        const int e = it * FI_NT + tid, pix = e >> 2, quad = e & 3;
+        const int ry = pix / F6_RW, rx = pix - ry * F6_RW;
+        const int iy = ry - 1, ix = rx - 1;
+        const bool pad = iy < 0 || iy >= H || ix < 0 || ix >= W;
+        const int lo = pix * F6_PRLD + quad * 4 + 4 * (ry >> 2);
+        itmL[it * FI_NT + tid] = pix >= F6_NPIX ? (1 << 25) : (lo | (pad ? (1 << 24) : ((iy * W + ix) << 14)));
+    }
+    const int quad = tid & 3;
+    const float *s0 = p.x0, *s1 = p.x1;
+    int c0 = p.C0, c1 = p.C1;
+    float4 xr[F6_QN];
+    auto load_raw = [&](int chunk) __attribute__((always_inline)) {                 // pass 1: global -> registers
+        const int c = chunk * F6_KC + quad * 4;
+        const bool first = c < c0;
+        const int ld = first ? c0 : c1;
+        const float *sb = (first ? s0 + c : s1 + (c - c0)) + (int64_t)img * (H * W) * ld;
+#pragma unroll
+        for (int it = 0; it < F6_QN; it++) xr[it] = *reinterpret_cast<const float4 *>(sb + ((itmL[it * FI_NT + tid] >> 14) & 255) * ld);
+    };
+    auto store_raw = [&](int chunk, auto first_pass) __attribute__((always_inline)) {
+        constexpr bool P1 = decltype(first_pass)::value;   // pass 1: x A + B, SiLU from registers; pass 2: copy from the LDS image
+        const int c = chunk * F6_KC + quad * 4;
+        float4 ca = make_float4(1.f, 1.f, 1.f, 1.f), cb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (P1) {
+            ca = *reinterpret_cast<const float4 *>(Cf + c);
+            cb = *reinterpret_cast<const float4 *>(Cf + 128 + c);
+        }
+#pragma unroll
+        for (int it = 0; it < F6_QN; it++) {
+            const int iv = itmL[it * FI_NT + tid];
+            if (iv & (1 << 25)) continue;
+            float4 x;
+            if (P1) {
+                x = xr[it];
+                x.x = silu_f(fmaf(x.x, ca.x, cb.x));
+                x.y = silu_f(fmaf(x.y, ca.y, cb.y));
+                x.z = silu_f(fmaf(x.z, ca.z, cb.z));
+                x.w = silu_f(fmaf(x.w, ca.w, cb.w));
+            } else {
+                x = *reinterpret_cast<const float4 *>(hL + ((iv >> 14) & 255) * F6_HLD + c);
+            }
+            if (iv & (1 << 24)) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(raw + (iv & 16383)) = x;
+        }
+    };
+    // input transform: wave w < 4 = (row group th = w & 1, channel-pair group cp = w >> 1); lane = (pair of the group, tile)
+    int rbase, vofs;
+    {
+        const int cp = (wave >> 1) & 1, tile = lane & 15, pair = 4 * cp + (lane >> 4);
+        const int ty = tile >> 2, tx = tile & 3;
+        rbase = (4 * ty * F6_RW + 4 * tx) * F6_PRLD + pair * 2 + 4 * ty;
+        vofs = (pair * F6_TILES + tile) * 4;
+    }
+    const int th = wave & 1;
+    auto transform = [&]() __attribute__((always_inline)) {
+        const float *rb = raw + rbase;
+        float *vb = V + vofs;
+        auto d = [&](int i, int c) {
+            return *reinterpret_cast<const float2 *>(rb + (i * F6_RW + c) * F6_PRLD + (i >= 4 ? 4 : 0));
+        };
+        auto row_out = [&](const float2 (&T)[6], int a) {
+            float *vr = vb + a * 3 * F6_VPP;
+            const float2 e1 = f2fma(-PB2, T[2], T[4]), o1 = f2fma(-PB2, T[1], T[3]);
+            const float2 e2 = f2fma(-PA2, T[2], T[4]), o2 = f2fma(-PA2, T[1], T[3]);
+            const float2 v0 = f2fma(PP2, T[0], f2fma(-PS2, T[2], T[4])), v1 = f2fma(PA, o1, e1), v2 = f2fma(-PA, o1, e1);
+            const float2 v3 = f2fma(PB, o2, e2), v4 = f2fma(-PB, o2, e2), v5 = f2fma(PP2, T[1], f2fma(-PS2, T[3], T[5]));
+            *reinterpret_cast<float4 *>(vr + 0 * F6_VPP) = make_float4(v0.x, v0.y, v1.x, v1.y);
+            *reinterpret_cast<float4 *>(vr + 1 * F6_VPP) = make_float4(v2.x, v2.y, v3.x, v3.y);
+            *reinterpret_cast<float4 *>(vr + 2 * F6_VPP) = make_float4(v4.x, v4.y, v5.x, v5.y);
+        };
+        float2 Ta[6], Tb[6];
+        if (th == 0) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const float2 e = f2fma(-PB2, d(2, c), d(4, c)), o = f2fma(-PB2, d(1, c), d(3, c));
+                Ta[c] = f2fma(PA, o, e);
+                Tb[c] = f2fma(-PA, o, e);
+            }
+            row_out(Ta, 1);
+            row_out(Tb, 2);
+#pragma unroll
+            for (int c = 0; c < 6; c++) Ta[c] = f2fma(PP2, d(0, c), f2fma(-PS2, d(2, c), d(4, c)));
+            row_out(Ta, 0);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const float2 e = f2fma(-PA2, d(2, c), d(4, c)), o = f2fma(-PA2, d(1, c), d(3, c));
+                Ta[c] = f2fma(PB, o, e);
+                Tb[c] = f2fma(-PB, o, e);
+            }
+            row_out(Ta, 3);
+            row_out(Tb, 4);
+#pragma unroll
+            for (int c = 0; c < 6; c++) Tb[c] = f2fma(PP2, d(1, c), f2fma(-PS2, d(3, c), d(5, c)));
+            row_out(Tb, 5);
+        }
+    };
+    constexpr int AHEAD = F4_RING - 1;
+    const float *asrc = V + ((4 * kh + lk) * F6_TILES + li) * 4;     // this K half's channel pairs of the chunk
+    floatx4 acc[36];
+    // one convolution over nch16 chunks of 16 channels; pass 1 has chunk 0 in xr on entry
+    auto conv_pass = [&](const float *wfrag, int nch16, auto first_pass) __attribute__((always_inline)) {
+        constexpr bool P1 = decltype(first_pass)::value;
+        const int last = nch16 - 1;
+        // Wf[ntile 0][wave nw][8-channel phase][18][lane][4]: this wave's phases are 2 c + kh
+        const float4 *__restrict__ wp = reinterpret_cast<const float4 *>(wfrag) + ((int64_t)nw * (2 * nch16) + kh) * 18 * 64;
+        float4 bq[F4_RING];
+#pragma unroll
+        for (int q = 0; q < 36; q++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[q][r] = 0.f;
+        store_raw(0, first_pass);
+        F4_LDS_BARRIER();
+#pragma unroll 1
+        for (int chunk = 0; chunk < nch16; chunk++) {
+            if (wave < 4) transform();
+#pragma unroll
+            for (int a = 0; a < AHEAD; a++) bq[a] = wp[a * 64 + lane];
+            if (P1) load_raw(min(chunk + 1, last));
+            F4_LDS_BARRIER();
+            float4 aq[2];
+            aq[0] = *reinterpret_cast<const float4 *>(asrc);
+#pragma unroll
+            for (int pp = 0; pp < 18; pp++) {
+                if (pp + AHEAD < 18) bq[(pp + AHEAD) % F4_RING] = wp[(pp + AHEAD) * 64 + lane];
+                if (pp + 1 < 18) aq[(pp + 1) & 1] = *reinterpret_cast<const float4 *>(asrc + (pp + 1) * F6_VPP);
+                const float4 aa = aq[pp & 1];
+                const float4 b = bq[pp % F4_RING];
+                acc[2 * pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.x, b.x, acc[2 * pp], 0, 0, 0);
+                acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.z, b.z, acc[2 * pp + 1], 0, 0, 0);
+                acc[2 * pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.y, b.y, acc[2 * pp], 0, 0, 0);
+                acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.w, b.w, acc[2 * pp + 1], 0, 0, 0);
+            }
+            wp += 2 * 18 * 64;
+            if (chunk < last) store_raw(chunk + 1, first_pass);
+            F4_LDS_BARRIER();
+        }
+    };
+    // the two K halves meet: wave (nw, kh) keeps tiles r = 2 kh, 2 kh + 1 of its lanes and receives the partner's sums for them (two
+    // rounds of 18 accumulator tiles through xb); afterwards acc[q][RA], acc[q][RA + 1] hold the complete sums
+    auto exchange = [&](auto ra_c) __attribute__((always_inline)) {
+        constexpr int RA = decltype(ra_c)::value, RO = 2 - RA;     // mine, the partner's
+        float2 *xb2 = reinterpret_cast<float2 *>(xb);      // [wave][18][lane] pairs of adjacent accumulator components: 8-byte LDS accesses
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+#pragma unroll
+            for (int q = 0; q < 18; q++) xb2[(wave * 18 + q) * 64 + lane] = make_float2(acc[18 * hh + q][RO], acc[18 * hh + q][RO + 1]);
+            F4_LDS_BARRIER();
+#pragma unroll
+            for (int q0 = 0; q0 < 18; q0 += 6) {      // six at a time: all 18 in flight at once are 36 more live registers beside the accumulators
+                float2 t[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) t[q] = xb2[((wave ^ 4) * 18 + q0 + q) * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    acc[18 * hh + q0 + q][RA] += t[q].x;
+                    acc[18 * hh + q0 + q][RA + 1] += t[q].y;
+                }
+                asm volatile("" ::: "memory");
+            }
+            F4_LDS_BARRIER();
+        }
+    };
+    auto out_tile = [&](auto r_c, float (&Yt)[16]) __attribute__((always_inline)) {
+        constexpr int r = decltype(r_c)::value;
+        float Z[4][6];
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+            const float m0 = acc[0 * 6 + b][r], m1 = acc[1 * 6 + b][r], m2 = acc[2 * 6 + b][r];
+            const float m3 = acc[3 * 6 + b][r], m4 = acc[4 * 6 + b][r], m5 = acc[5 * 6 + b][r];
+            const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+            Z[0][b] = m0 + s12 + s34;
+            Z[1][b] = fmaf(PB, d34, PA * d12);
+            Z[2][b] = fmaf(PB2, s34, PA2 * s12);
+            Z[3][b] = fmaf(PB3, d34, PA3 * d12) + m5;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float s12 = Z[i][1] + Z[i][2], d12 = Z[i][1] - Z[i][2], s34 = Z[i][3] + Z[i][4], d34 = Z[i][3] - Z[i][4];
+            Yt[i * 4 + 0] = Z[i][0] + s12 + s34;
+            Yt[i * 4 + 1] = fmaf(PB, d34, PA * d12);
+            Yt[i * 4 + 2] = fmaf(PB2, s34, PA2 * s12);
+            Yt[i * 4 + 3] = fmaf(PB3, d34, PA3 * d12) + Z[i][5];
+        }
+    };
+    // (mean, M2) of this wave's 128 pixels of its channel from the per-lane shifted sums over 32 values; every lane ends up with it
+    auto half_stats = [&](float K, float s1, float s2, float &mean, float &M2) __attribute__((always_inline)) {
+        mean = K + s1 * (1.f / 32.f);
+        M2 = fmaxf(s2 - s1 * s1 * (1.f / 32.f), 0.f);
+        float na = 32.f;
+#pragma unroll
+        for (int sft = 16; sft <= 32; sft <<= 1) {
+            const float om = __shfl_xor(mean, sft), oM2 = __shfl_xor(M2, sft);
+            const float lo_m = (lane & sft) ? om : mean, hi_m = (lane & sft) ? mean : om;
+            const float lo_M = (lane & sft) ? oM2 : M2, hi_M = (lane & sft) ? M2 : oM2;
+            const float dd = hi_m - lo_m;
+            mean = lo_m + dd * 0.5f;
+            M2 = lo_M + hi_M + dd * dd * (na * 0.5f);
+            na *= 2.f;
+        }
+    };
+
+    // ================= pass 1: h = conv1(silu(GN1(x)))
+    const int Cin = p.C0 + p.C1;
+    load_raw(0);
+    if (p.st0) {
+        gn_coeffs_from_stats_image(p.st0 + (int64_t)img * p.nt0 * p.C0, p.st1 ? p.st1 + (int64_t)img * p.nt1 * p.C1 : nullptr, p.C0, p.C1, p.nt0,
+                                   p.nt1, H * W, Cin < 32 ? Cin : 32, p.gn1_w, p.gn1_b, nullptr, gsh, Cf, Cf + 128, 1e-5f, tid, FI_NT,
+                                   [] { F4_LDS_BARRIER(); });
+    } else {
+        for (int i = tid; i < 2 * Cin; i += FI_NT) {
+            if (i < Cin) Cf[i] = p.coefA1[(int64_t)img * Cin + i];
+            else Cf[128 + (i - Cin)] = p.coefB1[(int64_t)img * Cin + (i - Cin)];
+        }
+    }
+    F4_LDS_BARRIER();
+    conv_pass(p.w1, Cin / F6_KC, std::integral_constant<bool, true>());
+    DLPM_PHASE(p, 8);
+
+    // ================= between: the halves meet; h + bias, statistics, GroupNorm-2 with scale-shift, a = silu(..) -> LDS image
+    auto between = [&](auto ra_c) __attribute__((always_inline)) {
+        constexpr int RA = decltype(ra_c)::value;
+        exchange(ra_c);
+        int chv = ch, lkv = lk;
+        asm volatile("" : "+v"(chv), "+v"(lkv));
+        const float bias_v = p.b1[chv];
+        float hv[2][16];
+        float K = 0.f, s1 = 0.f, s2 = 0.f;
+        {
+            float Yt[16];
+            out_tile(std::integral_constant<int, RA>(), Yt);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const float v = Yt[k] + bias_v;
+                if (k == 0) K = v;
+                const float dd = v - K;
+                s1 += dd;
+                s2 = fmaf(dd, dd, s2);
+                hv[0][k] = v;
+            }
+            out_tile(std::integral_constant<int, RA + 1>(), Yt);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const float v = Yt[k] + bias_v;
+                const float dd = v - K;
+                s1 += dd;
+                s2 = fmaf(dd, dd, s2);
+                hv[1][k] = v;
+            }
+        }
+        float mean, M2;
+        half_stats(K, s1, s2, mean, M2);
+        if (lkv == 0) part[kh * CO + chv] = make_float2(mean, M2);
+        F4_LDS_BARRIER();
+        gn_coeffs_from_stats_image(part, nullptr, CO, 0, 2, 1, H * W, 32, p.gn2_w, p.gn2_b, p.emb + (int64_t)img * p.emb_stride + p.emb_off, gsh, Cf,
+                                   Cf + 128, 1e-5f, tid, FI_NT, [] { F4_LDS_BARRIER(); });
+        F4_LDS_BARRIER();
+        const float a2 = Cf[chv], b2 = Cf[128 + chv];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int tile = 4 * lkv + RA + rr;
+            const int tpix = (4 * (tile >> 2)) * W + 4 * (tile & 3);
+#pragma unroll
+            for (int k = 0; k < 16; k++) hL[(tpix + (k >> 2) * W + (k & 3)) * F6_HLD + chv] = silu_f(fmaf(hv[rr][k], a2, b2));
+        }
+    };
+    if (kh == 0) between(std::integral_constant<int, 0>());
+    else between(std::integral_constant<int, 2>());
+    F4_LDS_BARRIER();
+
+    // ================= pass 2: out = conv2(a) + bias + skip
+    conv_pass(p.w2, CO / F6_KC, std::integral_constant<bool, false>());
+    DLPM_PHASE(p, 9);
+    auto epilogue = [&](auto ra_c) __attribute__((always_inline)) {
+        constexpr int RA = decltype(ra_c)::value;
+        exchange(ra_c);
+        int chv = ch, lkv = lk;
+        asm volatile("" : "+v"(chv), "+v"(lkv));
+        const float bias_v = p.b2[chv];
+        const int64_t pix0 = (int64_t)img * H * W;
+        float *__restrict__ out_blk = p.out + pix0 * CO;
+        const float *__restrict__ res_blk = p.res + pix0 * CO;
+        const bool do_stats = p.stats_out != nullptr;
+        float K = 0.f, s1 = 0.f, s2 = 0.f;
+        auto one = [&](auto r_c, int rr) __attribute__((always_inline)) {
+            const int tile = 4 * lkv + RA + rr;
+            const int tpix = (4 * (tile >> 2)) * W + 4 * (tile & 3);
+            float rs[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) rs[k] = res_blk[(tpix + (k >> 2) * W + (k & 3)) * CO + chv];
+            float Yt[16];
+            out_tile(r_c, Yt);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const float v = (Yt[k] + bias_v) + rs[k];
+                if (rr == 0 && k == 0) K = v;
+                const float dd = v - K;
+                s1 += dd;
+                s2 = fmaf(dd, dd, s2);
+                out_blk[(tpix + (k >> 2) * W + (k & 3)) * CO + chv] = v;
+            }
+        };
+        one(std::integral_constant<int, RA>(), 0);
+        one(std::integral_constant<int, RA + 1>(), 1);
+        if (do_stats) {     // per-image statistics: the two halves' 128-pixel partials merged in a fixed order (Chan's update)
+            float mean, M2;
+            half_stats(K, s1, s2, mean, M2);
+            if (lkv == 0) part[kh * CO + chv] = make_float2(mean, M2);
+            F4_LDS_BARRIER();
+            if (kh == 0 && lkv == 0) {
+                const float2 a = part[chv], b = part[CO + chv];
+                const float dd = b.x - a.x;
+                p.stats_out[(int64_t)img * CO + chv] = make_float2(a.x + dd * 0.5f, a.y + b.y + dd * dd * 64.f);
+            }
+        }
+    };
+    if (kh == 0) epilogue(std::integral_constant<int, 0>());
+    else epilogue(std::integral_constant<int, 2>());
+    DLPM_PHASE(p, 10);
+    DLPM_PHASE_FLUSH(p, 8);
+#ifdef DLPM_PHASE_TIMING
+    if (p.phase && tid == 0) atomicAdd(p.phase + 11, 1ull);
+#endif
+}
+
 // OIHW (3x3) -> U = G g G^T (6x6 per filter) in the kernel's fragment order Wf[ntile][wave][phase][18][lane][4]:
 // lane = lk*16 + li holds, for position pair pp and e = 0..3, U_pos[cin = phase*8 + 2 lk + (e & 1)][cout = ntile*128 + wave*16 + li]
 // with pos = 2 pp + (e >> 1).  Computed in double, rounded once.
@@ -1452,11 +1818,12 @@ static bool narrow_enabled() {
     return v != 0;
 }
 
-bool wino4_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
-    if (c.Cout % F4_NQ != 0 && !narrow_enabled()) return false;
+// geometry of a launch on n-tiles of nq channels (the narrow shapes' raw buffer holds halo patches of <= 400 pixels)
+static bool wino4_geometry_nq(const ConvLaunch &c, int nq, int *bh, int *bw, int *nimg) {
+    if (nq != F4_NQ && !narrow_enabled()) return false;
     if (!c.w_wino4 || c.ks != 3 || c.stride != 1 || c.in_nchw || c.out_nchw || c.abl) return false;
     if ((c.Hout & 3) || (c.Wout & 3) || c.Cout % 32 != 0 || (c.C0 + c.C1) % F4_KC != 0 || c.C0 % F4_KC != 0) return false;
-    const int rawpix = f4_nq_of(c.Cout) == F4_NQ ? F4_RAWPIX : F4_RAWPIX_N;
+    const int rawpix = nq == F4_NQ ? F4_RAWPIX : F4_RAWPIX_N;
     if ((c.R0 & 15) != 0) return false;   // a wave's 16 output channels stay on one side of a residual concat
     const int TH = c.Hout / 4, TW = c.Wout / 4;
     int h, w, n;
@@ -1476,6 +1843,32 @@ bool wino4_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
     return true;
 }
 
+// Round 6 -- the n-tile width of a 128-channel-multiple layer under a DECLARED batch.  At dispatch_B <= 256 the
+// 16x16 / 8x8 levels of the CIFAR net launch 32-128 workgroups of 128 channels on 256 CUs; the 64- / 32-channel n-tile shapes (4 + 3 and
+// 2 + 2 waves) give 2x / 4x as many from the same fragment arithmetic (same bits: a wave's share is 16 channels x 36 positions x 16 tiles
+// in every shape).  The widest n-tile whose grid fills the chip at the declared batch wins; if none does, the narrowest available.  A
+// function of the layer and the declaration only -- never of the batch a launch carries.  DLPM_WINO4_NQ=128 switches it off (A/B runs).
+static int wino4_nq_for(const ConvLaunch &c) {
+    const int base = f4_nq_of(c.Cout);
+    if (base != F4_NQ || c.dispatch_B <= 0 || (!c.w_wino4_n64 && !c.w_wino4_n32)) return base;
+    static int floor_nq = -1;
+    if (floor_nq < 0) { const char *e = getenv("DLPM_WINO4_NQ"); floor_nq = e ? atoi(e) : 32; }
+    int best = F4_NQ;
+    for (int nq = F4_NQ; nq >= 32 && nq >= floor_nq; nq >>= 1) {
+        if (nq == 64 && !c.w_wino4_n64) continue;
+        if (nq == 32 && !c.w_wino4_n32) continue;
+        int h, w, n;
+        if (!wino4_geometry_nq(c, nq, &h, &w, &n)) continue;
+        best = nq;
+        const int64_t tiles = c.dispatch_B * (c.Hout / 4) * (c.Wout / 4);
+        const int64_t mblocks = n == 1 ? tiles / F4_TILES : ceil_div(c.dispatch_B, (int64_t)n);
+        if (mblocks * (c.Cout / nq) >= 256) break;
+    }
+    return best;
+}
+
+bool wino4_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg) { return wino4_geometry_nq(c, wino4_nq_for(c), bh, bw, nimg); }
+
 // dispatch policy (a function of the layer and of ConvLaunch::gen / dispatch_B, never of the batch in this launch:
 // the generations round differently and a sample must not depend on how its batch was sharded or chunked):
 //   DLPM_CONV_F4     F(4x4) wherever the geometry qualifies;
@@ -1493,7 +1886,7 @@ bool wino4_preferred(const ConvLaunch &c, int *bh, int *bw, int *nimg) {
     if (c.dispatch_B <= 0) return true;
     const int64_t tiles = c.dispatch_B * (c.Hout / 4) * (c.Wout / 4);
     const int64_t mblocks = *nimg == 1 ? tiles / F4_TILES : ceil_div(c.dispatch_B, (int64_t)*nimg);
-    return mblocks * (c.Cout / f4_nq_of(c.Cout)) >= 256;
+    return mblocks * (c.Cout / wino4_nq_for(c)) >= 256;
 }
 
 // DLPM_WINO4_IMG=0 (A/B runs): the 32-channel 32x32 layers on the 2 + 2-wave 16-tile shape as in round 5 (same bits either way).  A
@@ -1504,6 +1897,8 @@ static bool wino4_whole_image(const ConvLaunch &c) {
     return v != 0 && c.Cout == 32 && !c.ups && c.Hout == 32 && c.Wout == 32 && (c.C0 + c.C1) <= 1024;
 }
 
+static int launch_conv_wino4_nq(const ConvLaunch &c, int nq, int bh, int bw, int nimg, hipStream_t st);
+
 int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
     int bh, bw, nimg;
     if (!wino4_geometry(c, &bh, &bw, &nimg)) {
@@ -1513,8 +1908,19 @@ int launch_conv_wino4(const ConvLaunch &c, hipStream_t st) {
 #ifdef DLPM_PHASE_TIMING
     const_cast<ConvLaunch &>(c).phase = phase_buffer();
 #endif
+    const int nq = wino4_nq_for(c);
+    if (nq != f4_nq_of(c.Cout)) {     // a 128-multiple layer on narrow n-tiles: the matching fragment stream
+        ConvLaunch cn = c;
+        cn.w_wino4 = nq == 64 ? c.w_wino4_n64 : c.w_wino4_n32;
+        cn.w_wino4_n64 = cn.w_wino4_n32 = nullptr;
+        cn.dispatch_B = 0;
+        return launch_conv_wino4_nq(cn, nq, bh, bw, nimg, st);
+    }
+    return launch_conv_wino4_nq(c, nq, bh, bw, nimg, st);
+}
+
+static int launch_conv_wino4_nq(const ConvLaunch &c, int nq, int bh, int bw, int nimg, hipStream_t st) {
     using KFn = void (*)(ConvLaunch, int, int, int);
-    const int nq = f4_nq_of(c.Cout);
     const int64_t tiles = (int64_t)c.B * (c.Hout / 4) * (c.Wout / 4);
     const int64_t mblocks = nimg == 1 ? tiles / F4_TILES : ceil_div(c.B, nimg);
     if (wino4_whole_image(c)) {   // 32 channels on 32x32 images: one workgroup per image, 8 MFMA waves (round 6)
@@ -1582,8 +1988,14 @@ bool res_img_ok(const ResImgLaunch &r) {
     static int v = -1;
     if (v < 0) { const char *e = getenv("DLPM_RES_IMG"); v = e ? atoi(e) : 1; }
     const int Cin = r.C0 + r.C1;
-    return v != 0 && wino4_enabled() && r.w1 && r.w2 && r.res && r.hbuf && Cin % F4_KC == 0 && r.C0 % F4_KC == 0 && Cin <= 128 && Cin >= 32 &&
-           (r.st0 ? (r.C1 == 0 || r.st1 != nullptr) : (r.coefA1 && r.coefB1));
+    const bool common = v != 0 && wino4_enabled() && r.w1 && r.w2 && r.res && Cin <= 128 && Cin >= 32 &&
+                        (r.st0 ? (r.C1 == 0 || r.st1 != nullptr) : (r.coefA1 && r.coefB1));
+    if (r.H == 16) {     // 64 output channels on 16x16 images (k_resblock_wino4_img16): 16-channel chunks that stay inside one concat source
+        static int v16 = -1;
+        if (v16 < 0) { const char *e = getenv("DLPM_RES_IMG16"); v16 = e ? atoi(e) : 1; }
+        return common && v16 != 0 && Cin % F6_KC == 0 && r.C0 % F6_KC == 0;
+    }
+    return common && r.H == 32 && r.hbuf && Cin % F4_KC == 0 && r.C0 % F4_KC == 0;
 }
 
 int launch_resblock_img(const ResImgLaunch &r, hipStream_t st) {
@@ -1592,11 +2004,21 @@ int launch_resblock_img(const ResImgLaunch &r, hipStream_t st) {
         return DLPM_ERR_UNSUPPORTED;
     }
     const int Cin = r.C0 + r.C1;
-    const double M = (double)r.B * 1024;
-    ProfScope ps("resblock_img:H32", 2.0 * M * 32 * 9.0 * (Cin + 32), 4.0 * (M * (Cin + 32 + 32) + 32 * 9.0 * (Cin + 32)), st);
 #ifdef DLPM_PHASE_TIMING
     const_cast<ResImgLaunch &>(r).phase = phase_buffer();
 #endif
+    if (r.H == 16) {
+        const double M16 = (double)r.B * 256;
+        ProfScope ps16("resblock_img:H16", 2.0 * M16 * 64 * 9.0 * (Cin + 64), 4.0 * (M16 * (Cin + 64 + 64) + 64 * 9.0 * (Cin + 64)), st);
+        const int e16 = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_resblock_wino4_img16), 160 * 1024);
+        if (e16 != DLPM_OK) return e16;
+        const size_t lds16 = (size_t)(F6_VBUF + F6_RAWBUF + F6_HBUF + 256 + 512 + 256 + F6_QN * FI_NT) * sizeof(float);
+        k_resblock_wino4_img16<<<(unsigned)r.B, FI_NT, lds16, st>>>(r);
+        DLPM_LAUNCH_CHECK();
+        return DLPM_OK;
+    }
+    const double M = (double)r.B * 1024;
+    ProfScope ps("resblock_img:H32", 2.0 * M * 32 * 9.0 * (Cin + 32), 4.0 * (M * (Cin + 32 + 32) + 32 * 9.0 * (Cin + 32)), st);
     const int e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_resblock_wino4_img), 160 * 1024);
     if (e != DLPM_OK) return e;
     const size_t lds = (size_t)(FI_VBUF + FI_RAWBUF + 256 + 512 + 256 + FI_QN * FI_NT) * sizeof(float);
@@ -1607,10 +2029,10 @@ int launch_resblock_img(const ResImgLaunch &r, hipStream_t st) {
 
 int64_t wino4_weight_floats(int Cout, int Cin) { return (int64_t)Cout * Cin * 36 + F4_PAD * 256; }
 
-int relayout_weight_wino4(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st) {
+int relayout_weight_wino4(const float *oihw_dev, float *dst_dev, int Cout, int Cin, hipStream_t st, int nq_in) {
     const int64_t n = (int64_t)Cout * Cin * 36;
     DLPM_HIP(hipMemsetAsync(dst_dev + n, 0, (size_t)F4_PAD * 256 * sizeof(float), st));
-    const int nq = f4_nq_of(Cout);
+    const int nq = nq_in > 0 ? nq_in : f4_nq_of(Cout);
     k_relayout_weight_wino4<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(oihw_dev, dst_dev, Cout, Cin, (nq == F4_NQ && wino4_vsplit()) ? 1 : 0, nq / 16);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;

@@ -44,6 +44,8 @@ struct ConvW {            // one convolution's weights
     float *w_frag = nullptr; // 3x3 only: MFMA fragment order for the weight-streaming halo kernel
     float *w_wino = nullptr; // 3x3 only: Winograd-domain weights in fragment order (conv_wino.hip)
     float *w_wino4 = nullptr;// 3x3 only: F(4x4,3x3) Winograd-domain weights (conv_wino4.hip), when DLPM_WINO_F4 is on
+    float *w_wino4_n64 = nullptr, *w_wino4_n32 = nullptr;   // cout % 128 == 0, built while a SMALL dispatch batch is declared: the same weights in the
+                             // fragment order of 64- / 32-channel n-tiles (narrow_wino4_copies)
     float *w_small = nullptr;// 3x3 with cout <= 4 (head): [tap][cin][4]
     float *w_taps = nullptr; // 3x3 with cout <= 3 (head): [9 cout -> 32][cin], the head as a 1x1 GEMM + gather (conv_direct.hip)
     void *w_split = nullptr; // 1x1 with cout % 128 == 0, cin % 32 == 0: three bf16 planes in stage-tile order (conv_split.hip)
@@ -387,6 +389,8 @@ int run_conv(const dlpm_unet *u, const ConvW &c, ConvLaunch L, hipStream_t st, c
     L.w_frag = c.w_frag;
     L.w_wino = c.w_wino;
     L.w_wino4 = c.w_wino4;
+    L.w_wino4_n64 = c.w_wino4_n64;
+    L.w_wino4_n32 = c.w_wino4_n32;
     L.w_small = c.w_small;
     L.w_taps = c.w_taps;
     L.w_hfused = c.w_hfused;
@@ -452,17 +456,18 @@ int run_res(Ctx &cx, const Layer &L, Tensor4 x0, Tensor4 x1, Tensor4 *out) {
             return launch_resblock_small(r, cx.st);
         }
     }
-    if (u->gen == DLPM_CONV_AUTO && Co == 32 && H == 32 && W == 32 && L.c1.w_wino4 && L.c2.w_wino4) {
+    if (u->gen == DLPM_CONV_AUTO && ((Co == 32 && H == 32 && W == 32) || (Co == 64 && H == 16 && W == 16)) && L.c1.w_wino4 && L.c2.w_wino4) {
         // 32 channels on 32x32 images: the whole block in ONE launch, one workgroup per image (conv_wino4.hip: k_resblock_wino4_img) -- the
         // bits of the separate launches below (a function of the layer and the policy only).  GroupNorm-1 runs inside the kernel when both
         // sources carry statistics; the 1x1 skip convolution of the concat blocks stays a launch of its own.
+        // 64 channels on 16x16 images likewise (k_resblock_wino4_img16: the intermediate stays in LDS; it rounds differently from the launches below).
         ResImgLaunch r;
-        r.x0 = x0.p; r.x1 = x1.p; r.C0 = C0; r.C1 = C1; r.B = B;
+        r.x0 = x0.p; r.x1 = x1.p; r.C0 = C0; r.C1 = C1; r.B = B; r.H = H;
         const bool from_stats = x0.stats && (C1 == 0 || x1.stats);
         r.w1 = L.c1.w_wino4; r.w2 = L.c2.w_wino4;
         float *cA1 = from_stats ? nullptr : cx.ws.alloc((int64_t)B * Cin), *cB1 = from_stats ? nullptr : cx.ws.alloc((int64_t)B * Cin);
         float *sk = L.has_skip ? cx.ws.alloc((int64_t)B * HW * Co) : nullptr;
-        float *hb = cx.ws.alloc((int64_t)B * HW * Co);
+        float *hb = H == 32 ? cx.ws.alloc((int64_t)B * HW * Co) : nullptr;
         float *o = cx.ws.alloc((int64_t)B * HW * Co);
         r.hbuf = hb; r.res = L.has_skip ? sk : x0.p;
         if (from_stats) {
@@ -822,6 +827,9 @@ static void free_conv(ConvW &c) {
     c.w_wino = nullptr;
     if (c.w_wino4) (void)hipFree(c.w_wino4);
     c.w_wino4 = nullptr;
+    if (c.w_wino4_n64) (void)hipFree(c.w_wino4_n64);
+    if (c.w_wino4_n32) (void)hipFree(c.w_wino4_n32);
+    c.w_wino4_n64 = c.w_wino4_n32 = nullptr;
     if (c.w_small) (void)hipFree(c.w_small);
     c.w_small = nullptr;
     if (c.w_taps) (void)hipFree(c.w_taps);
@@ -850,6 +858,42 @@ static void for_each_conv(dlpm_unet *u, void (*fn)(ConvW &)) {
     fn(u->te0);
     fn(u->te2);
     fn(u->head);
+}
+
+// Round 6: under a small DECLARED batch (dlpm_unet_set_conv_policy's dispatch_batch) the 128-channel-multiple F(4x4) layers may run on 64- / 32-
+// channel n-tiles (conv_wino4.hip: wino4_nq_for), which read the same Winograd-domain weights in another fragment order.  The copies
+// exist only while such a batch is declared (3x the F(4x4) weight bytes of those layers); built from the parameters, on the null stream.
+constexpr int64_t NARROW_COPIES_MAX_BATCH = 512;
+static int narrow_wino4_copies(dlpm_unet *u) {
+    const bool want = u->dispatch_B > 0 && u->dispatch_B <= NARROW_COPIES_MAX_BATCH;
+    int rc = DLPM_OK;
+    auto one = [&](ConvW &c) {
+        if (rc != DLPM_OK || !c.w_wino4 || c.cout % 128 != 0) return;
+        if (!want) {
+            if (c.w_wino4_n64) (void)hipFree(c.w_wino4_n64);
+            if (c.w_wino4_n32) (void)hipFree(c.w_wino4_n32);
+            c.w_wino4_n64 = c.w_wino4_n32 = nullptr;
+            return;
+        }
+        for (int nq : {64, 32}) {
+            float *&dst = nq == 64 ? c.w_wino4_n64 : c.w_wino4_n32;
+            if (dst) continue;
+            if (hipMalloc(&dst, (size_t)wino4_weight_floats(c.cout, c.cin) * sizeof(float)) != hipSuccess) { dst = nullptr; rc = DLPM_ERR_HIP; set_error("narrow_wino4_copies: hipMalloc failed"); return; }
+            rc = relayout_weight_wino4(u->params[c.p_w].dev, dst, c.cout, c.cin, nullptr, nq);
+            if (rc != DLPM_OK) return;
+        }
+    };
+    auto seq = [&](std::vector<Layer> &s) {
+        for (auto &L : s) {
+            one(L.c1);
+            if (L.kind == L_RES) one(L.c2);
+        }
+    };
+    for (auto &s : u->in_blocks) seq(s);
+    seq(u->mid);
+    for (auto &s : u->out_blocks) seq(s);
+    if (rc == DLPM_OK && hipDeviceSynchronize() != hipSuccess) { set_error("narrow_wino4_copies: synchronize failed"); rc = DLPM_ERR_HIP; }
+    return rc;
 }
 
 extern "C" int dlpm_unet_finalize(dlpm_unet *u) {
@@ -916,6 +960,7 @@ extern "C" int dlpm_unet_finalize(dlpm_unet *u) {
             TRY(relayout_weight(u->embcat_w, u->embcat.w_dev, u->emb_total, u->ted, 1, false, nullptr));
         }
     }
+    TRY(narrow_wino4_copies(u));     // (a dispatch batch declared before finalize, or weights re-uploaded under one)
     DLPM_HIP(hipDeviceSynchronize());
     u->flops = count_flops(u);
     u->finalized = true;
@@ -932,6 +977,7 @@ extern "C" int dlpm_unet_set_conv_policy(dlpm_unet *u, int32_t generation, int64
     u->gen = generation;
     u->dispatch_B = dispatch_batch;
     u->plan_version++;
+    if (u->finalized) TRY(narrow_wino4_copies(u));
     return DLPM_OK;
 }
 
@@ -1267,29 +1313,31 @@ extern "C" int dlpm_resblock_small_f32(const dlpm_resblock_args *a, float *scrat
 
 extern "C" int64_t dlpm_resblock_img_scratch_floats(int64_t B, int32_t Cin) {
     if (B <= 0 || Cin <= 0) return -1;
-    return wino4_weight_floats(32, Cin) + wino4_weight_floats(32, 32) + 2 * B * Cin + 2 * B * 1024 * 32 + 64;
+    // (sized for either shape: 32 channels on 32x32 images, 64 channels on 16x16 ones)
+    return wino4_weight_floats(64, Cin) + wino4_weight_floats(64, 64) + 2 * B * Cin + 2 * B * 1024 * 32 + 64;
 }
 
 extern "C" int dlpm_resblock_img_f32(const dlpm_resblock_args *a, float *scratch_dev, int64_t scratch_floats, dlpm_stream_t stream) {
     DLPM_CHECK_ARG(a && a->x0 && a->conv1_w && a->conv2_w && a->ss && a->out && scratch_dev, "dlpm_resblock_img_f32: null argument");
     DLPM_CHECK_ARG(a->gn1_w && a->gn1_b && a->gn2_w && a->gn2_b && a->conv1_b && a->conv2_b, "dlpm_resblock_img_f32: null GroupNorm / bias parameter");
-    DLPM_CHECK_ARG(a->B > 0 && a->H == 32 && a->W == 32, "dlpm_resblock_img_f32: B %d, %d x %d images (32x32)", a->B, a->H, a->W);
+    DLPM_CHECK_ARG(a->B > 0 && a->H == a->W && (a->H == 32 || a->H == 16), "dlpm_resblock_img_f32: B %d, %d x %d images (32x32 or 16x16)", a->B, a->H, a->W);
+    const int CO = a->H == 32 ? 32 : 64, HW = a->H * a->W;
     DLPM_CHECK_ARG((a->C1 == 0) == (a->x1 == nullptr), "dlpm_resblock_img_f32: x1/C1 mismatch");
     const int Cin = a->C0 + a->C1;
     DLPM_CHECK_ARG(Cin >= 32 && Cin <= 128 && Cin % 8 == 0 && a->C0 % 8 == 0, "dlpm_resblock_img_f32: %d + %d input channels", a->C0, a->C1);
-    DLPM_CHECK_ARG((Cin == 32) == (a->skip_w == nullptr) && (!a->skip_w || a->skip_b), "dlpm_resblock_img_f32: skip_w / skip_b (required unless C0 + C1 = 32)");
+    DLPM_CHECK_ARG((Cin == CO) == (a->skip_w == nullptr) && (!a->skip_w || a->skip_b), "dlpm_resblock_img_f32: skip_w / skip_b (required unless C0 + C1 = the output channels)");
     DLPM_CHECK_ARG(scratch_floats >= dlpm_resblock_img_scratch_floats(a->B, Cin), "dlpm_resblock_img_f32: scratch of %lld floats, need %lld",
                    (long long)scratch_floats, (long long)dlpm_resblock_img_scratch_floats(a->B, Cin));
     hipStream_t st = as_stream(stream);
-    float *w1 = scratch_dev, *w2 = w1 + wino4_weight_floats(32, Cin), *cA = w2 + wino4_weight_floats(32, 32), *cB = cA + (int64_t)a->B * Cin;
-    float *hb = cB + (int64_t)a->B * Cin, *sk = hb + (int64_t)a->B * 1024 * 32;
+    float *w1 = scratch_dev, *w2 = w1 + wino4_weight_floats(CO, Cin), *cA = w2 + wino4_weight_floats(CO, CO), *cB = cA + (int64_t)a->B * Cin;
+    float *hb = cB + (int64_t)a->B * Cin, *sk = hb + (int64_t)a->B * HW * CO;
     hb += (64 - ((hb - scratch_dev) & 63)) & 63;          // (16-byte rows: float4 staging loads)
-    sk = hb + (int64_t)a->B * 1024 * 32;
-    TRY(relayout_weight_wino4(a->conv1_w, w1, 32, Cin, st));
-    TRY(relayout_weight_wino4(a->conv2_w, w2, 32, 32, st));
-    TRY(launch_gn_coeffs(a->x0, a->x1, a->C0, a->C1, a->B, 1024, 32, a->gn1_w, a->gn1_b, nullptr, 0, 0, cA, cB, st));
+    sk = hb + (int64_t)a->B * HW * CO;
+    TRY(relayout_weight_wino4(a->conv1_w, w1, CO, Cin, st));
+    TRY(relayout_weight_wino4(a->conv2_w, w2, CO, CO, st));
+    TRY(launch_gn_coeffs(a->x0, a->x1, a->C0, a->C1, a->B, HW, 32, a->gn1_w, a->gn1_b, nullptr, 0, 0, cA, cB, st));
     ResImgLaunch r;
-    r.x0 = a->x0; r.x1 = a->x1; r.C0 = a->C0; r.C1 = a->C1; r.B = a->B;
+    r.x0 = a->x0; r.x1 = a->x1; r.C0 = a->C0; r.C1 = a->C1; r.B = a->B; r.H = a->H;
     r.coefA1 = cA; r.coefB1 = cB;
     r.gn1_w = a->gn1_w; r.gn1_b = a->gn1_b; r.gn2_w = a->gn2_w; r.gn2_b = a->gn2_b;
     r.w1 = w1; r.b1 = a->conv1_b; r.w2 = w2; r.b2 = a->conv2_b;
@@ -1297,8 +1345,8 @@ extern "C" int dlpm_resblock_img_f32(const dlpm_resblock_args *a, float *scratch
     r.hbuf = hb; r.out = a->out; r.stats_out = reinterpret_cast<float2 *>(a->stats_out);
     if (a->skip_w) {
         ConvLaunch s;
-        s.src0 = a->x0; s.src1 = a->x1; s.C0 = a->C0; s.C1 = a->C1; s.B = a->B; s.Hin = s.Hout = 32; s.Win = s.Wout = 32;
-        s.ks = 1; s.Cout = 32; s.w = a->skip_w; s.bias = a->skip_b; s.out = sk; s.gemm = DLPM_GEMM_F32;
+        s.src0 = a->x0; s.src1 = a->x1; s.C0 = a->C0; s.C1 = a->C1; s.B = a->B; s.Hin = s.Hout = a->H; s.Win = s.Wout = a->W;
+        s.ks = 1; s.Cout = CO; s.w = a->skip_w; s.bias = a->skip_b; s.out = sk; s.gemm = DLPM_GEMM_F32;
         TRY(launch_conv_igemm(s, st));
         r.res = sk;
     } else {

@@ -185,6 +185,8 @@ class EvaluationManager:
             dump = ImageDump(self.gen_data_path, Cc, H, W, min(batch_size, data_to_generate), level=self.png_level,
                              threads=self.png_threads, overlap=self.overlap)
             remaining = data_to_generate
+            # (the chunks are sampled with declare_batch=False: the nets keep whatever batch their owner declared -- none by default --
+            #  so that a pixel depends neither on the chunking nor on the last chunk's size; tests/test_image_dump.py)
             if self.verbose:
                 print('generating {} images for fid computation'.format(remaining))
             ctx = stream() if stream is not None else _null()
@@ -193,7 +195,7 @@ class EvaluationManager:
                     while remaining > 0:                                           # EvaluationManager.py:181-193
                         n = min(batch_size, remaining)
                         try:
-                            self.gen_manager.generate(models, n, to_host=False, **kwargs)
+                            self.gen_manager.generate(models, n, to_host=False, declare_batch=False, **kwargs)
                         except (torch.cuda.OutOfMemoryError, RuntimeError) as e:
                             # 'auto' sized the chunk from free HBM with a reserve; should the FIRST chunk not fit after all, halve it
                             # (the pixels do not depend on the chunking inside dataset_stream()) instead of failing the dump

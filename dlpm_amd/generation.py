@@ -44,10 +44,17 @@ class GenerationManager:
             return out.cpu() if to_host else out
         raise _lib.DlpmError('GenerationManager expects samples on the GPU; there is no CPU fallback')
 
-    def generate(self, models, nsamples, get_sample_history=False, print_progression=False, to_host=True, **kwargs):
+    def generate(self, models, nsamples, get_sample_history=False, print_progression=False, to_host=True, declare_batch=True, **kwargs):
         assert nsamples > 0, 'nsamples must be greater than 0, got {}'.format(nsamples)
         tmp_kwargs = copy.deepcopy(self.kwargs)
         tmp_kwargs.update(kwargs)
+        if declare_batch:
+            # nets whose caller never declared a batch learn the one this call samples (UNetModel.declare_batch): the kernel choice stays a
+            # function of the layer and of a DECLARATION -- here "generate(models, nsamples)" -- never of the batch a launch happens to
+            # carry.  Callers that sample one evaluation in chunks declare once and pass declare_batch=False (EvaluationManager).
+            for m in (models or {}).values():
+                if hasattr(m, 'declare_batch'):
+                    m.declare_batch(nsamples)
         _, (data, y) = next(enumerate(self.original_data))
         size = list(data.size())
         size[0] = nsamples

@@ -132,8 +132,20 @@ class UNetModel(nn.Module):
         for a batch the caller declares for the whole configuration."""
         gen = {'auto': _lib.CONV_AUTO, 'f4': _lib.CONV_F4, 'f2': _lib.CONV_F2, 'igemm': _lib.CONV_IGEMM}[generation]
         self._conv_policy = (gen, int(dispatch_batch))
+        self._conv_policy_declared = True      # an explicit declaration: GenerationManager.generate leaves it alone
         if self._handle is not None:
             _lib.check(_lib.lib().dlpm_unet_set_conv_policy(self._handle, gen, int(dispatch_batch)))
+
+    def declare_batch(self, nsamples):
+        """The batch a caller that never declared one is about to sample (GenerationManager.generate: its `nsamples`): becomes the
+        dispatch batch of the current generation, unless set_conv_policy was called explicitly.  At a declared batch <= 256 the
+        16x16 / 8x8 levels of a 128-channel-multiple net run on 64- / 32-channel n-tiles instead of leaving CUs idle (round 6)."""
+        if getattr(self, '_conv_policy_declared', False):
+            return
+        gen = self._conv_policy[0] if getattr(self, '_conv_policy', None) else _lib.CONV_AUTO
+        self._conv_policy = (gen, int(nsamples))
+        if self._handle is not None:
+            _lib.check(_lib.lib().dlpm_unet_set_conv_policy(self._handle, gen, int(nsamples)))
 
     def set_gemm_policy(self, mode='auto'):
         """Which matrix pipe the 1x1 convolutions take (dlpm_unet_set_gemm_policy): 'bf16x3' (fp32 operands cut exactly

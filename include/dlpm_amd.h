@@ -467,6 +467,9 @@ int dlpm_resblock_small_f32(const dlpm_resblock_args *args, float *scratch_dev, 
  * inside (conv_wino4.hip: k_resblock_wino4_img).  Same argument struct: C0 + C1 in {32, 64, 96} (multiples of 8), H = W = 32, conv1_w [32][C0+C1][3][3],
  * conv2_w [32][32][3][3], ss rows scale (32) | shift (32), skip_w [32][C0+C1][1][1] required unless C0 + C1 = 32, out NHWC [B,32,32,32],
  * stats_out optional [B][4][32][2]: (mean, centred sum of squares) per 256-pixel quadrant and channel, the layout the convolution kernels emit.
+ * H = W = 16 selects the second shape: 64 output channels on 16x16 images (k_resblock_wino4_img16; C0 + C1 in {32, 64, 96, 128}, multiples of 16,
+ * conv1_w [64][C0+C1][3][3], conv2_w [64][64][3][3], ss rows scale (64) | shift (64), skip_w required unless C0 + C1 = 64, out [B,16,16,64],
+ * stats_out optional [B][64][2] per image); its intermediate stays in LDS and it rounds differently from the separate launches (K split in two).
  * GroupNorm-1's coefficients are computed from the activations by a launch in front (the UNet plan hands the kernel its producers' statistics instead).
  * scratch_floats >= dlpm_resblock_img_scratch_floats(B, C0 + C1).  Bit-identical to the separate launches (convolution, coefficients, convolution). */
 int64_t dlpm_resblock_img_scratch_floats(int64_t B, int32_t Cin);

@@ -978,7 +978,7 @@ def test_resblock_whole_image_is_bit_identical_to_the_separate_launches():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
     for v in ('1', '0'):
-        e = dict(os.environ, DLPM_RES_IMG=v)
+        e = dict(os.environ, DLPM_RES_IMG=v, DLPM_RES_IMG16='0')   # (the 16x16 shape splits K over wave pairs: its own rounding, off in both)
         r = subprocess.run([sys.executable, '-c', _MNIST_NET_DIGEST_SCRIPT, root], env=e, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         out[v] = r.stdout.strip().splitlines()[-1]
@@ -1093,6 +1093,67 @@ def test_fused_small_resblock_vs_reference(cin, hs):
     big = torch.cat([x[2:3], x, x[0:1]])
     gb, _ = run(big, torch.cat([ss[2:3], ss, ss[0:1]]))
     assert torch.equal(gb[1:4], got) and torch.equal(gb[0], got[2]) and torch.equal(gb[4], got[0])
+
+
+@pytest.mark.parametrize('cin', [64, 128, 96])
+def test_whole_image_resblock_16x16_vs_reference(cin):
+    """Round 6: k_resblock_wino4_img16 (a whole 64-channel ResBlock of a 16x16 image in one launch: the intermediate stays in LDS, the K loop is
+    split over wave pairs) against the reference's ResBlock (unet.py:105-196) on the F14 fixtures -- 64 -> 64 with the identity skip, 128
+    (= 64 | 64) and 96 (= 64 | 32) -> 64 with the 1x1 skip convolution -- its per-image statistics, and bit-independence of the batch."""
+    import ctypes as C
+    import small_block_weights as sbw
+    from oracle import nets
+    f = golden('f14_blocks16')
+    tag = 'res_c%d_o64_h16_' % cin
+    sd = sbw.res_fine_state(cin, 64, 16)
+    assert sbw.digest(sd) == bytes(f[tag + 'digest']).hex()
+    x, emb = sbw.res_fine_input(cin, 16, 2)
+    assert sbw.input_digest(x, emb) == bytes(f[tag + 'xdigest']).hex()
+    want = f[tag + 'y']
+    ss = torch.nn.functional.linear(nets.silu(emb), sd['emb_layers.1.weight'], sd['emb_layers.1.bias'])
+    L, st = _lib.lib(), _lib.stream_ptr()
+
+    def run(xb, ssb):
+        B = xb.shape[0]
+        xh = _dev(nhwc(xb))
+        keep = [xh]
+        a = _lib.ResBlockArgs()
+        if cin > 64:
+            x0, x1 = _dev(xh[..., :64]), _dev(xh[..., 64:])
+            keep += [x0, x1]
+            a.x0, a.x1, a.C0, a.C1 = x0.data_ptr(), x1.data_ptr(), 64, cin - 64
+        else:
+            a.x0, a.x1, a.C0, a.C1 = xh.data_ptr(), None, 64, 0
+        a.B, a.H, a.W = B, 16, 16
+        w = {k: _dev(v) for k, v in sd.items()}
+        a.gn1_w, a.gn1_b = w['in_layers.0.weight'].data_ptr(), w['in_layers.0.bias'].data_ptr()
+        a.conv1_w, a.conv1_b = w['in_layers.2.weight'].data_ptr(), w['in_layers.2.bias'].data_ptr()
+        ssd = _dev(ssb)
+        a.ss, a.ss_stride = ssd.data_ptr(), 128
+        a.gn2_w, a.gn2_b = w['out_layers.0.weight'].data_ptr(), w['out_layers.0.bias'].data_ptr()
+        a.conv2_w, a.conv2_b = w['out_layers.3.weight'].data_ptr(), w['out_layers.3.bias'].data_ptr()
+        if cin > 64:
+            a.skip_w, a.skip_b = w['skip_connection.weight'].data_ptr(), w['skip_connection.bias'].data_ptr()
+        out = torch.empty(B, 16, 16, 64, device=DEV)
+        stats = torch.empty(B, 64, 2, device=DEV)
+        a.out, a.stats_out = out.data_ptr(), stats.data_ptr()
+        n = L.dlpm_resblock_img_scratch_floats(B, cin)
+        scratch = torch.empty(n, device=DEV)
+        _lib.check(L.dlpm_resblock_img_f32(C.byref(a), scratch.data_ptr(), n, st))
+        torch.cuda.synchronize()
+        return nchw(out).cpu(), stats.cpu()
+
+    got, stats = run(x, ss)
+    err = np.abs(got.numpy() - want).max()
+    print('whole-image ResBlock %d -> 64 at 16x16: max |hip - reference| = %.3g (|y| max %.3g)' % (cin, err, np.abs(want).max()))
+    assert err < 2e-5 * max(1.0, np.abs(want).max())
+    g64 = got.double()
+    assert (stats[..., 0].double() - g64.mean(dim=(2, 3))).abs().max() < 1e-5
+    m2 = ((g64 - g64.mean(dim=(2, 3), keepdim=True)) ** 2).sum(dim=(2, 3))
+    assert ((stats[..., 1].double() - m2).abs() / (1 + m2)).max() < 1e-5
+    big = torch.cat([x[1:2], x, 0.5 * x[0:1]])
+    gb, _ = run(big, torch.cat([ss[1:2], ss, ss[0:1] + 0.1]))
+    assert torch.equal(gb[1:3], got) and torch.equal(gb[0], got[1])
 
 
 @pytest.mark.parametrize('cin', [32, 64, 96])

@@ -155,7 +155,7 @@ def test_evaluation_manager_dumps_the_chunks_it_generates(tmp_path, overlap):
     method2 = dlpm_amd.GenerativeLevyProcess(1.7, 'cuda', 6, rescale_timesteps=True, seed=3)
     gm2 = dlpm_amd.GenerationManager(method2, dlpm_amd.ShapeProbe(shape), True, reverse_steps=6, clamp_a=10, clamp_eps=50)
     with method2.dataset_stream():
-        want = oimg.to_rgb8(gm2.generate({'default': net}, 11))
+        want = oimg.to_rgb8(gm2.generate({'default': net}, 11, declare_batch=False))   # (the dump path declares no batch either)
     assert np.array_equal(got, want)                       # chunking-invariant and bit-identical pixels
     assert got.std() > 1                                   # not a constant image
     assert method.calls == 1                               # one dataset = one stream

@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=256)
 ap.add_argument('--cin', type=int, default=32)
 ap.add_argument('--reps', type=int, default=100)
+ap.add_argument('--h16', action='store_true', help='the 16x16 / 64-channel shape (k_resblock_wino4_img16); --cin 64 | 128 | 96')
 args = ap.parse_args()
 L = _lib.lib()
 HAVE = hasattr(L, 'dlpm_debug_phases')
@@ -24,23 +25,24 @@ if HAVE:
     L.dlpm_debug_phases.restype = C.c_int
     L.dlpm_debug_phases.argtypes = [C.POINTER(C.c_ulonglong * 32)]
 B, cin, DEV = args.batch, args.cin, 'cuda'
-c0 = {32: 32, 64: 32, 96: 64}[cin]
+HS, CO = (16, 64) if args.h16 else (32, 32)
+c0 = ({64: 64, 128: 64, 96: 64} if args.h16 else {32: 32, 64: 32, 96: 64})[cin]
 g = torch.Generator(device=DEV).manual_seed(1)
-x0 = torch.randn(B, 32, 32, c0, device=DEV, generator=g)
-x1 = torch.randn(B, 32, 32, cin - c0, device=DEV, generator=g) if cin > c0 else None
+x0 = torch.randn(B, HS, HS, c0, device=DEV, generator=g)
+x1 = torch.randn(B, HS, HS, cin - c0, device=DEV, generator=g) if cin > c0 else None
 P = lambda *s: torch.randn(*s, device=DEV, generator=g)
 a = _lib.ResBlockArgs()
 a.x0, a.x1, a.C0, a.C1 = x0.data_ptr(), x1.data_ptr() if x1 is not None else None, c0, cin - c0
-a.B, a.H, a.W = B, 32, 32
-keep = dict(g1w=1 + 0.1 * P(cin), g1b=0.1 * P(cin), w1=P(32, cin, 3, 3) / (9 * cin) ** 0.5, b1=0.1 * P(32), ss=0.3 * P(B, 64), g2w=1 + 0.1 * P(32),
-            g2b=0.1 * P(32), w2=P(32, 32, 3, 3) / 17.0, b2=0.1 * P(32), sw=P(32, cin, 1, 1) / cin ** 0.5, sb=0.1 * P(32))
+a.B, a.H, a.W = B, HS, HS
+keep = dict(g1w=1 + 0.1 * P(cin), g1b=0.1 * P(cin), w1=P(CO, cin, 3, 3) / (9 * cin) ** 0.5, b1=0.1 * P(CO), ss=0.3 * P(B, 2 * CO), g2w=1 + 0.1 * P(CO),
+            g2b=0.1 * P(CO), w2=P(CO, CO, 3, 3) / (9 * CO) ** 0.5, b2=0.1 * P(CO), sw=P(CO, cin, 1, 1) / cin ** 0.5, sb=0.1 * P(CO))
 a.gn1_w, a.gn1_b, a.conv1_w, a.conv1_b = (keep[k].data_ptr() for k in ('g1w', 'g1b', 'w1', 'b1'))
-a.ss, a.ss_stride = keep['ss'].data_ptr(), 64
+a.ss, a.ss_stride = keep['ss'].data_ptr(), 2 * CO
 a.gn2_w, a.gn2_b, a.conv2_w, a.conv2_b = (keep[k].data_ptr() for k in ('g2w', 'g2b', 'w2', 'b2'))
-if cin > 32:
+if cin != CO:
     a.skip_w, a.skip_b = keep['sw'].data_ptr(), keep['sb'].data_ptr()
-out = torch.empty(B, 32, 32, 32, device=DEV)
-stats = torch.empty(B, 4, 32, 2, device=DEV)
+out = torch.empty(B, HS, HS, CO, device=DEV)
+stats = torch.empty(B, 4, 64, 2, device=DEV)
 a.out, a.stats_out = out.data_ptr(), stats.data_ptr()
 n = L.dlpm_resblock_img_scratch_floats(B, cin)
 scratch = torch.empty(n, device=DEV)
