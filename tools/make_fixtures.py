@@ -484,9 +484,12 @@ def f5_bounded_unet_trajectories():
              ('f5_traj_unet_cifar_clip_T1000', 1000, 2, 100, 'EPSILON', 1.0, 'cifar', 3, 32, 1.7, 10, 50),
              # BASELINE configs[1]: the mnist.yml UNet (mc = 32, mult (1, 2, 2, 2), attention at 16x16 and 8x8) at 32x32, T = 1000,
              # alpha = 1.7, the config's clamps -- on the GPU its 8x8 / 4x4 levels are the fused small-image blocks
-             ('f5_traj_unet_mnist_clip_T1000', 1000, 2, 100, 'EPSILON', 1.0, 'mnist', 1, 32, 1.7, 20, 200),
+             # (round 6: head convolution x 5 -- the x 1 run had sensitivity 0.13, i.e. a network wrong by 7e-4 relative still passed 1e-4;
+             #  tools/search_fixture_sensitivity.py: x 4 0.42 / 77 % in range, x 5 0.59 / 73.7 %, x 6 0.80 / 69 %)
+             ('f5_traj_unet_mnist_clip_T1000', 1000, 2, 100, 'EPSILON', 5.0, 'mnist', 1, 32, 1.7, 20, 200),
              # BASELINE configs[4]'s per-GPU net: the CIFAR architecture at 64x64 (dlpm_amd/configs/celeba64.yml), alpha = 1.8, B = 1
-             ('f5_traj_unet_celeba64_clip_T1000', 1000, 1, 100, 'EPSILON', 1.0, 'cifar', 3, 64, 1.8, 10, 50)]
+             # (round 6: head convolution x 2.5 -- x 1: sensitivity 0.22; x 2 0.39 / 76.8 %, x 2.5 0.40 / 72.3 %, x 3 0.66 / 68.0 %, x 4 0.67 / 61.6 %)
+             ('f5_traj_unet_celeba64_clip_T1000', 1000, 1, 100, 'EPSILON', 2.5, 'cifar', 3, 64, 1.8, 10, 50)]
     # Round 5: the headline configuration at B = 8 as well (B = 2 was the only batch the cifar10.yml net had been compared at; recorded
     # every 250th state to keep the file small), and -- for EVERY case -- how informative the fixture is: the same reference run is
     # repeated with the network's output multiplied by (1 + 1e-4 N(0, 1)) (its own seeded generator: the sampler's streams are
@@ -534,6 +537,8 @@ def f5_bounded_unet_trajectories():
         print('%s: |x| max %.4g, %.1f %% of the final pixels inside (-1, 1), max |state| over the run %.4g'
               % (name, float(x.abs().max()), 100 * inside, float(hist.abs().max())))
         assert inside >= 0.5, name
+        if 'mnist' in name or 'celeba64' in name:      # informative fixtures for the two configs that were weakest
+            assert inside >= 0.7, name
         path = os.path.join(OUT, name + '.npz')
         if os.path.exists(path):   # a fixture that is already committed keeps its trajectory: this run must reproduce it bit for bit
             old = np.load(path)
@@ -545,6 +550,8 @@ def f5_bounded_unet_trajectories():
         sens_state = float((xp - x).abs().max()) / REL
         print('    sensitivity to a %.0e relative perturbation of the network output: post-processed pixels %.3g, final state %.3g'
               % (REL, sens, sens_state))
+        if 'mnist' in name or 'celeba64' in name:
+            assert sens >= 0.4, name
         extra = {}
         if T == 1000 and 900 % every != 0:
             extra['state_900'] = hist[900]   # where the oracle's CPU test picks the run up (its last 100 steps)
