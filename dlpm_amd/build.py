@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, '_obj')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIB_DIR, 'libdlpm_amd.so')
-SOURCES = ['host.cpp', 'png.cpp', 'images.hip', 'noise.hip', 'conv_igemm.hip', 'conv_split.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_direct.hip', 'head_fused.hip', 'groupnorm.hip', 'attention.hip', 'block_small.hip',
+SOURCES = ['host.cpp', 'png.cpp', 'images.hip', 'noise.hip', 'conv_igemm.hip', 'conv_split.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_splitk.hip', 'conv_direct.hip', 'head_fused.hip', 'groupnorm.hip', 'attention.hip', 'block_small.hip',
            'embed.hip', 'unet.hip', 'mlp.hip', 'sampler.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off', '-Wall', '-Wno-unused-function']

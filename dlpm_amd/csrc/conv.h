@@ -40,6 +40,10 @@ struct ConvLaunch {
     int gen = 0;
     int64_t dispatch_B = 0;
     int gemm = 0;                   // DLPM_GEMM_AUTO / _F32 / _BF16X3: which matrix pipe the 1x1 and downsampling convolutions take (conv_split.hip)
+    // Round 6, split-K (conv_ksplit_for): > 1 = the launch runs `ksplit` copies of its grid, copy s walking the input channels
+    // [s Cin / ksplit, (s + 1) Cin / ksplit) and writing its partial outputs to out + s B Hout Wout Cout (bias / residual / statistics
+    // are null in such a launch: launch_splitk_reduce adds them).  Taken by the narrow F(4x4) shapes and the F(2x2) kernel only.
+    int ksplit = 0;
     // Optional fused GroupNorm statistics of the OUTPUT: per (image, pixel tile, channel) the
     // pair (mean, centred sum of squares) over the tile's pixels, written by the MFMA kernels'
     // epilogue when the tile lies inside one image.  [B][HW/tile][Cout] float2 with tile =
@@ -137,6 +141,16 @@ int64_t split_weight_floats(int Cout, int Cin, int taps);
 int relayout_weight_split(const float *oihw_dev, void *dst_dev, int Cout, int Cin, int taps, hipStream_t st);
 // pixels behind one stats_out partial for this launch (0: the launch cannot emit statistics)
 int conv_stats_pixels(const ConvLaunch &c);
+// Split-K factor of a 3x3 stride-1 launch under the AUTO policy with a DECLARED batch (1: none): when the kernel this layer takes would
+// put workgroups on at most half of the 256 CUs at that batch (8x8 / 4x4 levels at batch <= 128), its K loop -- 32-64 serial phases --
+// is cut over 2 / 4 / 8 grid copies.  A function of the layer and the declaration only.  DLPM_KSPLIT=0 switches it off.
+int conv_ksplit_for(const ConvLaunch &c);
+int wino4_launch_nq(const ConvLaunch &c);      // the n-tile width launch_conv_wino4 would use
+int64_t wino_grid_at(const ConvLaunch &c, int64_t B);   // workgroups of the F(2x2) kernel at batch B
+int wino_chunk_channels(const ConvLaunch &c);            // input channels per chunk of its K loop (8; 16 under DLPM_WINO_KC=16)
+// out = bias + sum_s part[s] (+ residual [res0 | res1]) over n = B Hout Wout pixels x Cout channels, partials summed in ascending s
+int launch_splitk_reduce(const float *part, int S, int64_t npix, int Cout, const float *bias, const float *res0, const float *res1, int R0,
+                         float *out, hipStream_t st);
 // non-MFMA shapes: the stem kernel when it applies, the generic direct kernel otherwise
 inline int launch_conv_fallback(const ConvLaunch &L, hipStream_t st) {
     if (L.in_nchw && !L.out_nchw && L.ks == 3 && L.stride == 1 && !L.ups && L.C1 == 0 && L.Cout % 4 == 0 && !L.coefA &&

@@ -1151,6 +1151,7 @@ int launch_conv_stem(const ConvLaunch &c, hipStream_t st) {
 
 int conv_stats_pixels(const ConvLaunch &c) {
     int a, b, n;
+    if (conv_ksplit_for(c) > 1) return 0;      // a split-K launch emits partial outputs: no statistics (the consumer's GroupNorm reads the tensor)
     if (c.in_nchw) return stem_stats_ok(c) ? 1024 : 0;
     // same order as launch_conv_igemm's dispatch: a launch that carries split weights runs k_conv_split whatever else it carries
     // (k_conv_split: per 128-pixel tile through the 4-wave row epilogue, or per whole 8x8 image from the registers of the 8 / 16-wave shapes)

@@ -78,12 +78,24 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
     const int wn = MT == 64 ? (wave & 1) : (NW == 8 ? (wave & 3) : (wave & 1)), wm = MT == 64 ? ((wave >> 1) & 1) : 0;
     const int W = p.Wout, H = p.Hout, TW = W >> 1, TH = H >> 1;
     const int Ws = UPS ? (W >> 1) : W, Hs = UPS ? (H >> 1) : H;
-    const int Cin = p.C0 + p.C1, nch = Cin / KC;
+    const int Cin = p.C0 + p.C1;
+    int nch = Cin / KC, kb = 0;
+    unsigned bid = blockIdx.x, nblk = gridDim.x;      // (unsigned, like the grid built-ins: the prologue's divisions stay what they were)
+    if (p.ksplit > 1) {
+        // split-K (round 6): grid copy ks walks chunks [kb, kb + nch) and writes its partial outputs behind those of the copies before
+        // it; such a launch carries no bias / residual / statistics (launch_splitk_reduce adds them)
+        nblk = gridDim.x / p.ksplit;
+        const int ks = (int)(blockIdx.x / nblk);
+        bid = blockIdx.x - (unsigned)ks * nblk;
+        nch /= p.ksplit;
+        kb = ks * nch;
+        p.out += (int64_t)ks * p.B * H * W * p.Cout;
+    }
     // n-tile-major grid: all workgroups in flight stream the SAME half of the Winograd-domain weights (2.1 MB for a
     // 256 x 256 layer: fits the 4-MB L2 of an XCD; both halves together do not)
     const int ntn = p.Cout / NQ;
-    const int nmb = gridDim.x / ntn;
-    const int mb = blockIdx.x % nmb, n0 = (blockIdx.x / nmb) * NQ;
+    const int nmb = nblk / ntn;
+    const int mb = bid % nmb, n0 = (bid / nmb) * NQ;
     int img0, ty0, tx0, blk_in_img = 0;
     if (nimg == 1) {
         const int bpr = TW / bw, bpi = (TH / bh) * bpr;
@@ -115,10 +127,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
     const bool has_coef = p.coefA != nullptr;
     const int cf_img = tid / (2 * NQD), cf_isb = (tid / NQD) & 1;
     const bool cf_mine = has_coef && tid < nimg * 2 * NQD;
-    const float *cf_base = has_coef ? ((cf_isb ? p.coefB : p.coefA) + (int64_t)min(img0 + cf_img, p.B - 1) * Cin + squad * 4) : nullptr;
+    const float *cf_base = has_coef ? ((cf_isb ? p.coefB : p.coefA) + (int64_t)min(img0 + cf_img, p.B - 1) * Cin + kb * KC + squad * 4) : nullptr;
     float4 xr[QNIT], cfr = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_raw = [&](int chunk) {
-        const int c = chunk * KC + squad * 4;
+        const int c = (kb + chunk) * KC + squad * 4;
         const bool first = c < p.C0;
         const float *sb = first ? p.src0 + c : p.src1 + (c - p.C0);
         const int ld = first ? p.C0 : p.C1;
@@ -197,7 +209,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
 
     // ---- weight stream of this wave: Wf[nb][ph][chunk][8 positions][lane][4]
     const float4 *__restrict__ wbase = reinterpret_cast<const float4 *>(p.w_wino) + lane;
-    int64_t woff = (int64_t)(((n0 >> 5) + wn) * 2 + ph) * nch * 8 * NJQ * 64;
+    int64_t woff = ((int64_t)(((n0 >> 5) + wn) * 2 + ph) * (Cin / KC) + kb) * 8 * NJQ * 64;
     constexpr int AHEAD = QRING - 1;
     float4 bq[QRING];
     const float *asrc = V + (ph * 8) * MT * PVLD + (wm * 32 + l31) * PVLD + kh * (KC / 2);
@@ -214,7 +226,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) k_conv3x3_wino_q(Con
     float4 xr1[QNIT], cfr1 = make_float4(0.f, 0.f, 0.f, 0.f), cfr2 = cfr1;
     load_raw(0);
     {
-        const int c = min(1, last) * KC + squad * 4;
+        const int c = (kb + min(1, last)) * KC + squad * 4;
         const bool first = c < p.C0;
         const float *sb = first ? p.src0 + c : p.src1 + (c - p.C0);
         const int ld = first ? p.C0 : p.C1;
@@ -555,10 +567,27 @@ int launch_conv_wino(const ConvLaunch &c, hipStream_t st) {
     if (shmem < epi) shmem = epi;
     const int64_t tiles = (int64_t)c.B * (c.Hout / 2) * (c.Wout / 2);
     const int64_t mblocks = nimg == 1 ? tiles / mt : ceil_div(c.B, nimg);
-    fn<<<(unsigned)(mblocks * (c.Cout / nq)), nw * 64, shmem, st>>>(c, bh, bw, nimg);
+    const int ks = c.ksplit > 1 ? c.ksplit : 1;
+    if (ks > 1 && (c.bias || c.res0 || c.stats_out || ((c.C0 + c.C1) / kc) % ks != 0)) {
+        set_error("launch_conv_wino: a split-K launch carries no bias / residual / statistics and divides its chunks evenly");
+        return DLPM_ERR_ARG;
+    }
+    fn<<<(unsigned)(mblocks * (c.Cout / nq) * ks), nw * 64, shmem, st>>>(c, bh, bw, nimg);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }
+
+int64_t wino_grid_at(const ConvLaunch &c, int64_t B) {
+    int bh, bw, nimg;
+    if (!wino_geometry(c, &bh, &bw, &nimg)) return 0;
+    const int mt = wino_tiles(c), nw = wino_waves(c);
+    const int nq = nw == 8 ? 4096 / mt : 64;
+    const int64_t tiles = B * (c.Hout / 2) * (c.Wout / 2);
+    const int64_t mblocks = nimg == 1 ? tiles / mt : ceil_div(B, (int64_t)nimg);
+    return mblocks * (c.Cout / nq);
+}
+
+int wino_chunk_channels(const ConvLaunch &c) { return wino_kc_for(c.Cout); }
 
 int64_t wino_weight_floats(int Cout, int Cin) {
     // + AHEAD groups of padding: the prefetch ring reads past the last group

@@ -180,11 +180,25 @@ __global__ void __launch_bounds__((NW + (NW == 8 ? 0 : NW == 4 ? 3 : 2)) * 64, N
     const int li = lane & 15, lk = lane >> 4;
     const int W = p.Wout, H = p.Hout, TW = W >> 2, TH = H >> 2;
     const int Ws = UPS ? (W >> 1) : W, Hs = UPS ? (H >> 1) : H;
-    const int Cin = p.C0 + p.C1, nch = Cin / F4_KC;
+    const int Cin = p.C0 + p.C1;
+    int nch = Cin / F4_KC, kb = 0;
+    unsigned bid = blockIdx.x, nblk = gridDim.x;      // (unsigned, like the grid built-ins: the prologue's divisions stay what they were)
+    if constexpr (HELP) {
+        // split-K (round 6, narrow shapes only: the 8-wave instantiations compile without it): grid copy ks walks chunks [kb, kb + nch) and
+        // writes its partial outputs behind those of the copies before it (the launch carries no bias / residual / statistics)
+        if (p.ksplit > 1) {
+            nblk = gridDim.x / p.ksplit;
+            const int ks = (int)(blockIdx.x / nblk);
+            bid = blockIdx.x - (unsigned)ks * nblk;
+            nch /= p.ksplit;
+            kb = ks * nch;
+            p.out += (int64_t)ks * p.B * H * W * p.Cout;
+        }
+    }
     // n-tile-major grid: all workgroups in flight stream the same 128-channel slab of the Winograd-domain weights
     const int ntn = p.Cout / F4_NQ;
-    const int nmb = gridDim.x / ntn;
-    const int mb = blockIdx.x % nmb, n0 = (blockIdx.x / nmb) * F4_NQ;
+    const int nmb = nblk / ntn;
+    const int mb = bid % nmb, n0 = (bid / nmb) * F4_NQ;
     int img0, ty0, tx0, blk_in_img = 0;
     if (nimg == 1) {
         const int bpr = TW / bw, bpi = (TH / bh) * bpr;
@@ -224,10 +238,10 @@ __global__ void __launch_bounds__((NW + (NW == 8 ? 0 : NW == 4 ? 3 : 2)) * 64, N
     const bool has_coef = p.coefA != nullptr;
     const int cf_img = tid >> 2, cf_isb = (tid >> 1) & 1;
     const bool cf_mine = has_coef && tid < nimg * 4;
-    const float *cf_base = has_coef ? ((cf_isb ? p.coefB : p.coefA) + (int64_t)min(img0 + cf_img, p.B - 1) * Cin + squad * 4) : nullptr;
+    const float *cf_base = has_coef ? ((cf_isb ? p.coefB : p.coefA) + (int64_t)min(img0 + cf_img, p.B - 1) * Cin + kb * F4_KC + squad * 4) : nullptr;
     float4 xr[QN], cfr = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_raw_into = [&](float4 (&dst)[QN], int chunk) {
-        const int c = chunk * F4_KC + squad * 4;
+        const int c = (kb + chunk) * F4_KC + squad * 4;
         const bool first = c < p.C0;
         const float *sb = first ? p.src0 + c : p.src1 + (c - p.C0);
         const int ld = first ? p.C0 : p.C1;
@@ -344,7 +358,7 @@ __global__ void __launch_bounds__((NW + (NW == 8 ? 0 : NW == 4 ? 3 : 2)) * 64, N
     // ---- weight stream of this wave: Wf[ntile][wave][phase][18 position pairs][lane][4], contiguous per wave
     // (wave-uniform pointer + lane: the per-fragment advance is scalar arithmetic)
     const float4 *__restrict__ wp = reinterpret_cast<const float4 *>(p.w_wino4) +
-                                    (int64_t)((n0 / F4_NQ) * NW + __builtin_amdgcn_readfirstlane(wave)) * nch * 18 * 64;
+                                    ((int64_t)((n0 / F4_NQ) * NW + __builtin_amdgcn_readfirstlane(wave)) * (Cin / F4_KC) + kb) * 18 * 64;
     constexpr int AHEAD = F4_RING - 1;
     float4 bq[F4_RING];
     // A fragments: lane (li = tile, lk) reads channels 2 lk, 2 lk + 1 of the phase (= k index lk of the two k-steps) for both
@@ -1868,6 +1882,7 @@ static int wino4_nq_for(const ConvLaunch &c) {
 }
 
 bool wino4_geometry(const ConvLaunch &c, int *bh, int *bw, int *nimg) { return wino4_geometry_nq(c, wino4_nq_for(c), bh, bw, nimg); }
+int wino4_launch_nq(const ConvLaunch &c) { return wino4_nq_for(c); }
 
 // dispatch policy (a function of the layer and of ConvLaunch::gen / dispatch_B, never of the batch in this launch:
 // the generations round differently and a sample must not depend on how its batch was sharded or chunked):
@@ -1937,9 +1952,18 @@ static int launch_conv_wino4_nq(const ConvLaunch &c, int nq, int bh, int bw, int
         const int r = ensure_dynamic_lds(reinterpret_cast<const void *>(fn), 160 * 1024);
         if (r != DLPM_OK) return r;
         const size_t lds = (size_t)(2 * F4_VBUF + 2 * F4_RAWBUF_N + 2 * F4_CFS) * sizeof(float);
-        fn<<<(unsigned)(mblocks * (c.Cout / nq)), (nq == 64 ? 7 : 4) * 64, lds, st>>>(c, bh, bw, nimg);
+        const int ks = c.ksplit > 1 ? c.ksplit : 1;
+        if (ks > 1 && (c.bias || c.res0 || c.stats_out || ((c.C0 + c.C1) / F4_KC) % ks != 0)) {
+            set_error("launch_conv_wino4: a split-K launch carries no bias / residual / statistics and divides its chunks evenly");
+            return DLPM_ERR_ARG;
+        }
+        fn<<<(unsigned)(mblocks * (c.Cout / nq) * ks), (nq == 64 ? 7 : 4) * 64, lds, st>>>(c, bh, bw, nimg);
         DLPM_LAUNCH_CHECK();
         return DLPM_OK;
+    }
+    if (c.ksplit > 1) {
+        set_error("launch_conv_wino4: split-K is a narrow-shape launch");
+        return DLPM_ERR_ARG;
     }
     const int RHp = c.ups ? 2 * bh + 2 : 4 * bh + 2, RWp = c.ups ? 2 * bw + 2 : 4 * bw + 2;
     const bool small = nimg * RHp * RWp <= F4_NT;      // two staging items per thread cover the patch

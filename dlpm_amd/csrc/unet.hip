@@ -133,7 +133,7 @@ void plan_stats(const dlpm_unet *u, Bump &ws, Tensor4 &t, const ConvW &c, int B,
     t.stats_px = 0;
     if (off || (!c.use_igemm && !stem)) return;
     ConvLaunch L;
-    L.w_wino = c.w_wino; L.w_wino4 = c.w_wino4; L.w_split = c.w_split; L.ks = c.ks; L.stride = stride; L.ups = ups; L.Hout = t.H; L.Wout = t.W; L.Cout = c.cout;
+    L.w_wino = c.w_wino; L.w_wino4 = c.w_wino4; L.w_wino4_n64 = c.w_wino4_n64; L.w_wino4_n32 = c.w_wino4_n32; L.w_split = c.w_split; L.ks = c.ks; L.stride = stride; L.ups = ups; L.Hout = t.H; L.Wout = t.W; L.Cout = c.cout;
     L.Hin = ups ? t.H / 2 : t.H * stride; L.Win = ups ? t.W / 2 : t.W * stride;
     L.C0 = C0; L.C1 = c.cin - C0; L.B = B;
     L.in_nchw = stem ? 1 : 0;
@@ -383,6 +383,24 @@ int prep_conv(dlpm_unet *u, ConvW &c, int C0, int boundary) {  // boundary: 0 no
     return relayout_weight(src, c.w_dev, c.cout, c.cin, c.ks, c.use_igemm, nullptr);
 }
 
+// the launch descriptor with the net's policy and this convolution's weight layouts attached
+void attach_conv(const dlpm_unet *u, const ConvW &c, ConvLaunch &L) {
+    policy_of(u, L);
+    L.w = c.w_dev;
+    L.w_frag = c.w_frag;
+    L.w_wino = c.w_wino;
+    L.w_wino4 = c.w_wino4;
+    L.w_wino4_n64 = c.w_wino4_n64;
+    L.w_wino4_n32 = c.w_wino4_n32;
+    L.w_small = c.w_small;
+    L.w_taps = c.w_taps;
+    L.w_hfused = c.w_hfused;
+    L.w_split = c.w_split;
+    L.ws_gemm = (c.ks == 1 && c.w_frag) ? 1 : 0;
+    L.ks = c.ks;
+    L.Cout = c.cout;
+}
+
 int run_conv(const dlpm_unet *u, const ConvW &c, ConvLaunch L, hipStream_t st, const HeadUpdate *hu = nullptr, float *head_scratch = nullptr) {
     policy_of(u, L);
     L.w = c.w_dev;
@@ -421,6 +439,31 @@ struct Ctx {
     const HeadUpdate *hu = nullptr;   // the sampler's reverse update, fused into the head convolution (dlpm_unet_forward_update)
     bool dry() const { return ws.dry; }
 };
+
+// Split-K factor of a 3x3 stride-1 convolution of the plan (conv_splitk.hip: conv_ksplit_for): a function of the layer and the declared batch
+int ksplit_of(const Ctx &cx, const ConvW &c, ConvLaunch L) {
+    attach_conv(cx.u, c, L);
+    L.bias = nullptr;
+    return conv_ksplit_for(L);
+}
+// ... and the launch: S grid copies write their partial outputs into a workspace buffer, launch_splitk_reduce adds bias / residual.  (The
+// caller's dry run reserves the buffer with reserve_ksplit at the point where this runs.)
+int run_conv3(Ctx &cx, const ConvW &c, const ConvLaunch &L) {
+    const int S = ksplit_of(cx, c, L);
+    if (S <= 1) return run_conv(cx.u, c, L, cx.st);
+    const int64_t npix = (int64_t)L.B * L.Hout * L.Wout;
+    float *part = cx.ws.alloc((int64_t)S * npix * c.cout);
+    ConvLaunch P = L;
+    P.bias = nullptr; P.res0 = nullptr; P.res1 = nullptr; P.R0 = 0; P.stats_out = nullptr; P.out = part; P.ksplit = S;
+    int rc = run_conv(cx.u, c, P, cx.st);
+    if (rc == DLPM_OK) rc = launch_splitk_reduce(part, S, npix, c.cout, L.bias, L.res0, L.res1, L.R0, L.out, cx.st);
+    cx.ws.release(part);
+    return rc;
+}
+void reserve_ksplit(Ctx &cx, const ConvW &c, const ConvLaunch &L) {     // dry run: the partial buffer's share of the workspace peak
+    const int S = ksplit_of(cx, c, L);
+    if (S > 1) cx.ws.release(cx.ws.alloc((int64_t)S * L.B * L.Hout * L.Wout * c.cout));
+}
 
 void release_res_temps(Ctx &cx, float *cA1, float *cB1, Tensor4 &h1, float *cA2, float *cB2, float *sk) {
     cx.ws.release(cA1);
@@ -511,6 +554,11 @@ int run_res(Ctx &cx, const Layer &L, Tensor4 x0, Tensor4 x1, Tensor4 *out) {
     out->p = o; out->C = Co; out->H = H; out->W = W;
     plan_stats(cx.u, cx.ws, *out, L.c2, B, Co, 1, 0);
     if (cx.dry()) {
+        ConvLaunch g;      // (geometry of the block's two 3x3 convolutions: what ksplit_of looks at)
+        g.C0 = C0; g.C1 = C1; g.B = B; g.Hin = g.Hout = H; g.Win = g.Wout = W;
+        reserve_ksplit(cx, L.c1, g);
+        g.C0 = Co; g.C1 = 0;
+        reserve_ksplit(cx, L.c2, g);
         release_res_temps(cx, cA1, cB1, h1, cA2, cB2, sk);
         return DLPM_OK;
     }
@@ -519,7 +567,7 @@ int run_res(Ctx &cx, const Layer &L, Tensor4 x0, Tensor4 x1, Tensor4 *out) {
     ConvLaunch a;
     a.src0 = x0.p; a.src1 = x1.p; a.C0 = C0; a.C1 = C1; a.B = B; a.Hin = a.Hout = H; a.Win = a.Wout = W;
     a.bias = u->params[L.c1.p_b].dev; a.coefA = cA1; a.coefB = cB1; a.act_silu = 1; a.out = h1.p; a.stats_out = h1.stats;
-    TRY(run_conv(u, L.c1, a, cx.st));
+    TRY(run_conv3(cx, L.c1, a));
     TRY(gn_any(h1, Tensor4(), B, G2, u->params[L.p_gn2_w].dev, u->params[L.p_gn2_b].dev, cx.embout,
                cx.uniform_t ? 0 : u->emb_total, L.emb_off, cA2, cB2, cx.st));   // row pitch 0: all samples read the one emb row
     ConvLaunch b;
@@ -534,7 +582,7 @@ int run_res(Ctx &cx, const Layer &L, Tensor4 x0, Tensor4 x1, Tensor4 *out) {
     } else {
         b.res0 = x0.p; b.res1 = x1.p; b.R0 = C0;
     }
-    TRY(run_conv(u, L.c2, b, cx.st));
+    TRY(run_conv3(cx, L.c2, b));
     release_res_temps(cx, cA1, cB1, h1, cA2, cB2, sk);
     return DLPM_OK;
 }
@@ -633,12 +681,13 @@ int run_seq(Ctx &cx, const std::vector<Layer> &seq, Tensor4 x0, Tensor4 x1, cons
                 o.W = up ? h.W * 2 : (h.W - 1) / 2 + 1;
                 o.p = cx.ws.alloc((int64_t)B * o.H * o.W * o.C);
                 plan_stats(cx.u, cx.ws, o, L.c1, B, h.C, up ? 1 : 2, up ? 1 : 0);
-                if (!cx.dry()) {
+                {
                     ConvLaunch a;
                     a.src0 = h.p; a.C0 = h.C; a.B = B; a.Hin = h.H; a.Win = h.W; a.Hout = o.H; a.Wout = o.W;
                     a.stride = up ? 1 : 2; a.ups = up ? 1 : 0;
                     a.bias = u->params[L.c1.p_b].dev; a.out = o.p; a.stats_out = o.stats;
-                    TRY(run_conv(u, L.c1, a, cx.st));
+                    if (cx.dry()) { if (up) reserve_ksplit(cx, L.c1, a); }
+                    else TRY(up ? run_conv3(cx, L.c1, a) : run_conv(u, L.c1, a, cx.st));
                 }
                 break;
             }

@@ -42,6 +42,29 @@ def test_unet_forward_matches_reference(name):
     assert np.abs(y2 - f['y_same_t']).max() < 1e-4
 
 
+@pytest.mark.parametrize('declared', [2, 64, 256])
+def test_cifar_unet_under_a_small_declared_batch_against_reference(declared):
+    """Round 6: under a small DECLARED batch the CIFAR net's 128-channel-multiple F(4x4) layers run on 64- / 32-channel
+    n-tiles and the launches that would still leave half the chip empty split their K loop over 2 / 4 / 8 grid copies (partial outputs +
+    launch_splitk_reduce; conv_splitk.hip).  The reference's own output (f6_unet_cifar) within the usual 2e-5 for each declaration, a
+    declaration is what decides (the SAME call under another declaration may differ in the last bits, under the same one it may not), and
+    a sample's bits do not depend on the batch of the CALL."""
+    f = golden('f6_unet_cifar')
+    net, _ = build_unet('cifar')
+    net.set_conv_policy('auto', declared)
+    x, t = torch.from_numpy(f['x']).to(DEV), torch.from_numpy(f['t']).to(DEV)
+    y = net(x, t)
+    err = (y.cpu() - torch.from_numpy(f['y'])).abs().max().item()
+    print('declared batch %d: max |hip - reference| = %.3g' % (declared, err))
+    assert err < 2e-5
+    assert torch.equal(net(x, t), y)
+    xb = torch.cat([x, x.flip(0), 0.5 * x, x[:1]])
+    tb = torch.cat([t, t.flip(0), t, t[:1]])
+    yb = net(xb, tb)
+    assert torch.equal(yb[:x.shape[0]], y) and torch.equal(yb[-1], y[0])
+    net.set_conv_policy('auto', 0)
+
+
 @pytest.mark.parametrize('env,bound', [({'DLPM_WINO_F4': '0'}, 1e-5), ({'DLPM_WINO_F4': '0', 'DLPM_NO_WINO': '1'}, 1e-5),
                                        ({}, 2e-5), ({'DLPM_WINO_VS': '1'}, 2e-5), ({'DLPM_WINO_SPEC': '1'}, 2e-5),
                                        ({'DLPM_NO_FUSED_BLOCKS': '1', 'DLPM_NO_HEAD_FUSED': '1'}, 2e-5), ({'DLPM_HEAD_F32': '1'}, 2e-5)],
