@@ -44,6 +44,7 @@ struct ConvLaunch {
     // [s Cin / ksplit, (s + 1) Cin / ksplit) and writing its partial outputs to out + s B Hout Wout Cout (bias / residual / statistics
     // are null in such a launch: launch_splitk_reduce adds them).  Taken by the narrow F(4x4) shapes and the F(2x2) kernel only.
     int ksplit = 0;
+    int pers_total = 0;             // persistent form of the 8-wave F(4x4) shape (DLPM_WINO4_PERSIST): tiles of the launch (the grid is one workgroup per CU)
     // Optional fused GroupNorm statistics of the OUTPUT: per (image, pixel tile, channel) the
     // pair (mean, centred sum of squares) over the tile's pixels, written by the MFMA kernels'
     // epilogue when the tile lies inside one image.  [B][HW/tile][Cout] float2 with tile =

@@ -143,8 +143,13 @@ __device__ __forceinline__ float2 f2sub(float2 x, float2 y) { return make_float2
 // the clock on that LDS traffic).  Y = A^T M A splits by rows of A^T: each wave of a pair turns its 18 positions into 16 partial outputs
 // per (tile, channel), hands the partials of the channel tile its PARTNER finalises over through LDS (one barrier pair, 128 KB: the
 // loop's buffers are dead by then) and runs the unchanged register epilogue on the other.
-template <bool UPS, int ABL = 0, int QN = F4_QNIT, int SPEC = 0, int VS = 0, int NW = 8>
+// PERS = 1 (round 6, the 8-wave shape): PERSISTENT workgroups -- the grid is one workgroup per CU and each walks the tiles wgid, wgid + gridDim.x,
+// ... of the n-tile-major order (all workgroups in flight still stream the same slab of weights); the tile body is unchanged.  What it
+// saves is the turnover between the 16 workgroups a CU runs per launch of the CIFAR net (teardown, dispatch, LDS allocation, kernel-argument
+// loads: ~4 us per round by the launch time against the sum of the workgroups' lives, profiles/r06/persistent_wino4/).
+template <bool UPS, int ABL = 0, int QN = F4_QNIT, int SPEC = 0, int VS = 0, int NW = 8, int PERS = 0>
 __global__ void __launch_bounds__((NW + (NW == 8 ? 0 : NW == 4 ? 3 : 2)) * 64, NW == 2 ? 2 : 1) k_conv3x3_wino4(ConvLaunch p_in, int bh_in, int bw_in, int nimg_in) {
+    static_assert(PERS == 0 || NW == 8, "persistent workgroups: the 8-wave shape");
     constexpr bool HELP = NW != 8;                                        // MFMA waves 0 .. NW-1 + helper waves NW .. NW+NH-1
     constexpr int NH = NW == 8 ? 0 : NW == 4 ? 3 : 2;
     constexpr int F4_NT = (NW + NH) * 64, F4_NQ = NW * 16;                // threads, channels (shadow the main shape's constants)
@@ -175,21 +180,31 @@ __global__ void __launch_bounds__((NW + (NW == 8 ? 0 : NW == 4 ? 3 : 2)) * 64, N
 #ifdef DLPM_PHASE_TIMING
     const long long _c0 = clock64(), _r0 = wall_clock64();   // shader cycles and 100-MHz ticks: their ratio is the clock the chip holds
 #endif
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef DLPM_PHASE_TIMING
+    long long _wait = 0;      // cycles this wave spends at the phase barrier (developer builds: slots 16 + wave)
+#endif
+    unsigned wgid = blockIdx.x;
+    const unsigned ngrid = PERS ? (unsigned)p.pers_total : gridDim.x;
+    do {      // (one trip unless PERS)
+    int tid_ = threadIdx.x;
+    // (persistent form: the thread index is opaque per tile -- otherwise every lane-dependent constant of the body is hoisted out of the
+    //  tile loop and lives in scratch memory across the K loop: 79 spilled registers)
+    if (PERS) asm volatile("" : "+v"(tid_));
+    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
     const bool mfma_wave = !HELP || wave < NW;                 // wave-uniform
     const int li = lane & 15, lk = lane >> 4;
     const int W = p.Wout, H = p.Hout, TW = W >> 2, TH = H >> 2;
     const int Ws = UPS ? (W >> 1) : W, Hs = UPS ? (H >> 1) : H;
     const int Cin = p.C0 + p.C1;
     int nch = Cin / F4_KC, kb = 0;
-    unsigned bid = blockIdx.x, nblk = gridDim.x;      // (unsigned, like the grid built-ins: the prologue's divisions stay what they were)
+    unsigned bid = wgid, nblk = ngrid;      // (unsigned, like the grid built-ins: the prologue's divisions stay what they were)
     if constexpr (HELP) {
         // split-K (round 6, narrow shapes only: the 8-wave instantiations compile without it): grid copy ks walks chunks [kb, kb + nch) and
         // writes its partial outputs behind those of the copies before it (the launch carries no bias / residual / statistics)
         if (p.ksplit > 1) {
-            nblk = gridDim.x / p.ksplit;
-            const int ks = (int)(blockIdx.x / nblk);
-            bid = blockIdx.x - (unsigned)ks * nblk;
+            nblk = ngrid / p.ksplit;
+            const int ks = (int)(wgid / nblk);
+            bid = wgid - (unsigned)ks * nblk;
             nch /= p.ksplit;
             kb = ks * nch;
             p.out += (int64_t)ks * p.B * H * W * p.Cout;
@@ -402,9 +417,6 @@ __global__ void __launch_bounds__((NW + (NW == 8 ? 0 : NW == 4 ? 3 : 2)) * 64, N
     __syncthreads();
     DLPM_PHASE(p, 8);
 
-#ifdef DLPM_PHASE_TIMING
-    long long _wait = 0;      // cycles this wave spends at the phase barrier (developer builds: slots 16 + wave)
-#endif
 #pragma unroll 1
     for (int chunk = 0; chunk < nch; chunk++) {
         const int cur = chunk & 1, nxt = cur ^ 1;
@@ -768,8 +780,12 @@ __global__ void __launch_bounds__((NW + (NW == 8 ? 0 : NW == 4 ? 3 : 2)) * 64, N
             if (lk == 0) p.stats_out[((int64_t)img0 * ((H * W) / 256) + blk_in_img) * p.Cout + ch] = make_float2(mean, M2);
         }
     }
+    } while (PERS && (wgid += gridDim.x) < ngrid);
     DLPM_PHASE(p, 10);
     DLPM_PHASE_FLUSH(p, 8);
+#ifdef DLPM_PHASE_TIMING
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#endif
 #ifdef DLPM_PHASE_DEFER
     if (p.phase && lane == 0) atomicAdd(p.phase + 16 + wave, (unsigned long long)_wait);
 #endif
@@ -2002,7 +2018,27 @@ static int launch_conv_wino4_nq(const ConvLaunch &c, int nq, int bh, int bw, int
     }
     size_t loop_b = (size_t)(2 * F4_VBUF + 2 * F4_RAWBUF + 2 * F4_CFS) * sizeof(float);
     if (wino4_vsplit() && loop_b < (size_t)8 * 4 * 16 * 64 * sizeof(float)) loop_b = (size_t)8 * 4 * 16 * 64 * sizeof(float);   // the epilogue's exchange buffer
-    fn<<<(unsigned)(mblocks * (c.Cout / F4_NQ)), F4_NT, loop_b, st>>>(c, bh, bw, nimg);
+    const int64_t total = mblocks * (c.Cout / F4_NQ);
+    // DLPM_WINO4_PERSIST=1 (round 6 experiment): one workgroup per CU walking total / CUs tiles (launches of more than two rounds, plain shapes only)
+    static int pers = -1, ncu = 0;
+    if (pers < 0) {
+        const char *e = getenv("DLPM_WINO4_PERSIST"); pers = e ? atoi(e) : 0;
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+    }
+    if (pers && ncu > 0 && total > 2 * ncu && !wino4_vsplit() && fn == (c.ups ? (small ? (KFn)&k_conv3x3_wino4<true, 0, 2> : (KFn)&k_conv3x3_wino4<true>)
+                                                                            : (small ? (KFn)&k_conv3x3_wino4<false, 0, 2> : (KFn)&k_conv3x3_wino4<false>))) {
+        KFn pf = c.ups ? (small ? &k_conv3x3_wino4<true, 0, 2, 0, 0, 8, 1> : &k_conv3x3_wino4<true, 0, F4_QNIT, 0, 0, 8, 1>)
+                       : (small ? &k_conv3x3_wino4<false, 0, 2, 0, 0, 8, 1> : &k_conv3x3_wino4<false, 0, F4_QNIT, 0, 0, 8, 1>);
+        const int r = ensure_dynamic_lds(reinterpret_cast<const void *>(pf), 160 * 1024);
+        if (r != DLPM_OK) return r;
+        ConvLaunch cp = c;
+        cp.pers_total = (int)total;
+        pf<<<(unsigned)ncu, F4_NT, loop_b, st>>>(cp, bh, bw, nimg);
+        DLPM_LAUNCH_CHECK();
+        return DLPM_OK;
+    }
+    fn<<<(unsigned)total, F4_NT, loop_b, st>>>(c, bh, bw, nimg);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;
 }
