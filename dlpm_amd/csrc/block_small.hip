@@ -514,6 +514,13 @@ __global__ void __launch_bounds__(RS_NT, 1) k_attnblock16(AttnSmallLaunch p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ln = lane & 15, lq = lane >> 4;
     const int b = blockIdx.x;
+#ifdef DLPM_PHASE_TIMING      // developer builds: cycles of wave 0 per section (load + GroupNorm | q k v | attention | proj | epilogue), added at the end
+    long long _t = clock64();
+    unsigned long long _sec[5] = {0, 0, 0, 0, 0};
+#define A16_MARK(i) do { const long long _n = clock64(); _sec[i] += (unsigned long long)(_n - _t); _t = _n; } while (0)
+#else
+#define A16_MARK(i)
+#endif
     const int c_gn = min(2 * (tid >> 4) + (tid & 15), AB_C - 1);
     const float pr_gw = p.gn_w[c_gn], pr_gb = p.gn_b[c_gn];
     float pr_bp[4];
@@ -554,6 +561,7 @@ __global__ void __launch_bounds__(RS_NT, 1) k_attnblock16(AttnSmallLaunch p) {
         *reinterpret_cast<float4 *>(xn + pix * AB_LD + c) = make_float4(fmaf(x.x, A.x, Bc.x), fmaf(x.y, A.y, Bc.y), fmaf(x.z, A.z, Bc.z), fmaf(x.w, A.w, Bc.w));
     }
     __syncthreads();
+    A16_MARK(0);
     // this wave's rows of the two GEMMs: pixels 32 wave .. 32 wave + 31 (two pixel tiles)
     const int row0 = 32 * wave;
     int abx[2];
@@ -622,6 +630,7 @@ __global__ void __launch_bounds__(RS_NT, 1) k_attnblock16(AttnSmallLaunch p) {
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) wpj[nt] = reinterpret_cast<const float4 *>(p.wproj)[((int64_t)nt * 4 + h) * 64 + lane];
         __syncthreads();
+        A16_MARK(1);
         // ---- (2) attention of head h: query tiles wave, wave + 8; a_h -> ah
 #pragma unroll 1
         for (int u = wave; u < MT; u += 8) {
@@ -689,6 +698,7 @@ __global__ void __launch_bounds__(RS_NT, 1) k_attnblock16(AttnSmallLaunch p) {
             for (int r = 0; r < 4; r++) ah[(t0 + 4 * lq + r) * A16_ALD + ln] = (o4[0][r] + o4[1][r]) + (o4[2][r] + o4[3][r]);
         }
         __syncthreads();
+        A16_MARK(2);
         // ---- (3) out += a_h Wproj[:, 16 h ..]: one K = 16 fragment per (pixel tile, output tile)
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) {
@@ -701,6 +711,7 @@ __global__ void __launch_bounds__(RS_NT, 1) k_attnblock16(AttnSmallLaunch p) {
                 pacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wpj[nt].w, pacc[mt][nt], 0, 0, 0);
             }
         }
+        A16_MARK(3);
         // (the next head's (1) overwrites qh -- every wave is past (2); its (2) overwrites ah behind the barrier that follows (1))
     }
     // ---- epilogue: out = x + (proj + bias); x is re-read (L2: this workgroup loaded it at entry)
@@ -763,6 +774,14 @@ __global__ void __launch_bounds__(RS_NT, 1) k_attnblock16(AttnSmallLaunch p) {
             p.stats_out[(int64_t)b * AB_C + tid] = make_float2(t * (1.0f / (float)T), q);
         }
     }
+    A16_MARK(4);
+#ifdef DLPM_PHASE_TIMING
+    if (p.phase && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) atomicAdd(p.phase + i, _sec[i]);
+        atomicAdd(p.phase + 5, 1ull);
+    }
+#endif
 }
 
 // OIHW (taps = ks * ks) -> Wf[cout / 16][fragment = tap * Cin / 16 + j][lane = lk * 16 + li][e]:
@@ -838,6 +857,9 @@ int launch_attnblock16(const AttnSmallLaunch &a, hipStream_t st) {
     const size_t lds = (size_t)(T * AB_LD + T * A16_QLD + AB_CH * A16_VLD + T * A16_ALD + 2 * AB_C) * sizeof(float);
     int e = ensure_dynamic_lds(reinterpret_cast<const void *>(&k_attnblock16), 160 * 1024);
     if (e != DLPM_OK) return e;
+#ifdef DLPM_PHASE_TIMING
+    const_cast<AttnSmallLaunch &>(a).phase = phase_buffer();
+#endif
     k_attnblock16<<<(unsigned)a.B, RS_NT, lds, st>>>(a);
     DLPM_LAUNCH_CHECK();
     return DLPM_OK;

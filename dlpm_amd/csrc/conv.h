@@ -199,6 +199,9 @@ struct AttnSmallLaunch {                         // AttentionBlock, 64 channels,
     const float *wproj = nullptr, *bproj = nullptr;  // proj_out (1x1, 64 -> 64), fragment order
     float *out = nullptr;
     float2 *stats_out = nullptr;
+#ifdef DLPM_PHASE_TIMING
+    unsigned long long *phase = nullptr;
+#endif
 };
 bool attn_small_ok(const AttnSmallLaunch &a);
 int launch_attnblock_small(const AttnSmallLaunch &a, hipStream_t st);

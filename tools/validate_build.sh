@@ -5,6 +5,7 @@ tag=${1:-r6}
 mkdir -p gpurun_out/$tag
 python -m pytest tests -m gpu -q -s > gpurun_out/$tag/gpu_tests_verbose.log 2>&1
 tail -3 gpurun_out/$tag/gpu_tests_verbose.log
+python __graft_entry__.py smoke > gpurun_out/$tag/smoke.log 2>&1; tail -1 gpurun_out/$tag/smoke.log
 python bench.py > gpurun_out/$tag/bench_cifar.json 2> gpurun_out/$tag/bench_cifar.err
 python bench.py --workload mnist_unet_b256_T1000 --no-cpu-baseline > gpurun_out/$tag/bench_mnist.json 2>&1
 python bench.py --workload celeba64_unet_b256_T1000 --no-cpu-baseline --steps 20 > gpurun_out/$tag/bench_celeba64_shard.json 2>&1
