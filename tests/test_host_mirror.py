@@ -292,3 +292,38 @@ def test_split_epilogue_ragged_tile_addresses_stay_inside_the_tensor():
                         assert 0 <= read_row < M, (M, wm, kh, i, r, read_row)
                         if row <= rlim:
                             assert m0 + first + row < M
+
+
+def test_declared_batch_semantics_of_the_host_classes():
+    """Round 6: `GenerationManager.generate(models, n)` declares n as the nets' dispatch batch (UNetModel.declare_batch) unless their owner
+    declared a policy explicitly; `declare_batch=False` (what EvaluationManager passes for the chunks of one evaluation) leaves it alone.
+    Host logic only: no native handle is created."""
+    net, _ = build_unet('tiny')
+    assert net._conv_policy == (_lib.CONV_AUTO, 0)
+    net.declare_batch(64)
+    assert net._conv_policy == (_lib.CONV_AUTO, 64)
+    net.declare_batch(8)                                   # the latest undeclared caller wins
+    assert net._conv_policy == (_lib.CONV_AUTO, 8)
+    net.set_conv_policy('f2', 1024)                        # an explicit declaration ...
+    net.declare_batch(8)                                   # ... is never overridden
+    assert net._conv_policy == (_lib.CONV_F2, 1024)
+
+    class Method:
+        device = 'cpu'
+
+        def __init__(self):
+            self.shapes = []
+
+        def sample(self, shape, models, **kw):
+            self.shapes.append(list(shape))
+            raise RuntimeError('stop here')                # (the sampler itself needs the GPU)
+
+    net2, _ = build_unet('tiny')
+    m = Method()
+    gm = dlpm_amd.GenerationManager(m, dlpm_amd.ShapeProbe([3, 16, 16]), True)
+    with pytest.raises(RuntimeError, match='stop here'):
+        gm.generate({'default': net2}, 5)
+    assert net2._conv_policy == (_lib.CONV_AUTO, 5) and m.shapes == [[5, 3, 16, 16]]
+    with pytest.raises(RuntimeError, match='stop here'):
+        gm.generate({'default': net2}, 3, declare_batch=False)
+    assert net2._conv_policy == (_lib.CONV_AUTO, 5)
