@@ -794,13 +794,14 @@ def main():
                        note='algorithmic bytes = read x + read eps + write x (12 B/element, in-kernel Philox); in-loop launch '
                             'time from HIP events (the state was last touched a whole UNet forward earlier: HBM, not cache)')
 
-        # the standalone update launch (k_update_rows): every variant that cannot take the fused head -- --clip, --deterministic, LIM,
+        # the standalone update launch (dlpm_update_f32: k_update_rows, or k_update<VEC> under the clip / DLIM flags): every variant that cannot take the fused head -- --clip, --deterministic, LIM,
         # START_X / Z / PREVIOUS_X -- and the path all bounded parity fixtures run
         uu = prof.get('update') or prof.get('lim_update')
         if uu and ((hf or hu) is None or args.clip or args.deterministic or args.lim):
             gbs = uu['bytes'] / (uu['ms'] * 1e-3) / 1e9
-            upd_unfused = dict(kernel='k_update_lim' if args.lim else ('k_update_rows (x_{t-1} update as its own launch behind the head convolution, Philox noise%s)'
-                                      % (', clip_denoised: x0 predicted, clamped, eps recomputed' if args.clip else ', DLIM' if args.deterministic else '')),
+            upd_unfused = dict(kernel='k_update_lim' if args.lim else ('%s (x_{t-1} update as its own launch behind the head convolution, Philox noise%s)'
+                                      % ('k_update<VEC>' if (args.clip or args.deterministic) else 'k_update_rows',
+                                         ', clip_denoised: x0 predicted, clamped, eps recomputed' if args.clip else ', DLIM' if args.deterministic else '')),
                                bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(gbs / PEAK_HBM_GBS, 4),
                                traffic=None, bytes_per_launch=uu['bytes'] / uu['launches'], avg_launch_ms=round(uu['ms'] / uu['launches'], 5),
                                note='algorithmic bytes = read x + read eps + write x (12 B/element, in-kernel Philox); in-loop launch time from '
